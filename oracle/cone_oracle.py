@@ -1,0 +1,483 @@
+"""CPU ORACLE for the CONE coarse-to-fine inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a functional restatement (torch-CPU fp32 for tensor math, plain
+Python doubles for fusion / NMS exactly as the reference) of the algorithm that
+``/root/reference/cone/inference.py`` drives.  It is written from SURVEY.md and
+from reading the reference; no reference code is copied.  Every function cites
+the reference file:line it follows.
+
+Who may use it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` -- as the checker / the timed CPU port, never as a fallback
+of the product.  Nothing under ``cone_amd/`` imports this module.
+
+Pinning: the reference holds no golden vectors for this path (SURVEY.md section
+4); the oracle is pinned against outputs of the reference itself, imported in the
+build container by ``tests/golden/gen_golden.py`` (fixtures committed under
+``tests/golden/``; ``tests/test_oracle_golden.py`` replays them).  Third-party
+arithmetic (``torch.nn.MultiheadAttention``, ``nn.LayerNorm`` -- torch pinned at
+1.12.1 by the reference's INSTALL.md:24, 2.10 in this image) is restated
+explicitly below from torch's documented semantics.
+
+Known pinned deviation: window-rank ties use the *stable* descending order
+(lower window index first), hazard H6 of SURVEY.md; the golden generator patches
+``torch.sort`` to ``stable=True`` and says so.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- utils
+def as_torch_sd(sd):
+    """numpy / torch state dict -> torch CPU fp32 tensors."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k] = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).float().cpu()
+    return out
+
+
+def l2_normalize_np(x, eps=1e-5):
+    """utils/basic_utils.py:97-99 -- eps is added to the norm."""
+    return x / (np.linalg.norm(x, axis=-1, keepdims=True) + eps)
+
+
+def span_cxw_to_xx(cxw):
+    """cone/span_utils.py:25-41."""
+    x1 = cxw[..., 0] - 0.5 * cxw[..., 1]
+    x2 = cxw[..., 0] + 0.5 * cxw[..., 1]
+    return torch.stack([x1, x2], dim=-1)
+
+
+def span_xx_to_cxw(xx):
+    """cone/span_utils.py:4-22."""
+    return torch.stack([xx.sum(-1) * 0.5, xx[..., 1] - xx[..., 0]], dim=-1)
+
+
+def temporal_iou(s1, s2):
+    """cone/span_utils.py:44-71."""
+    a1 = s1[:, 1] - s1[:, 0]
+    a2 = s2[:, 1] - s2[:, 0]
+    left = torch.max(s1[:, None, 0], s2[:, 0])
+    right = torch.min(s1[:, None, 1], s2[:, 1])
+    inter = (right - left).clamp(min=0)
+    union = a1[:, None] + a2 - inter
+    return inter / union, union
+
+
+def generalized_temporal_iou(s1, s2):
+    """cone/span_utils.py:90-122."""
+    iou, union = temporal_iou(s1.float(), s2.float())
+    left = torch.min(s1[:, None, 0], s2[:, 0])
+    right = torch.max(s1[:, None, 1], s2[:, 1])
+    enclosing = (right - left).clamp(min=0)
+    return iou - (enclosing - union) / enclosing
+
+
+def window_bounds(i, ctx_l, max_v_l):
+    """Window i of a video of ctx_l clips (cone/inference.py:286-292, H1):
+    stride S=int(W/2); window 0 is the half window [0, S)."""
+    s = int(max_v_l / 2)
+    return max((i - 1) * s, 0), min((i - 1) * s + max_v_l, ctx_l)
+
+
+def num_windows(ctx_l, max_v_l):
+    return math.ceil(ctx_l / int(max_v_l / 2)) + 1
+
+
+# ------------------------------------------------------------------ stage A (A1-A4)
+def mlp(x, sd, prefix, n_layers):
+    """cone/model.py:428-440."""
+    for i in range(n_layers):
+        x = F.linear(x, sd[f"{prefix}.layers.{i}.weight"], sd[f"{prefix}.layers.{i}.bias"])
+        if i < n_layers - 1:
+            x = F.relu(x)
+    return x
+
+
+def adapter_norm(sd, vid, adapter_module="linear"):
+    """A2: cone/inference.py:250-260 -- y = adapter(x) + x; y /= ||y|| (no eps)."""
+    if adapter_module != "linear":
+        return vid
+    y = mlp(vid, sd, "adapter_layer", 2) + vid
+    return y / y.norm(dim=-1, keepdim=True)
+
+
+def frame_scores(vid_ctx, cls_txt):
+    """A3: cone/inference.py:284 -- einsum('db,b->d')."""
+    return torch.einsum("db,b->d", vid_ctx, cls_txt)
+
+
+def window_scores(fscore, max_v_l):
+    """A4: cone/inference.py:285-296 -- max of the frame scores inside each window."""
+    ctx_l = fscore.shape[0]
+    nw = num_windows(ctx_l, max_v_l)
+    out = torch.empty(nw, dtype=torch.float32)
+    for i in range(nw):
+        s, e = window_bounds(i, ctx_l, max_v_l)
+        out[i] = torch.max(fscore[s:e])
+    return out
+
+
+def rank_windows(wscore):
+    """A4: cone/inference.py:297-299 with the tie order pinned to stable descending (H6)."""
+    _, idx = torch.sort(wscore, descending=True, stable=True)
+    return idx.tolist()
+
+
+# ------------------------------------------------------------------ stage B (A5-A12)
+def pad_sequences_1d(seqs):
+    """utils/tensor_utils.py:5-53 for a list of 2-D fp32 tensors: zero pad to the
+    longest, float mask 1=valid."""
+    lengths = [len(s) for s in seqs]
+    L = max(lengths)
+    out = torch.zeros((len(seqs), L) + tuple(seqs[0].shape[1:]), dtype=torch.float32)
+    mask = torch.zeros((len(seqs), L), dtype=torch.float32)
+    for i, s in enumerate(seqs):
+        out[i, :lengths[i]] = s
+        mask[i, :lengths[i]] = 1
+    return out, mask
+
+
+def layer_norm(x, sd, prefix, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def input_proj(x, sd, name, n_input_proj):
+    """A6: cone/model.py:58-73, 443-465 -- LN -> Linear -> ReLU (all but the last layer)."""
+    for i in range(n_input_proj):
+        x = layer_norm(x, sd, f"{name}.{i}.LayerNorm")
+        x = F.linear(x, sd[f"{name}.{i}.net.1.weight"], sd[f"{name}.{i}.net.1.bias"])
+        if i != n_input_proj - 1:
+            x = F.relu(x)
+    return x
+
+
+def sine_position(mask, num_pos_feats, temperature=10000, scale=2 * math.pi):
+    """A7: cone/position_encoding.py:51-72 (normalize=True)."""
+    x_embed = mask.cumsum(1, dtype=torch.float32)
+    x_embed = x_embed / (x_embed[:, -1:] + 1e-6) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos = x_embed[:, :, None] / dim_t
+    return torch.stack((pos[:, :, 0::2].sin(), pos[:, :, 1::2].cos()), dim=3).flatten(2)
+
+
+def mha(sd, prefix, q_in, k_in, v_in, nheads, key_pad=None):
+    """torch.nn.MultiheadAttention forward (eval, need_weights irrelevant) as used at
+    cone/transformer.py:239-240, 304-311, restated batch-first.
+
+    q_in (B,Lq,d), k_in/v_in (B,Lk,d); key_pad (B,Lk) bool, True = padded key.
+    Packed in_proj rows [0:d]=W_q, [d:2d]=W_k, [2d:3d]=W_v; q is scaled by
+    sqrt(1/head_dim) *after* the projection; padded keys get -inf before softmax."""
+    w, b = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    d = w.shape[1]
+    hd = d // nheads
+    q = F.linear(q_in, w[:d], b[:d])
+    k = F.linear(k_in, w[d:2 * d], b[d:2 * d])
+    v = F.linear(v_in, w[2 * d:], b[2 * d:])
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    q = q.view(B, Lq, nheads, hd).transpose(1, 2) * math.sqrt(1.0 / float(hd))
+    k = k.view(B, Lk, nheads, hd).transpose(1, 2)
+    v = v.view(B, Lk, nheads, hd).transpose(1, 2)
+    att = q @ k.transpose(-1, -2)
+    if key_pad is not None:
+        att = att + torch.zeros(B, 1, 1, Lk).masked_fill(key_pad[:, None, None, :], float("-inf"))
+    att = torch.softmax(att, dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, Lq, d)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def encoder_layer(sd, p, x, pos, key_pad, nheads):
+    """A9: cone/transformer.py:233-246 (post-norm)."""
+    qk = x + pos
+    x = layer_norm(x + mha(sd, p + ".self_attn", qk, qk, x, nheads, key_pad), sd, p + ".norm1")
+    h = F.linear(F.relu(F.linear(x, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return layer_norm(x + h, sd, p + ".norm2")
+
+
+def decoder_layer(sd, p, tgt, memory, pos, query_pos, key_pad, nheads):
+    """A10: cone/transformer.py:296-317 (post-norm)."""
+    qk = tgt + query_pos
+    tgt = layer_norm(tgt + mha(sd, p + ".self_attn", qk, qk, tgt, nheads), sd, p + ".norm1")
+    tgt = layer_norm(tgt + mha(sd, p + ".multihead_attn", tgt + query_pos, memory + pos, memory,
+                               nheads, key_pad), sd, p + ".norm2")
+    h = F.linear(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return layer_norm(tgt + h, sd, p + ".norm3")
+
+
+def cone_forward(sd, opt, src_txt, src_txt_mask, src_vid_motion, src_vid_motion_mask,
+                 return_intermediates=False):
+    """A6-A11: ``CONE.forward`` (cone/model.py:82-128) + ``Transformer.forward``
+    (cone/transformer.py:49-73), batch-first."""
+    H = opt.nheads
+    src_vid = input_proj(src_vid_motion, sd, "input_vid_proj", opt.n_input_proj)
+    src_txt_p = input_proj(src_txt, sd, "input_txt_proj", opt.n_input_proj)
+    src = torch.cat([src_vid, src_txt_p], dim=1)
+    mask = torch.cat([src_vid_motion_mask, src_txt_mask], dim=1).bool()
+    pos_vid = sine_position(src_vid_motion_mask, opt.hidden_dim)
+    pos = torch.cat([pos_vid, torch.zeros_like(src_txt_p)], dim=1)
+    key_pad = ~mask
+    x = src
+    for i in range(opt.enc_layers):
+        x = encoder_layer(sd, f"transformer.encoder.layers.{i}", x, pos, key_pad, H)
+    memory = x
+    B = src.shape[0]
+    query_pos = sd["query_embed.weight"][None].expand(B, -1, -1)
+    tgt = torch.zeros_like(query_pos)
+    hs = []
+    for i in range(opt.dec_layers):
+        tgt = decoder_layer(sd, f"transformer.decoder.layers.{i}", tgt, memory, pos, query_pos,
+                            key_pad, H)
+        hs.append(layer_norm(tgt, sd, "transformer.decoder.norm"))
+    hs = torch.stack(hs)  # (layers, B, Nq, d)
+    logits = F.linear(hs, sd["class_embed.weight"], sd["class_embed.bias"])
+    coord = mlp(hs, sd, "span_embed", 3).sigmoid()
+    Lv = src_vid.shape[1]
+    sal = F.linear(memory[:, :Lv], sd["saliency_proj.weight"], sd["saliency_proj.bias"]).squeeze(-1)
+    out = {"pred_logits": logits[-1], "pred_spans": coord[-1], "saliency_scores": sal}
+    if getattr(opt, "aux_loss", True):
+        out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b}
+                              for a, b in zip(logits[:-1], coord[:-1])]
+    if return_intermediates:
+        out["memory"] = memory
+        out["hs"] = hs
+        out["src"] = src
+        out["pos"] = pos
+    return out
+
+
+def proposal_slices(pred_spans, mask):
+    """cone/model.py:186-192: integer [start, end) of every proposal on the padded window."""
+    duration = torch.sum(mask, dim=-1)
+    prop = torch.einsum("bld,b->bld", span_cxw_to_xx(pred_spans), duration)
+    start = F.relu(torch.floor(prop[:, :, 0]).to(torch.int32))
+    end = torch.ceil(prop[:, :, 1]).to(torch.int32)
+    return start, end, prop
+
+
+def clip_matching(sd, opt, src_cls_txt, src_vid_appear, src_vid_appear_mask, proposal):
+    """A12: ``CONE.forward_clip_matching`` (cone/model.py:130-152, 178-210).  The mean is
+    taken over ``feat[s:e]`` of the ZERO-PADDED tensor, so it depends on the padded
+    length of the batch (H3)."""
+    txt = src_cls_txt / src_cls_txt.norm(dim=1, keepdim=True)
+    start, end, _ = proposal_slices(proposal, src_vid_appear_mask)
+    B, Nq = start.shape
+    feats = []
+    for b in range(B):
+        for n in range(Nq):
+            feats.append(src_vid_appear[b, int(start[b, n]):int(end[b, n])].mean(dim=0))
+    pf = torch.stack(feats)
+    if opt.adapter_module == "linear":
+        pf = mlp(pf, sd, "adapter_layer", 2) + pf
+    pf = pf.reshape(B, Nq, -1)
+    pf = pf / pf.norm(dim=2, keepdim=True)
+    return torch.einsum("bld,bd->bl", pf, txt)
+
+
+def compose_rows(opt, pred_logits, pred_spans, matching, durations, video_starts):
+    """A13: cone/inference.py:47-91 -- per window (Nq,4) fp32 rows [st, ed, prop, match]
+    sorted by proposal score (stable, descending) unless --no_sort_results; rounding to
+    4 decimals is applied by :func:`round4_rows`."""
+    prob = F.softmax(pred_logits, -1)[..., 0]
+    out = []
+    for b in range(pred_spans.shape[0]):
+        spans = (span_cxw_to_xx(pred_spans[b]) * int(durations[b]) + int(video_starts[b])) * opt.clip_length
+        rows = torch.cat([spans, prob[b][:, None], matching[b][:, None]], dim=1).tolist()
+        if not opt.no_sort_results:
+            rows = sorted(rows, key=lambda r: r[2], reverse=True)
+        out.append(rows)
+    return out
+
+
+def round4_rows(rows):
+    """cone/inference.py:83 -- float(f"{e:.4f}") (H4)."""
+    return [[float(f"{e:.4f}") for e in r] for r in rows]
+
+
+# ------------------------------------------------------------------ stage C (A14-A16)
+def normalize_score(vals):
+    """utils/basic_utils.py:10-20."""
+    amin, amax = min(vals), max(vals)
+    if amin == amax:
+        return vals
+    return [(v - amin) / (amax - amin) for v in vals]
+
+
+def score_fusion(prediction):
+    """A14: cone/inference.py:205-217 -- dict keyed by (st, ed): duplicates collapse,
+    last value wins, first position kept (H5)."""
+    ret = {}
+    a = normalize_score([p[2] for p in prediction])
+    m = normalize_score([p[3] for p in prediction])
+    for item, fa, fm in zip(prediction, a, m):
+        ret[(item[0], item[1])] = [item[2], item[3], sum((fa, fm))]
+    return ret
+
+
+def compute_temporal_iou(pred, gt):
+    """utils/temporal_nms.py:6-22 -- pseudo union max(end)-min(start) (H7)."""
+    inter = max(0, min(pred[1], gt[1]) - max(pred[0], gt[0]))
+    union = max(pred[1], gt[1]) - min(pred[0], gt[0])
+    return 0 if union == 0 else 1.0 * inter / union
+
+
+def temporal_nms(predictions, nms_thd, max_after_nms=100):
+    """A15: utils/temporal_nms.py:25-74, restated as the equivalent greedy scan:
+    stable sort by score (descending); keep a candidate iff no kept one overlaps it by
+    more than nms_thd (strict); stop at max_after_nms."""
+    if len(predictions) == 1:
+        return predictions
+    cand = sorted(predictions, key=lambda x: x[2], reverse=True)
+    kept = []
+    alive = [True] * len(cand)
+    for i, c in enumerate(cand):
+        if len(kept) >= max_after_nms:
+            break
+        if not alive[i]:
+            continue
+        kept.append(c)
+        for j in range(i + 1, len(cand)):
+            if alive[j] and compute_temporal_iou(c, cand[j]) > nms_thd:
+                alive[j] = False
+    return [[c[0], c[1], c[2]] for c in kept]
+
+
+def post_processing_mr_nms(opt, return_dict, idx):
+    """cone/inference.py:103-127."""
+    moments = [[k[0], k[1], v[idx]] for k, v in return_dict.items()]
+    moments = sorted(moments, key=lambda x: x[2], reverse=True)
+    before = [[m[0], m[1]] + return_dict[(m[0], m[1])] for m in moments]
+    if opt.nms_thd != -1:
+        after = temporal_nms(moments[:opt.max_before_nms], opt.nms_thd, opt.max_after_nms)
+        return [[m[0], m[1]] + return_dict[(m[0], m[1])] for m in after]
+    return before[:opt.max_after_nms]
+
+
+def postprocess(submission, opt):
+    """A16: cone/inference.py:130-202 -- group window-level rows by query, fuse, 3x NMS."""
+    qid2 = OrderedDict()
+    for item in submission:
+        qid = item["query_id"]
+        if qid not in qid2:
+            if opt.dset_name == "ego4d":
+                parts = qid.split("_")
+                assert len(parts) == 2
+                qid2[qid] = {"query_idx": int(parts[1]), "annotation_uid": parts[0],
+                             "predicted_times": [], "clip_uid": item["clip_id"]}
+            else:
+                qid2[qid] = {"query_id": qid, "predicted_times": [], "video_id": item["video_id"]}
+        qid2[qid]["predicted_times"].extend(item["pred_relevant_windows"])
+    fusion, proposal, matching = [], [], []
+    for item in qid2.values():
+        rd = score_fusion(item["predicted_times"])
+        for lst, idx in ((fusion, 2), (proposal, 0), (matching, 1)):
+            o = item.copy()
+            o["predicted_times"] = post_processing_mr_nms(opt, rd, idx)
+            lst.append(o)
+    return fusion, proposal, matching
+
+
+# ------------------------------------------------------------------- A17 (matcher cost)
+def matcher_cost(opt_costs, pred_logits, pred_spans, tgt_spans):
+    """cone/matcher.py:61-95 cost matrix C = span*L1 + giou*(-GIoU) + class*(-p_fg).
+    opt_costs = (cost_span, cost_giou, cost_class)."""
+    cs, cg, cc = opt_costs
+    prob = pred_logits.flatten(0, 1).softmax(-1)
+    cost_class = -prob[:, [0] * len(tgt_spans)]
+    out_spans = pred_spans.flatten(0, 1)
+    cost_span = torch.cdist(out_spans, tgt_spans, p=1)
+    cost_giou = -generalized_temporal_iou(span_cxw_to_xx(out_spans), span_cxw_to_xx(tgt_spans))
+    return cs * cost_span + cg * cost_giou + cc * cost_class
+
+
+# ------------------------------------------------------------------ whole path driver
+def prepare_query_inputs(opt, q):
+    """StartEndDataset._get_query_feat_by_qid (cone/ego4d_mad_dataloader.py:258-282):
+    tokens truncated to max_q_l and L2-normalised (+eps); cls normalised (+eps)."""
+    tok = np.asarray(q["token_features"], dtype=np.float32)[:opt.max_q_l]
+    tok = l2_normalize_np(tok).astype(np.float32)
+    cls = np.asarray(q.get("cls_features", q.get("eot_features")), dtype=np.float32)
+    if cls.ndim == 2:
+        cls = cls[0]
+    cls = l2_normalize_np(cls).astype(np.float32)
+    return torch.from_numpy(tok), torch.from_numpy(cls)
+
+
+def prefilter(sd, opt, ann, video_feats, query_feats):
+    """Stage A over a split: returns query_id -> full window rank list and the window
+    scores (cone/inference.py:241-301)."""
+    sd = as_torch_sd(sd)
+    ctx_cache, ranks, scores = {}, OrderedDict(), OrderedDict()
+    for row in ann:
+        cid = row["clip_id"]
+        if cid not in ctx_cache:
+            v = torch.from_numpy(l2_normalize_np(np.asarray(video_feats[cid], dtype=np.float32)).astype(np.float32))
+            ctx_cache[cid] = adapter_norm(sd, v, opt.adapter_module)
+        _, cls = prepare_query_inputs(opt, query_feats[row["query_id"]])
+        ws = window_scores(frame_scores(ctx_cache[cid], cls), opt.max_v_l)
+        scores[row["query_id"]] = ws
+        ranks[row["query_id"]] = rank_windows(ws)
+    return ranks, scores
+
+
+def build_batch(opt, ann_rows, video_feats, query_feats, ranks):
+    """A5: eval branch of StartEndDataset.__getitem__ + start_end_collate
+    (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-358).  Model-side video features
+    are the RAW ones (H2)."""
+    metas, vids, txts, clss = [], [], [], []
+    for row in ann_rows:
+        tok, cls = prepare_query_inputs(opt, query_feats[row["query_id"]])
+        v = torch.from_numpy(np.asarray(video_feats[row["clip_id"]], dtype=np.float32))
+        ctx_l = v.shape[0]
+        for w in ranks[row["query_id"]][:opt.topk_window]:
+            s, e = window_bounds(w, ctx_l, opt.max_v_l)
+            vids.append(v[s:e])
+            txts.append(tok)
+            clss.append(cls)
+            m = dict(row)
+            m["duration"] = e - s
+            m["video_start"] = s
+            metas.append(m)
+    src_vid, vid_mask = pad_sequences_1d(vids)
+    src_txt, txt_mask = pad_sequences_1d(txts)
+    return metas, dict(src_txt=src_txt, src_txt_mask=txt_mask, src_vid_motion=src_vid,
+                       src_vid_motion_mask=vid_mask), dict(
+        src_cls_txt=torch.stack(clss), src_vid_appear=src_vid.clone(), src_vid_appear_mask=vid_mask.clone())
+
+
+def compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks, capture=None):
+    """cone/inference.py:30-100 with the DataLoader batching of eval_bsz queries."""
+    sd = as_torch_sd(sd)
+    mr_res = []
+    for b0 in range(0, len(ann), opt.eval_bsz):
+        rows = ann[b0:b0 + opt.eval_bsz]
+        metas, mi, ci = build_batch(opt, rows, video_feats, query_feats, ranks)
+        out = cone_forward(sd, opt, **mi)
+        match = clip_matching(sd, opt, proposal=out["pred_spans"], **ci)
+        if capture is not None:
+            capture.append(dict(model_inputs=mi, clip_inputs=ci, outputs=out, matching=match, metas=metas))
+        comp = compose_rows(opt, out["pred_logits"], out["pred_spans"], match,
+                            [m["duration"] for m in metas], [m["video_start"] for m in metas])
+        for m, r in zip(metas, comp):
+            mr_res.append(dict(query_id=m["query_id"], query=m["query"], video_id=m["video_id"],
+                               clip_id=m["clip_id"], pred_relevant_windows=round4_rows(r)))
+        if opt.debug:
+            break
+    return mr_res
+
+
+def eval_epoch(sd, opt, ann, video_feats, query_feats):
+    """Stages A->C on an in-memory split; returns the three submission lists
+    (fusion, proposal, matching) and the rank lists."""
+    with torch.no_grad():
+        ranks, _ = prefilter(sd, opt, ann, video_feats, query_feats)
+        mr = compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks)
+    return postprocess(mr, opt), ranks, mr
