@@ -1,0 +1,158 @@
+"""ctypes binding of libcone_hip.so (include/cone_hip.h).
+
+This is the whole FFI surface: every product code path goes through these calls, and a
+missing / unbuilt library is a hard error (there is no CPU fallback anywhere in cone_amd).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcone_hip.so")
+
+MAX_LAYERS = 8
+MAX_PROJ = 3
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class LNorm(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("b", C.c_void_p)]
+
+
+class Mha(C.Structure):
+    _fields_ = [("in_proj_w", C.c_void_p), ("in_proj_b", C.c_void_p), ("out_proj", Linear)]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [("self_attn", Mha), ("linear1", Linear), ("linear2", Linear), ("norm1", LNorm),
+                ("norm2", LNorm)]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [("self_attn", Mha), ("cross_attn", Mha), ("linear1", Linear), ("linear2", Linear),
+                ("norm1", LNorm), ("norm2", LNorm), ("norm3", LNorm)]
+
+
+class Weights(C.Structure):
+    _fields_ = [
+        ("hidden_dim", C.c_int32), ("nheads", C.c_int32), ("dim_ff", C.c_int32), ("enc_layers", C.c_int32),
+        ("dec_layers", C.c_int32), ("num_queries", C.c_int32), ("n_input_proj", C.c_int32),
+        ("t_dim", C.c_int32), ("v_dim", C.c_int32), ("has_adapter", C.c_int32),
+        ("vid_proj_ln", LNorm * MAX_PROJ), ("vid_proj", Linear * MAX_PROJ),
+        ("txt_proj_ln", LNorm * MAX_PROJ), ("txt_proj", Linear * MAX_PROJ),
+        ("enc", EncLayer * MAX_LAYERS), ("dec", DecLayer * MAX_LAYERS),
+        ("dec_norm", LNorm), ("query_embed", C.c_void_p), ("class_embed", Linear),
+        ("span_embed", Linear * 3), ("saliency_proj", Linear), ("adapter", Linear * 2),
+        ("pos_dim_t", C.c_void_p),
+    ]
+
+
+class Taps(C.Structure):
+    _fields_ = [("memory", C.c_void_p), ("hs", C.c_void_p), ("aux_logits", C.c_void_p),
+                ("aux_spans", C.c_void_p)]
+
+
+_SIGNATURES = {
+    "cone_last_error": (C.c_char_p, []),
+    "cone_abi_version": (C.c_int, []),
+    "cone_model_create": (C.c_int, [C.POINTER(Weights), C.POINTER(C.c_void_p)]),
+    "cone_model_destroy": (None, [C.c_void_p]),
+    "cone_adapter_norm_workspace": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "cone_adapter_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "cone_l2_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "cone_num_windows": (C.c_int64, [C.c_int64, C.c_int]),
+    "cone_prefilter_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_topk_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),
+    "cone_project_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "cone_forward_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cone_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Taps),
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_forward_packed_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cone_forward_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(Taps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_clip_matching_workspace": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "cone_clip_matching_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_clip_matching": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_compose_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cone_fuse_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_fuse_nms_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_temporal_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "cone_matcher_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # cone_test_gemm(A, A2, a2_mod, W, bias, R, ln_g, ln_b, C, M, N, K, flags, stream)
+    "cone_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "cone_test_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                      C.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class ConeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcone_hip.so; raises if it has not been built (python -m cone_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ConeHipError(
+            f"{LIB_PATH} is missing: build the HIP extension with `python -m cone_amd.build` "
+            "(hipcc, gfx950). cone_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cone_abi_version() != 1:
+        raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise ConeHipError(f"libcone_hip error {rc}: {load().cone_last_error().decode()}")
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    import torch
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ConeHipError("expected a tensor on the GPU")
+    if not t.is_contiguous():
+        raise ConeHipError("expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise ConeHipError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,508 @@
+// Model handle, workspace carving and the launch sequences behind the C ABI (include/cone_hip.h).
+//
+// The window model runs on PACKED tokens: window b owns rows off[b] .. off[b+1] of every (M,*)
+// activation matrix (its valid video clips, then its valid text tokens).  Padded keys never exist,
+// so no masks are needed, and every dense layer is one tall GEMM over all windows of the batch.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace cone {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Linear { const float* w = nullptr; const float* b = nullptr; };
+struct LNorm { const float* g = nullptr; const float* b = nullptr; };
+struct Mha { const float* in_w = nullptr; const float* in_b = nullptr; Linear out; };
+struct EncLayer { Mha sa; Linear l1, l2; LNorm n1, n2; };
+struct DecLayer { Mha sa, ca; Linear l1, l2; LNorm n1, n2, n3; };
+
+}  // namespace cone
+
+struct cone_model {
+    int d, heads, ff, n_enc, n_dec, nq, n_proj, dt, dv, has_adapter;
+    float* arena = nullptr;  // every weight, one allocation
+    cone::LNorm vproj_ln[CONE_MAX_PROJ], tproj_ln[CONE_MAX_PROJ];
+    cone::Linear vproj[CONE_MAX_PROJ], tproj[CONE_MAX_PROJ];
+    cone::EncLayer enc[CONE_MAX_LAYERS];
+    cone::DecLayer dec[CONE_MAX_LAYERS];
+    cone::LNorm dec_norm;
+    const float* query_embed = nullptr;
+    cone::Linear class_embed, span[3], saliency, adapter[2];
+    const float* dim_t = nullptr;
+    // derived: the cross-attention K / V projections of all decoder layers stacked along N
+    cone::Linear dec_k, dec_v;
+};
+
+namespace cone {
+
+// ------------------------------------------------------------------------------ weights
+struct ArenaBuilder {
+    struct Item { const float* src; size_t n; const float** dst; };
+    std::vector<Item> items;
+    size_t total = 0;
+    void add(const float* src, size_t n, const float** dst) {
+        items.push_back({src, n, dst});
+        total += align_up(n, 64);
+    }
+};
+
+static int build_model(const cone_weights* w, cone_model** out) {
+    CONE_REQUIRE(w && out, "model_create: null argument");
+    CONE_REQUIRE(w->hidden_dim == 256 && w->nheads == 8,
+                 "model_create: kernels are built for hidden_dim=256, nheads=8 (got %d, %d)", w->hidden_dim,
+                 w->nheads);
+    CONE_REQUIRE(w->dim_ff % 128 == 0 && w->dim_ff >= 128, "model_create: dim_feedforward=%d must be a multiple of 128", w->dim_ff);
+    CONE_REQUIRE(w->enc_layers >= 1 && w->enc_layers <= CONE_MAX_LAYERS && w->dec_layers >= 1 &&
+                     w->dec_layers <= CONE_MAX_LAYERS, "model_create: layer counts out of range");
+    CONE_REQUIRE(w->num_queries >= 1 && w->num_queries <= 8, "model_create: num_queries=%d not in [1,8]", w->num_queries);
+    CONE_REQUIRE(w->n_input_proj >= 1 && w->n_input_proj <= CONE_MAX_PROJ, "model_create: n_input_proj out of range");
+    CONE_REQUIRE(w->t_dim % 32 == 0 && w->v_dim % 32 == 0 && w->t_dim <= 1024 && w->v_dim <= 1024,
+                 "model_create: feature dims must be multiples of 32 and <= 1024 (t=%d v=%d)", w->t_dim, w->v_dim);
+    cone_model* m = new cone_model();
+    m->d = 256; m->heads = 8; m->ff = w->dim_ff; m->n_enc = w->enc_layers; m->n_dec = w->dec_layers;
+    m->nq = w->num_queries; m->n_proj = w->n_input_proj; m->dt = w->t_dim; m->dv = w->v_dim;
+    m->has_adapter = w->has_adapter;
+    const size_t d = 256, ff = m->ff;
+    ArenaBuilder ab;
+    auto lin = [&](const cone_linear_w& s, size_t nout, size_t nin, Linear& dst) {
+        ab.add(s.w, nout * nin, &dst.w);
+        ab.add(s.b, nout, &dst.b);
+    };
+    auto ln = [&](const cone_ln_w& s, size_t n, LNorm& dst) { ab.add(s.g, n, &dst.g); ab.add(s.b, n, &dst.b); };
+    auto mha = [&](const cone_mha_w& s, Mha& dst) {
+        ab.add(s.in_proj_w, 3 * d * d, &dst.in_w);
+        ab.add(s.in_proj_b, 3 * d, &dst.in_b);
+        lin(s.out_proj, d, d, dst.out);
+    };
+    for (int i = 0; i < m->n_proj; ++i) {
+        ln(w->vid_proj_ln[i], i == 0 ? m->dv : d, m->vproj_ln[i]);
+        lin(w->vid_proj[i], d, i == 0 ? m->dv : d, m->vproj[i]);
+        ln(w->txt_proj_ln[i], i == 0 ? m->dt : d, m->tproj_ln[i]);
+        lin(w->txt_proj[i], d, i == 0 ? m->dt : d, m->tproj[i]);
+    }
+    for (int i = 0; i < m->n_enc; ++i) {
+        mha(w->enc[i].self_attn, m->enc[i].sa);
+        lin(w->enc[i].linear1, ff, d, m->enc[i].l1);
+        lin(w->enc[i].linear2, d, ff, m->enc[i].l2);
+        ln(w->enc[i].norm1, d, m->enc[i].n1);
+        ln(w->enc[i].norm2, d, m->enc[i].n2);
+    }
+    for (int i = 0; i < m->n_dec; ++i) {
+        mha(w->dec[i].self_attn, m->dec[i].sa);
+        mha(w->dec[i].cross_attn, m->dec[i].ca);
+        lin(w->dec[i].linear1, ff, d, m->dec[i].l1);
+        lin(w->dec[i].linear2, d, ff, m->dec[i].l2);
+        ln(w->dec[i].norm1, d, m->dec[i].n1);
+        ln(w->dec[i].norm2, d, m->dec[i].n2);
+        ln(w->dec[i].norm3, d, m->dec[i].n3);
+    }
+    ln(w->dec_norm, d, m->dec_norm);
+    ab.add(w->query_embed, (size_t)m->nq * d, &m->query_embed);
+    lin(w->class_embed, 2, d, m->class_embed);
+    lin(w->span_embed[0], d, d, m->span[0]);
+    lin(w->span_embed[1], d, d, m->span[1]);
+    lin(w->span_embed[2], 2, d, m->span[2]);
+    lin(w->saliency_proj, 1, d, m->saliency);
+    if (m->has_adapter) {
+        lin(w->adapter[0], d, m->dv, m->adapter[0]);
+        lin(w->adapter[1], m->dv, d, m->adapter[1]);
+    }
+    ab.add(w->pos_dim_t, d, &m->dim_t);
+    for (auto& it : ab.items)
+        if (!it.src) {
+            delete m;
+            set_error("model_create: a required weight pointer is null");
+            return CONE_E_INVALID;
+        }
+    const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64;
+    hipError_t e = hipMalloc((void**)&m->arena, (ab.total + stacked) * sizeof(float));
+    if (e != hipSuccess) {
+        delete m;
+        set_error("model_create: hipMalloc of %zu bytes failed: %s", (ab.total + stacked) * sizeof(float),
+                  hipGetErrorString(e));
+        return CONE_E_HIP;
+    }
+    size_t cur = 0;
+    for (auto& it : ab.items) {
+        e = hipMemcpy(m->arena + cur, it.src, it.n * sizeof(float), hipMemcpyDefault);
+        if (e != hipSuccess) {
+            (void)hipFree(m->arena);
+            delete m;
+            set_error("model_create: weight copy failed: %s", hipGetErrorString(e));
+            return CONE_E_HIP;
+        }
+        *it.dst = m->arena + cur;
+        cur += align_up(it.n, 64);
+    }
+    // stack W_k / W_v (rows [d:2d] / [2d:3d] of each layer's multihead_attn.in_proj) along N
+    float* kw = m->arena + cur; cur += align_up((size_t)m->n_dec * d * d, 64);
+    float* kb = m->arena + cur; cur += align_up((size_t)m->n_dec * d, 64);
+    float* vw = m->arena + cur; cur += align_up((size_t)m->n_dec * d * d, 64);
+    float* vb = m->arena + cur; cur += align_up((size_t)m->n_dec * d, 64);
+    for (int i = 0; i < m->n_dec; ++i) {
+        const float* iw = m->dec[i].ca.in_w;
+        const float* ib = m->dec[i].ca.in_b;
+        (void)hipMemcpy(kw + (size_t)i * d * d, iw + d * d, d * d * sizeof(float), hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(kb + (size_t)i * d, ib + d, d * sizeof(float), hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(vw + (size_t)i * d * d, iw + 2 * d * d, d * d * sizeof(float), hipMemcpyDeviceToDevice);
+        e = hipMemcpy(vb + (size_t)i * d, ib + 2 * d, d * sizeof(float), hipMemcpyDeviceToDevice);
+    }
+    if (e != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(m->arena);
+        delete m;
+        set_error("model_create: stacking decoder K/V weights failed");
+        return CONE_E_HIP;
+    }
+    m->dec_k = {kw, kb};
+    m->dec_v = {vw, vb};
+    *out = m;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ workspace
+struct Carver {
+    char* base; size_t cap, cur = 0; bool ok = true;
+    Carver(void* p, size_t n) : base((char*)p), cap(n) {}
+    template <typename T> T* take(size_t n) {
+        const size_t bytes = align_up(n * sizeof(T), 256);
+        T* r = (T*)(base + cur);
+        cur += bytes;
+        if (cur > cap) ok = false;
+        return r;
+    }
+};
+
+static GemmArgs G(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                  const int* M_dev, int N, int K, int flags = 0) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.M_dev = M_dev; g.N = N; g.K = K; g.flags = flags;
+    return g;
+}
+
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// input_{vid,txt}_proj: LN -> Linear -> ReLU (all but last) with the next LN fused into the GEMM epilogue.
+static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
+    const size_t din = which == 0 ? m->dv : m->dt;
+    return align_up(n * din * 4, 256) + 2 * align_up(n * 256 * 4, 256);
+}
+static int project_tokens(const cone_model* m, int which, const float* x, int64_t n, float* out, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+    CONE_REQUIRE(n < (1ll << 31), "project: too many rows");
+    const int din = which == 0 ? m->dv : m->dt;
+    const LNorm* lns = which == 0 ? m->vproj_ln : m->tproj_ln;
+    const Linear* lin = which == 0 ? m->vproj : m->tproj;
+    Carver c(ws, ws_bytes);
+    float* t0 = c.take<float>((size_t)n * din);
+    float* ta = c.take<float>((size_t)n * 256);
+    float* tb = c.take<float>((size_t)n * 256);
+    if (!c.ok) { set_error("project: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    RUN(launch_layernorm(x, din, lns[0].g, lns[0].b, t0, din, n, nullptr, din, s));
+    const float* cur = t0;
+    int K = din;
+    for (int i = 0; i < m->n_proj; ++i) {
+        const bool last = i == m->n_proj - 1;
+        float* dst = last ? out : (cur == ta ? tb : ta);
+        GemmArgs g = G(cur, K, lin[i].w, K, lin[i].b, dst, 256, (int)n, nullptr, 256, K, last ? 0 : EPI_RELU);
+        if (!last) { g.flags |= EPI_LN; g.ln_g = lns[i + 1].g; g.ln_b = lns[i + 1].b; }
+        RUN(launch_gemm(g, s));
+        cur = dst;
+        K = 256;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ packed forward
+struct FwdBuffers {
+    int* off;
+    float *X, *POS, *QK, *V, *ATT, *X1, *H, *KD, *VD;
+    float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP;
+};
+static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, FwdBuffers& f) {
+    const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
+    f.off = c.take<int>(B + 1);
+    f.X = c.take<float>(M * 256); f.POS = c.take<float>(M * 256); f.QK = c.take<float>(M * 512);
+    f.V = c.take<float>(M * 256); f.ATT = c.take<float>(M * 256); f.X1 = c.take<float>(M * 256);
+    f.H = c.take<float>(M * m->ff);
+    f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd);
+    f.TGT = c.take<float>(T * 256); f.TGT1 = c.take<float>(T * 256); f.TGT2 = c.take<float>(T * 256);
+    f.DQK = c.take<float>(T * 512); f.DV = c.take<float>(T * 256); f.DATT = c.take<float>(T * 256);
+    f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
+    f.HS = c.take<float>(nd * T * 256); f.S1 = c.take<float>(nd * T * 256); f.S2 = c.take<float>(nd * T * 256);
+    f.LG = c.take<float>(nd * T * 2); f.SP = c.take<float>(nd * T * 2);
+}
+static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax) {
+    Carver c(nullptr, ~(size_t)0);
+    FwdBuffers f;
+    carve_fwd(m, c, B, Lmax, f);
+    return c.cur;
+}
+
+static int forward_packed(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
+                          const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
+                          float* logits, float* spans, float* saliency, const cone_taps* taps, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+    CONE_REQUIRE(B > 0 && Lv_max > 0 && Lq_max >= 0, "forward: bad sizes B=%d Lv=%d Lq=%d", B, Lv_max, Lq_max);
+    const int Lmax = Lv_max + Lq_max;
+    CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
+    CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
+    Carver c(ws, ws_bytes);
+    FwdBuffers f;
+    carve_fwd(m, c, B, Lmax, f);
+    if (!c.ok) { set_error("forward: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    const int Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
+    const int* Mdev = f.off + B;
+
+    RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
+    RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, B, Lmax, s));
+
+    for (int l = 0; l < m->n_enc; ++l) {  // cone/transformer.py:233-246
+        const EncLayer& e = m->enc[l];
+        GemmArgs g = G(f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
+        g.A2 = f.POS; g.lda2 = 256;
+        RUN(launch_gemm(g, s));                                                             // q | k = (x+pos) W^T
+        RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
+        RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
+        g = G(f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
+        g.R = f.X; g.ldr = 256; g.ln_g = e.n1.g; g.ln_b = e.n1.b;
+        RUN(launch_gemm(g, s));                                                             // norm1(x + attn)
+        RUN(launch_gemm(G(f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
+        g = G(f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
+        g.R = f.X1; g.ldr = 256; g.ln_g = e.n2.g; g.ln_b = e.n2.b;
+        RUN(launch_gemm(g, s));                                                             // norm2(x + ffn)
+    }
+    const float* MEM = f.X;
+
+    // decoder (cone/transformer.py:296-317, 117-146): memory K/V for all layers in two GEMMs
+    {
+        GemmArgs g = G(MEM, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
+        g.A2 = f.POS; g.lda2 = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_gemm(G(MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
+    }
+    CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
+    for (int l = 0; l < nd; ++l) {
+        const DecLayer& dl = m->dec[l];
+        GemmArgs g = G(f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, T, nullptr, 512, 256);
+        g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_gemm(G(f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, T, nullptr, 256, 256), s));
+        RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
+        g = G(f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+        g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
+        RUN(launch_gemm(g, s));
+        g = G(f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, T, nullptr, 256, 256);
+        g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
+                              m->nq, Lmax, s));
+        g = G(f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+        g.R = f.TGT1; g.ldr = 256; g.ln_g = dl.n2.g; g.ln_b = dl.n2.b;
+        RUN(launch_gemm(g, s));
+        RUN(launch_gemm(G(f.TGT2, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
+        g = G(f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
+        g.R = f.TGT2; g.ldr = 256; g.ln_g = dl.n3.g; g.ln_b = dl.n3.b;
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
+                             256, s));
+    }
+    // heads on every decoder layer's output (cone/model.py:112-117); the last layer is the prediction
+    const int HT = nd * T;
+    RUN(launch_rowdot(f.HS, 256, m->class_embed.w, m->class_embed.b, f.LG, 2, HT, 2, 0, s));
+    RUN(launch_gemm(G(f.HS, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_gemm(G(f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP, 2, HT, 2, 1, s));
+    const size_t last = (size_t)(nd - 1) * T * 2;
+    CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (taps) {
+        if (taps->hs)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)HT * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_logits && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_logits, f.LG, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_spans && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_spans, f.SP, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
+                        taps ? taps->memory : nullptr, Lq_max, B, s));
+    return 0;
+}
+
+__global__ void iota_rows_kernel(int* a, int n, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i * stride;
+}
+__global__ void fill_int_kernel(int* a, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+}  // namespace cone
+
+using namespace cone;
+
+extern "C" const char* cone_last_error(void) { return g_err; }
+extern "C" int cone_abi_version(void) { return CONE_HIP_ABI_VERSION; }
+
+extern "C" int cone_model_create(const cone_weights* w, cone_model** out) { return build_model(w, out); }
+extern "C" void cone_model_destroy(cone_model* m) {
+    if (!m) return;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+
+extern "C" size_t cone_adapter_norm_workspace(const cone_model* m, int64_t n_rows) {
+    return align_up((size_t)n_rows * 256 * 4, 256) + align_up((size_t)n_rows * m->dv * 4, 256);
+}
+extern "C" int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    CONE_REQUIRE(m && x && out, "adapter_norm: null argument");
+    CONE_REQUIRE(n_rows > 0 && n_rows < (1ll << 31), "adapter_norm: bad row count");
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->has_adapter) {  // adapter_module == "none": features pass through (cone/inference.py:259-260)
+        if (out != x)
+            CONE_CHECK_HIP(hipMemcpyAsync(out, x, (size_t)n_rows * m->dv * 4, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    Carver c(ws, ws_bytes);
+    float* h = c.take<float>((size_t)n_rows * 256);
+    float* y = c.take<float>((size_t)n_rows * m->dv);
+    if (!c.ok) { set_error("adapter_norm: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    RUN(launch_gemm(G(x, m->dv, m->adapter[0].w, m->dv, m->adapter[0].b, h, 256, (int)n_rows, nullptr, 256, m->dv, EPI_RELU), s));
+    GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, y, m->dv, (int)n_rows, nullptr, m->dv, 256, EPI_RESIDUAL);
+    g.R = x; g.ldr = m->dv;
+    RUN(launch_gemm(g, s));
+    return launch_l2norm(y, n_rows, m->dv, 0.f, out, s);
+}
+
+extern "C" int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, float* out, void* stream) {
+    return launch_l2norm(x, n_rows, dim, eps, out, (hipStream_t)stream);
+}
+
+extern "C" size_t cone_project_workspace(const cone_model* m, int which, int64_t n_rows) {
+    return project_ws_bytes(m, which, n_rows);
+}
+extern "C" int cone_project_tokens(const cone_model* m, int which, const float* x, int64_t n_rows, float* out,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    CONE_REQUIRE(m && x && out && (which == 0 || which == 1), "project_tokens: bad argument");
+    if (n_rows <= 0) return 0;
+    return project_tokens(m, which, x, n_rows, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max) {
+    return fwd_ws_bytes(m, B, Lv_max + Lq_max);
+}
+extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
+                                   const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
+                                   const int32_t* txt_len, int B, int Lv_max, int Lq_max, float* logits,
+                                   float* spans, float* saliency, const cone_taps* taps, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    CONE_REQUIRE(m && vproj && tproj && vid_row0 && vid_len && txt_row0 && txt_len && logits && spans && saliency,
+                 "forward_packed: null argument");
+    return forward_packed(m, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, B, Lv_max, Lq_max, logits, spans,
+                          saliency, taps, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad) {
+    const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
+    size_t pw = project_ws_bytes(m, 0, nv);
+    const size_t pt = project_ws_bytes(m, 1, nt);
+    if (pt > pw) pw = pt;
+    return fwd_ws_bytes(m, B, Lv_pad + Lq_pad) + pw + align_up(nv * 256 * 4, 256) + align_up(nt * 256 * 4, 256) +
+           2 * align_up((size_t)B * 4, 256);
+}
+extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len, const float* txt,
+                                    const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,
+                                    float* spans, float* saliency, const cone_taps* taps, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    CONE_REQUIRE(m && vid && txt && vid_len && txt_len && logits && spans && saliency, "forward_windows: null argument");
+    CONE_REQUIRE(B > 0 && Lv_pad > 0 && Lq_pad > 0, "forward_windows: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
+    Carver c(ws, ws_bytes);
+    float* vp = c.take<float>(nv * 256);
+    float* tp = c.take<float>(nt * 256);
+    int* vrow0 = c.take<int>(B);
+    int* trow0 = c.take<int>(B);
+    size_t pw = project_ws_bytes(m, 0, nv);
+    const size_t pt = project_ws_bytes(m, 1, nt);
+    if (pt > pw) pw = pt;
+    char* pws = c.take<char>(pw);
+    if (!c.ok) { set_error("forward_windows: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    // Rows of the zero padding are projected too (wasted work, only on this compatibility path).
+    RUN(project_tokens(m, 0, vid, nv, vp, pws, pw, s));
+    RUN(project_tokens(m, 1, txt, nt, tp, pws, pw, s));
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, vrow0, B, Lv_pad);
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trow0, B, Lq_pad);
+    CONE_LAUNCH_CHECK();
+    return forward_packed(m, vp, vrow0, vid_len, tp, trow0, txt_len, B, Lv_pad, Lq_pad, logits, spans, saliency,
+                          taps, (char*)ws + c.cur, ws_bytes - c.cur, s);
+}
+
+extern "C" size_t cone_clip_matching_workspace(const cone_model* m, int B) {
+    const size_t T = (size_t)B * m->nq;
+    return 2 * align_up(T * m->dv * 4, 256) + align_up(T * 256 * 4, 256) + 3 * align_up((size_t)B * 4, 256);
+}
+extern "C" int cone_clip_matching_gathered(const cone_model* m, const float* cls, const int32_t* cls_row,
+                                           const float* vid, const int32_t* vid_row0, const int32_t* vid_len,
+                                           const int32_t* pad_len, const float* spans, int B, float* match,
+                                           void* ws, size_t ws_bytes, void* stream) {
+    CONE_REQUIRE(m && cls && vid && vid_row0 && vid_len && pad_len && spans && match, "clip_matching: null argument");
+    if (B <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * m->nq, dv = m->dv;
+    Carver c(ws, ws_bytes);
+    float* pf = c.take<float>((size_t)T * dv);
+    float* pa = c.take<float>((size_t)T * dv);
+    float* h = c.take<float>((size_t)T * 256);
+    if (!c.ok) { set_error("clip_matching: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    RUN(launch_proposal_mean(vid, vid_row0, vid_len, pad_len, spans, B, m->nq, dv, pf, s));
+    const float* feat = pf;
+    if (m->has_adapter) {
+        RUN(launch_gemm(G(pf, dv, m->adapter[0].w, dv, m->adapter[0].b, h, 256, T, nullptr, 256, dv, EPI_RELU), s));
+        GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, pa, dv, T, nullptr, dv, 256, EPI_RESIDUAL);
+        g.R = pf; g.ldr = dv;
+        RUN(launch_gemm(g, s));
+        feat = pa;
+    }
+    return launch_cosine_match(feat, cls, cls_row, B, m->nq, dv, match, s);
+}
+extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const float* vid, const int32_t* vid_len,
+                                  int Lv_pad, const float* spans, int B, float* match, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    CONE_REQUIRE(m && ws, "clip_matching: null argument");
+    if (B <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(ws, ws_bytes);
+    int* vrow0 = c.take<int>(B);
+    int* padl = c.take<int>(B);
+    if (!c.ok) { set_error("clip_matching: workspace too small"); return CONE_E_WORKSPACE; }
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, vrow0, B, Lv_pad);
+    hipLaunchKernelGGL(fill_int_kernel, dim3((B + 255) / 256), dim3(256), 0, s, padl, B, Lv_pad);
+    CONE_LAUNCH_CHECK();
+    return cone_clip_matching_gathered(m, cls, nullptr, vid, vrow0, vid_len, padl, spans, B, match,
+                                       (char*)ws + c.cur, ws_bytes - c.cur, stream);
+}
+
+extern "C" int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
+                              const float* R, const float* ln_g, const float* ln_b, float* C, int M, int N, int K,
+                              int flags, void* stream) {
+    GemmArgs g = G(A, K, W, K, bias, C, N, M, nullptr, N, K, flags);
+    g.A2 = A2; g.lda2 = K; g.a2_mod = a2_mod; g.R = R; g.ldr = N; g.ln_g = ln_g; g.ln_b = ln_b;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
+                                   int dim, void* stream) {
+    return launch_layernorm(x, dim, g, b, out, dim, n_rows, nullptr, dim, (hipStream_t)stream);
+}

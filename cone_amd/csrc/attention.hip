@@ -1,0 +1,228 @@
+// Multi-head attention cores of the Moment-DETR window model (head_dim = 32).
+//
+//   enc_attn_kernel   : encoder self-attention (cone/transformer.py:233-240 -> nn.MultiheadAttention),
+//                       one workgroup per (window, head) over the window's PACKED tokens
+//                       (video clips then text tokens; padded keys simply do not exist, which is what
+//                       the reference's -inf key_padding_mask amounts to).
+//   small_attn_kernel : the decoder's attentions with Nq<=8 query slots per window
+//                       (cone/transformer.py:296-311): self-attention over the slots and
+//                       cross-attention to the window's memory tokens.
+//
+// enc_attn_kernel layout (exact-fp32 MFMA 32x32x2):
+//   S^T = K . Q^T is computed with the KEY on the accumulator rows and the QUERY on the lanes, so a
+//   lane owns one query column: the row softmax is an in-register reduction plus ONE cross-half
+//   shuffle (lane ^ 32), and the probability registers are directly the A operand of O = P . V
+//   (the MFMA k index may be permuted freely as long as A and B agree, and the accumulator row
+//   pattern (r&3)+8(r>>2)+4(lane>>5) is used as that permutation).  K is staged in LDS as
+//   [key][33] (odd stride: conflict-free lane==key reads), V as [key][32] (lane==d reads).
+#include "common.h"
+
+namespace cone {
+
+constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
+
+template <int NKB>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
+                                                       const float* __restrict__ V,   // (M,256)
+                                                       float* __restrict__ OUT,       // (M,256)
+                                                       const int* __restrict__ off) {
+    __shared__ float Ks[NKB * 32 * 33];
+    __shared__ __attribute__((aligned(16))) float Vs[NKB * 32 * 32];
+    const int b = blockIdx.x, head = blockIdx.y;
+    const int t0 = off[b];
+    const int L = off[b + 1] - t0;
+    const int nkb = (L + 31) >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    {   // stage K (transposing scalar writes, stride 33) and V (float4) for all keys of the window
+        const int kr = tid >> 3, c = tid & 7;
+        for (int key = kr; key < nkb * 32; key += 32) {
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (key < L) {
+                kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
+                vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
+            }
+            float* kd = Ks + key * 33 + c * 4;
+            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            *reinterpret_cast<float4*>(Vs + key * 32 + c * 4) = vv;
+        }
+    }
+    __syncthreads();
+
+    for (int qb = wave; qb < nkb; qb += 4) {
+        // this lane's query row, dims 16*lh .. 16*lh+15, pre-scaled
+        float qv[16];
+        {
+            int qrow = qb * 32 + li;
+            qrow = qrow < L ? qrow : L - 1;
+            const float* qp = QK + (size_t)(t0 + qrow) * 512 + head * 32 + 16 * lh;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 x = reinterpret_cast<const float4*>(qp)[u];
+                qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
+                qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+            }
+        }
+        f32x16 sc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+            if (kb < nkb) {
+                const float* kp = Ks + (kb * 32 + li) * 33 + 16 * lh;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], qv[t], sc[kb], 0, 0, 0);
+            }
+        }
+        // softmax over keys: registers (half of each key block) + the other half-wave
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nkb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + acc_row(r, lane);
+                    const float s = key < L ? sc[kb][r] : -INFINITY;
+                    sc[kb][r] = s;
+                    m = fmaxf(m, s);
+                }
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nkb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = expf(sc[kb][r] - m);
+                    sc[kb][r] = e;
+                    l += e;
+                }
+            }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nkb) {
+                const float* vp = Vs + (kb * 32 + 4 * lh) * 32 + li;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kb][t] * inv, vp[((t & 3) + 8 * (t >> 2)) * 32], o,
+                                                             0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = qb * 32 + acc_row(r, lane);
+            if (qrow < L) OUT[(size_t)(t0 + qrow) * 256 + head * 32 + li] = o[r];
+        }
+    }
+}
+
+int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
+                    hipStream_t s) {
+    CONE_REQUIRE(Lmax >= 1 && Lmax <= 192, "enc attention: window length %d not in [1,192]", Lmax);
+    if (B <= 0) return 0;
+    dim3 grid(B, 8), block(256);
+    const int nkb = (Lmax + 31) / 32;
+    if (nkb <= 4) hipLaunchKernelGGL(enc_attn_kernel<4>, grid, block, 0, s, QK, V, OUT, off);
+    else if (nkb == 5) hipLaunchKernelGGL(enc_attn_kernel<5>, grid, block, 0, s, QK, V, OUT, off);
+    else hipLaunchKernelGGL(enc_attn_kernel<6>, grid, block, 0, s, QK, V, OUT, off);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Decoder attentions: NQ (<= 8) query slots per window, one wavefront per (window, head).
+// off == nullptr : keys are the window's own NQ slot rows (self-attention, no mask);
+// off != nullptr : keys are memory tokens off[b] .. off[b+1] (cross-attention, <= 192 keys).
+constexpr int kSmallMaxKeys = 192;
+__global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict__ Q, int ldq,
+                                                        const float* __restrict__ K, int ldk,
+                                                        const float* __restrict__ V, int ldv,
+                                                        float* __restrict__ OUT, int ldo,
+                                                        const int* __restrict__ off, int nq) {
+    __shared__ float qs[8][32];
+    __shared__ float ps[8][kSmallMaxKeys];
+    const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+    const int k0 = off ? off[b] : b * nq;
+    const int L = off ? off[b + 1] - k0 : nq;
+    if (lane < nq * 8) {
+        const int qi = lane >> 3, c = lane & 7;
+        const float4 x = *reinterpret_cast<const float4*>(Q + (size_t)(b * nq + qi) * ldq + head * 32 + c * 4);
+        qs[qi][c * 4] = x.x * kQScale; qs[qi][c * 4 + 1] = x.y * kQScale;
+        qs[qi][c * 4 + 2] = x.z * kQScale; qs[qi][c * 4 + 3] = x.w * kQScale;
+    }
+    __syncthreads();
+    float sc[3][8];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = lane + 64 * jj;
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi) sc[jj][qi] = -INFINITY;
+        if (j < L) {
+            float kv[32];
+            const float* kp = K + (size_t)(k0 + j) * ldk + head * 32;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 x = reinterpret_cast<const float4*>(kp)[u];
+                kv[4 * u] = x.x; kv[4 * u + 1] = x.y; kv[4 * u + 2] = x.z; kv[4 * u + 3] = x.w;
+            }
+#pragma unroll
+            for (int qi = 0; qi < 8; ++qi)
+                if (qi < nq) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 32; ++d) a = fmaf(qs[qi][d], kv[d], a);
+                    sc[jj][qi] = a;
+                }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < 8; ++qi)
+        if (qi < nq) {
+            const float m = wave_max(fmaxf(fmaxf(sc[0][qi], sc[1][qi]), sc[2][qi]));
+            float e[3], l = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                e[jj] = (lane + 64 * jj < L) ? expf(sc[jj][qi] - m) : 0.f;
+                l += e[jj];
+            }
+            const float inv = 1.0f / wave_sum(l);
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                if (lane + 64 * jj < L) ps[qi][lane + 64 * jj] = e[jj] * inv;
+        }
+    __syncthreads();
+    const int d = lane & 31, h = lane >> 5;
+    float o[8];
+#pragma unroll
+    for (int qi = 0; qi < 8; ++qi) o[qi] = 0.f;
+    for (int j = h; j < L; j += 2) {
+        const float v = V[(size_t)(k0 + j) * ldv + head * 32 + d];
+#pragma unroll
+        for (int qi = 0; qi < 8; ++qi)
+            if (qi < nq) o[qi] = fmaf(ps[qi][j], v, o[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < 8; ++qi)
+        if (qi < nq) {
+            const float t = o[qi] + __shfl_xor(o[qi], 32, 64);
+            if (h == 0) OUT[(size_t)(b * nq + qi) * ldo + head * 32 + d] = t;
+        }
+}
+
+int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
+                      int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s) {
+    CONE_REQUIRE(nq >= 1 && nq <= 8, "decoder attention: num_queries=%d not in [1,8]", nq);
+    CONE_REQUIRE(Lmax <= kSmallMaxKeys, "decoder attention: %d keys > %d", Lmax, kSmallMaxKeys);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(small_attn_kernel, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cone

@@ -1,0 +1,104 @@
+// Shared host/device helpers for libcone_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cone_hip.h"
+
+namespace cone {
+
+void set_error(const char* fmt, ...);
+
+#define CONE_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            cone::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                            __LINE__);                                                        \
+            return CONE_E_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define CONE_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            cone::set_error(__VA_ARGS__); \
+            return CONE_E_INVALID;       \
+        }                                \
+    } while (0)
+
+#define CONE_LAUNCH_CHECK() CONE_CHECK_HIP(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- device helpers
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// Sum / max over the 64 lanes of a wavefront (wave64 on gfx950).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Sum over the 32 lanes that share (lane >> 5).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Row index inside a 32x32 MFMA accumulator tile: register r of lane l holds
+// D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]   (cdna_hip_programming.md section 3).
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+#endif
+
+// ---------------------------------------------------------------- GEMM launcher (gemm.hip)
+enum { EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_LN = 4 };
+
+struct GemmArgs {
+    const float* A; int lda;              // (M,K) row-major, K contiguous
+    const float* A2; int lda2; int a2_mod; // optional addend; row index = a2_mod ? row % a2_mod : row
+    const float* W; int ldw;              // (N,K): torch Linear weight
+    const float* bias;                    // (N) or null
+    const float* R; int ldr;              // residual (M,N), EPI_RESIDUAL
+    const float* ln_g; const float* ln_b; // EPI_LN (N == 256)
+    float* C; int ldc;
+    int M; const int* M_dev;              // rows; *M_dev wins when non-null (grid sized by M)
+    int N, K;
+    int flags;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- row kernels (rowops.hip)
+int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
+                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s);
+int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s);
+// out[m][n] = act(<X[m], W[n]> + b[n]), n < nout <= 2, K = 256; act 0 none, 1 sigmoid
+int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float* out, int ldo,
+                  int64_t n_rows, int nout, int act, hipStream_t s);
+
+// ---------------------------------------------------------------- attention.hip
+int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
+int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
+                      int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
+
+// ---------------------------------------------------------------- window_ops.hip
+int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s);
+int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
+                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, int B, int Lmax,
+                    hipStream_t s);
+int launch_saliency(const float* MEM, const int* off, const int* vlen, const int* qlen, const float* w,
+                    const float* bias, float* sal, int Lv_out, float* mem_tap, int Lq_out, int B, hipStream_t s);
+int launch_proposal_mean(const float* vid, const int* vrow0, const int* vlen, const int* pad_len,
+                         const float* spans, int B, int Nq, int dv, float* out, hipStream_t s);
+int launch_cosine_match(const float* pf, const float* cls, const int* cls_row, int B, int Nq, int dv, float* match,
+                        hipStream_t s);
+
+}  // namespace cone

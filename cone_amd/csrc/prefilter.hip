@@ -1,0 +1,175 @@
+// Stage A: sliding-window pre-filter (cone/inference.py:276-299).
+//
+//   frame_score_kernel : frame_scores[q][f] = <vid[f], txt[q]>  -- the HBM-bound stream over the
+//                        pre-extracted clip features (12.7 GB for the MAD-scale stress video).
+//                        One wavefront streams whole rows with coalesced 16-B lane loads (1 KiB per
+//                        wave-instruction), RPW rows in flight per wave, QG query vectors held in
+//                        registers; per-(row,query) partial sums are combined with wave shuffles.
+//   window_max_kernel  : win[q][i] = max(frame_scores[q][max((i-1)S,0) : min((i-1)S+W, ctx_l)])
+//   topk_kernel        : first k entries of the stable descending sort of each score row.
+#include "common.h"
+
+namespace cone {
+
+template <int VPL /* float4 per lane per row: dv = 256*VPL */, int QG, int RPW>
+__global__ __launch_bounds__(256) void frame_score_kernel(const float* __restrict__ vid, int64_t ctx_l,
+                                                          const float* __restrict__ txt, int q0, int nq,
+                                                          float* __restrict__ fs) {
+    constexpr int DV = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float4 q[QG][VPL];
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int qi = min(q0 + g, nq - 1);
+            q[g][v] = reinterpret_cast<const float4*>(txt + (size_t)qi * DV)[lane + 64 * v];
+        }
+    for (int64_t r0 = wave_id * RPW; r0 < ctx_l; r0 += n_waves * RPW) {
+        float4 x[RPW][VPL];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t row = min(r0 + r, ctx_l - 1);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v)
+                x[r][v] = reinterpret_cast<const float4*>(vid + row * DV)[lane + 64 * v];
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    s += (x[r][v].x * q[g][v].x + x[r][v].y * q[g][v].y) +
+                         (x[r][v].z * q[g][v].z + x[r][v].w * q[g][v].w);
+                s = wave_sum(s);
+                if (lane == 0 && r0 + r < ctx_l && q0 + g < nq) fs[(size_t)(q0 + g) * ctx_l + r0 + r] = s;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void window_max_kernel(const float* __restrict__ fs, int64_t ctx_l, int W,
+                                                         int S, int64_t num_window, float* __restrict__ win) {
+    const int q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_window) return;
+    const int64_t s = max((i - 1) * S, (int64_t)0);
+    const int64_t e = min((i - 1) * S + W, ctx_l);
+    const float* f = fs + (size_t)q * ctx_l;
+    float m = -INFINITY;
+    for (int64_t t = s; t < e; ++t) m = fmaxf(m, f[t]);
+    win[(size_t)q * num_window + i] = m;
+}
+
+// Stable descending top-k: pass p picks the largest (score, then lowest index) strictly after the
+// previous pick in that order.  One workgroup per score row.
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sc, int64_t n, int k,
+                                                   int32_t* __restrict__ idx, float* __restrict__ val) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ float best_v;
+    __shared__ int best_i;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = sc + (size_t)q * n;
+    float last_v = INFINITY;
+    int last_i = -1;
+    for (int p = 0; p < k; ++p) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int64_t j = tid; j < n; j += 256) {
+            const float v = row[j];
+            const bool after = (v < last_v) || (v == last_v && (int)j > last_i);
+            if (after && (v > bv || (v == bv && (int)j < bi))) { bv = v; bi = (int)j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_v[0];
+            int i = s_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
+            best_v = v; best_i = i;
+            idx[(size_t)q * k + p] = i == 0x7fffffff ? -1 : i;
+            if (val) val[(size_t)q * k + p] = v;
+        }
+        __syncthreads();
+        last_v = best_v;
+        last_i = best_i;
+        __syncthreads();
+    }
+}
+
+template <int VPL>
+static int launch_frame_scores(const float* vid, int64_t ctx_l, const float* txt, int nq, float* fs,
+                               hipStream_t s) {
+    constexpr int RPW = 4;
+    int64_t blocks = (ctx_l + 4 * RPW - 1) / (4 * RPW);
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: 8 workgroups per CU
+    for (int q0 = 0; q0 < nq;) {
+        const int rem = nq - q0;
+        if (rem >= 4) {
+            hipLaunchKernelGGL((frame_score_kernel<VPL, 4, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
+                               ctx_l, txt, q0, nq, fs);
+            q0 += 4;
+        } else if (rem >= 2) {
+            hipLaunchKernelGGL((frame_score_kernel<VPL, 2, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
+                               ctx_l, txt, q0, nq, fs);
+            q0 += 2;
+        } else {
+            hipLaunchKernelGGL((frame_score_kernel<VPL, 1, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
+                               ctx_l, txt, q0, nq, fs);
+            q0 += 1;
+        }
+        CONE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace cone
+
+extern "C" int64_t cone_num_windows(int64_t ctx_l, int W) {
+    const int S = W / 2;
+    if (S <= 0 || ctx_l <= 0) return 0;
+    return (ctx_l + S - 1) / S + 1;
+}
+
+extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W,
+                                     int S, float* frame_scores, float* win_scores, void* stream) {
+    CONE_REQUIRE(ctx_l > 0 && nq > 0 && W > 0 && S > 0, "prefilter: bad sizes ctx_l=%lld nq=%d W=%d S=%d",
+                 (long long)ctx_l, nq, W, S);
+    CONE_REQUIRE(dv == 256 || dv == 512 || dv == 768 || dv == 1024,
+                 "prefilter: feature dim %d not in {256,512,768,1024}", dv);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (dv / 256) {
+        case 1: rc = cone::launch_frame_scores<1>(vid, ctx_l, txt, nq, frame_scores, s); break;
+        case 2: rc = cone::launch_frame_scores<2>(vid, ctx_l, txt, nq, frame_scores, s); break;
+        case 3: rc = cone::launch_frame_scores<3>(vid, ctx_l, txt, nq, frame_scores, s); break;
+        default: rc = cone::launch_frame_scores<4>(vid, ctx_l, txt, nq, frame_scores, s); break;
+    }
+    if (rc) return rc;
+    const int64_t nw = (ctx_l + S - 1) / S + 1;
+    hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nw + 255) / 256), nq), dim3(256), 0, s,
+                       frame_scores, ctx_l, W, S, nw, win_scores);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cone_topk_windows(const float* win_scores, int nq, int64_t num_window, int k, int32_t* idx,
+                                 float* val, void* stream) {
+    CONE_REQUIRE(nq > 0 && num_window > 0 && k > 0 && k <= num_window && num_window < 0x7fffffff,
+                 "topk: bad sizes nq=%d num_window=%lld k=%d", nq, (long long)num_window, k);
+    hipLaunchKernelGGL(cone::topk_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, win_scores, num_window, k,
+                       idx, val);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,135 @@
+// Row-wise (HBM-bound) kernels: LayerNorm, L2 normalisation, tiny-N heads.
+// One wavefront per row, float4 per lane, wave-shuffle reductions.
+#include "common.h"
+
+namespace cone {
+
+// nn.LayerNorm over the last dim (eps 1e-5): cone/model.py:451 (input projections),
+// cone/transformer.py:135-141 (decoder.norm).  dim is a multiple of 4, <= 1024.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* out, int ldo,
+                                                        int64_t n_rows, const int* n_rows_dev, int dim) {
+    if (n_rows_dev) { int64_t nd = *n_rows_dev; n_rows = nd < n_rows ? nd : n_rows; }
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* xr = x + row * ldx;
+    const int nv = dim >> 2;  // float4 per row
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = reinterpret_cast<const float4*>(xr)[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bq * bq) + (cq * cq + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + 1e-5f);
+    float* orow = out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 gg = reinterpret_cast<const float4*>(g)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            reinterpret_cast<float4*>(orow)[c] = o;
+        }
+    }
+}
+
+int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
+                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s) {
+    CONE_REQUIRE(dim % 4 == 0 && dim <= 1024 && ldx % 4 == 0 && ldo % 4 == 0,
+                 "layernorm: dim=%d must be a multiple of 4 and <= 1024", dim);
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, ldx, g, b,
+                       out, ldo, n_rows, n_rows_dev, dim);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = x / (||x||_2 + eps): utils/basic_utils.py:97-99 (eps=1e-5), cone/inference.py:257 (eps=0).
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
+                                                     float eps, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* xr = x + row * dim;
+    const int nv = dim >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = reinterpret_cast<const float4*>(xr)[c];
+            s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float nrm = sqrtf(wave_sum(s)) + eps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 o;
+            o.x = v[i].x / nrm; o.y = v[i].y / nrm; o.z = v[i].z / nrm; o.w = v[i].w / nrm;
+            reinterpret_cast<float4*>(out + row * dim)[c] = o;
+        }
+    }
+}
+
+int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s) {
+    CONE_REQUIRE(dim % 4 == 0 && dim <= 1024, "l2norm: dim=%d must be a multiple of 4 and <= 1024", dim);
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, n_rows, dim, eps,
+                       out);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Heads with 1-2 outputs over d=256 inputs: class_embed, last span_embed layer (+sigmoid)
+// (cone/model.py:112-115).
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int ldx,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ b, float* out, int ldo,
+                                                     int64_t n_rows, int nout, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float4 xv = reinterpret_cast<const float4*>(X + row * ldx)[lane];
+    for (int n = 0; n < nout; ++n) {
+        const float4 wv = reinterpret_cast<const float4*>(W + n * 256)[lane];
+        float s = (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+        s = wave_sum(s) + b[n];
+        if (act == 1) s = 1.0f / (1.0f + expf(-s));
+        if (lane == 0) out[row * ldo + n] = s;
+    }
+}
+
+int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float* out, int ldo,
+                  int64_t n_rows, int nout, int act, hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, X, ldx, W, b, out,
+                       ldo, n_rows, nout, act);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cone

@@ -1,0 +1,261 @@
+// Per-window glue kernels of stage B: token packing + sine position encoding, saliency head,
+// proposal pooling / cosine matching, row composition.
+#include "common.h"
+
+namespace cone {
+
+// off[0..B] = exclusive prefix sum of (vlen[b] + qlen[b]); off[B] is the packed token count.
+__global__ __launch_bounds__(256) void scan_lengths_kernel(const int* __restrict__ vlen,
+                                                           const int* __restrict__ qlen, int B, int* off) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int b0 = tid * per, b1 = min(b0 + per, B);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += vlen[b] + qlen[b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = run; run += t; }
+        off[B] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int b = b0; b < b1; ++b) { off[b] = run; run += vlen[b] + qlen[b]; }
+}
+
+int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s) {
+    hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(256), 0, s, vlen, qlen, B, off);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Pack window b = [vproj rows vrow0[b] .. +vlen[b]) ++ [tproj rows trow0[b] .. +qlen[b]) into the
+// token matrix X at off[b], and write the matching position rows:
+//   video token p : PositionEmbeddingSine(normalize=True), cone/position_encoding.py:51-72:
+//                   x = (p+1) / (vlen + 1e-6) * 2pi ;  pos[c] = c even ? sin(x / dim_t[c]) : cos(x / dim_t[c])
+//   text token    : zeros (cone/model.py:106, use_txt_pos off).
+// One wavefront per token, float4 per lane (d = 256).
+__global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__ vproj,
+                                                       const int* __restrict__ vrow0,
+                                                       const int* __restrict__ vlen,
+                                                       const float* __restrict__ tproj,
+                                                       const int* __restrict__ trow0,
+                                                       const int* __restrict__ qlen,
+                                                       const int* __restrict__ off,
+                                                       const float* __restrict__ dim_t, float* X, float* POS) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int lv = vlen[b], lq = qlen[b];
+    if (p >= lv + lq) return;
+    const size_t dst = (size_t)(off[b] + p) * 256;
+    float4 x, ps;
+    if (p < lv) {
+        x = reinterpret_cast<const float4*>(vproj + (size_t)(vrow0[b] + p) * 256)[lane];
+        const float xe = __fmul_rn(__fdiv_rn((float)(p + 1), __fadd_rn((float)lv, 1e-6f)), 6.283185307179586f);
+        const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
+        ps.x = sinf(__fdiv_rn(xe, dt.x));
+        ps.y = cosf(__fdiv_rn(xe, dt.y));
+        ps.z = sinf(__fdiv_rn(xe, dt.z));
+        ps.w = cosf(__fdiv_rn(xe, dt.w));
+    } else {
+        x = reinterpret_cast<const float4*>(tproj + (size_t)(trow0[b] + p - lv) * 256)[lane];
+        ps = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    reinterpret_cast<float4*>(X + dst)[lane] = x;
+    reinterpret_cast<float4*>(POS + dst)[lane] = ps;
+}
+
+int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
+                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, int B, int Lmax,
+                    hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pack_pos_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, vproj, vrow0, vlen, tproj,
+                       trow0, qlen, off, dim_t, X, POS);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// saliency_proj on the video part of memory (cone/model.py:119-122) scattered to (B, Lv_out);
+// optional copy of the packed memory into the padded (B, Lv_out + Lq_out, 256) tap.
+__global__ __launch_bounds__(256) void saliency_kernel(const float* __restrict__ MEM, const int* __restrict__ off,
+                                                       const int* __restrict__ vlen,
+                                                       const int* __restrict__ qlen, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* sal, int Lv_out,
+                                                       float* mem_tap, int Lq_out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int lv = vlen[b], lq = qlen[b];
+    if (p < Lv_out) {
+        float s = 0.f;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < lv) {
+            x = reinterpret_cast<const float4*>(MEM + (size_t)(off[b] + p) * 256)[lane];
+            const float4 wv = reinterpret_cast<const float4*>(w)[lane];
+            s = wave_sum((x.x * wv.x + x.y * wv.y) + (x.z * wv.z + x.w * wv.w)) + bias[0];
+        }
+        if (lane == 0) sal[(size_t)b * Lv_out + p] = s;
+        if (mem_tap) reinterpret_cast<float4*>(mem_tap + ((size_t)b * (Lv_out + Lq_out) + p) * 256)[lane] = x;
+    } else if (mem_tap && p < Lv_out + Lq_out) {
+        const int t = p - Lv_out;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < lq) x = reinterpret_cast<const float4*>(MEM + (size_t)(off[b] + lv + t) * 256)[lane];
+        reinterpret_cast<float4*>(mem_tap + ((size_t)b * (Lv_out + Lq_out) + p) * 256)[lane] = x;
+    }
+}
+
+int launch_saliency(const float* MEM, const int* off, const int* vlen, const int* qlen, const float* w,
+                    const float* bias, float* sal, int Lv_out, float* mem_tap, int Lq_out, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int span = mem_tap ? Lv_out + Lq_out : Lv_out;
+    hipLaunchKernelGGL(saliency_kernel, dim3((span + 3) / 4, B), dim3(256), 0, s, MEM, off, vlen, qlen, w, bias,
+                       sal, Lv_out, mem_tap, Lq_out);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Proposal pooling (cone/model.py:186-199): one wavefront per (window, slot).
+//   dur = vlen;  (x1,x2) = (c - 0.5w, c + 0.5w) * dur;  s = max(floor(x1),0);  e = ceil(x2)
+//   feat = sum(rows s .. min(e,vlen)-1) / (min(e,pad_len) - s)      (zero rows of the padded tensor: H3)
+__global__ __launch_bounds__(256) void proposal_mean_kernel(const float* __restrict__ vid,
+                                                            const int* __restrict__ vrow0,
+                                                            const int* __restrict__ vlen,
+                                                            const int* __restrict__ pad_len,
+                                                            const float* __restrict__ spans, int n_prop, int Nq,
+                                                            int dv, float* out) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pi >= n_prop) return;
+    const int b = pi / Nq;
+    const float c = spans[2 * pi], w = spans[2 * pi + 1];
+    const float hw = __fmul_rn(0.5f, w);
+    const float dur = (float)vlen[b];
+    const float p1 = __fmul_rn(__fsub_rn(c, hw), dur), p2 = __fmul_rn(__fadd_rn(c, hw), dur);
+    int s = (int)floorf(p1);
+    s = s > 0 ? s : 0;
+    const int e = (int)ceilf(p2);
+    const int e_pad = min(e, pad_len[b]);
+    const int e_val = min(e, vlen[b]);
+    const float cnt = (float)(e_pad - s);  // <= 0 -> the reference's mean of an empty slice (NaN)
+    const float* base = vid + (size_t)vrow0[b] * dv;
+    const int nv = dv >> 2;
+    for (int ch = lane; ch < nv; ch += 64) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = s; r < e_val; ++r) {
+            const float4 x = reinterpret_cast<const float4*>(base + (size_t)r * dv)[ch];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        }
+        if (e_pad - s <= 0) {
+            a.x = a.y = a.z = a.w = __builtin_nanf("");
+        } else {
+            a.x = __fdiv_rn(a.x, cnt); a.y = __fdiv_rn(a.y, cnt); a.z = __fdiv_rn(a.z, cnt); a.w = __fdiv_rn(a.w, cnt);
+        }
+        reinterpret_cast<float4*>(out + (size_t)pi * dv)[ch] = a;
+    }
+}
+
+int launch_proposal_mean(const float* vid, const int* vrow0, const int* vlen, const int* pad_len,
+                         const float* spans, int B, int Nq, int dv, float* out, hipStream_t s) {
+    const int n = B * Nq;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(proposal_mean_kernel, dim3((n + 3) / 4), dim3(256), 0, s, vid, vrow0, vlen, pad_len,
+                       spans, n, Nq, dv, out);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// match[b][n] = < pf / ||pf||, cls / ||cls|| >   (cone/model.py:142,151-152; no eps).
+__global__ __launch_bounds__(256) void cosine_match_kernel(const float* __restrict__ pf,
+                                                           const float* __restrict__ cls,
+                                                           const int* __restrict__ cls_row, int n_prop, int Nq,
+                                                           int dv, float* match) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pi >= n_prop) return;
+    const int b = pi / Nq;
+    const float* p = pf + (size_t)pi * dv;
+    const float* c = cls + (size_t)(cls_row ? cls_row[b] : b) * dv;
+    float pp = 0.f, cc = 0.f;
+    for (int ch = lane * 4; ch < dv; ch += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(p + ch);
+        const float4 y = *reinterpret_cast<const float4*>(c + ch);
+        pp += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        cc += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+    }
+    const float pn = sqrtf(wave_sum(pp)), cn = sqrtf(wave_sum(cc));
+    float d = 0.f;
+    for (int ch = lane * 4; ch < dv; ch += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(p + ch);
+        const float4 y = *reinterpret_cast<const float4*>(c + ch);
+        d += (__fdiv_rn(x.x, pn) * __fdiv_rn(y.x, cn) + __fdiv_rn(x.y, pn) * __fdiv_rn(y.y, cn)) +
+             (__fdiv_rn(x.z, pn) * __fdiv_rn(y.z, cn) + __fdiv_rn(x.w, pn) * __fdiv_rn(y.w, cn));
+    }
+    d = wave_sum(d);
+    if (lane == 0) match[pi] = d;
+}
+
+int launch_cosine_match(const float* pf, const float* cls, const int* cls_row, int B, int Nq, int dv, float* match,
+                        hipStream_t s) {
+    const int n = B * Nq;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cosine_match_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pf, cls, cls_row, n, Nq, dv,
+                       match);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// A13, cone/inference.py:47-82.  One thread per window; every fp32 operation is rounded separately
+// (no fma contraction) to track the reference's op-by-op torch arithmetic.
+__global__ __launch_bounds__(256) void compose_rows_kernel(const float* __restrict__ logits,
+                                                           const float* __restrict__ spans,
+                                                           const float* __restrict__ match,
+                                                           const int* __restrict__ duration,
+                                                           const int* __restrict__ vstart, float clip_len,
+                                                           int sort, int B, int Nq, float* rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float st[8], ed[8], pr[8], mt[8];
+    int order[8];
+    const float dur = (float)duration[b], vs = (float)vstart[b];
+    for (int n = 0; n < Nq; ++n) {
+        const float l0 = logits[(b * Nq + n) * 2], l1 = logits[(b * Nq + n) * 2 + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(__fsub_rn(l0, m)), e1 = expf(__fsub_rn(l1, m));
+        pr[n] = __fdiv_rn(e0, __fadd_rn(e0, e1));
+        const float c = spans[(b * Nq + n) * 2], w = spans[(b * Nq + n) * 2 + 1];
+        const float hw = __fmul_rn(0.5f, w);
+        st[n] = __fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(c, hw), dur), vs), clip_len);
+        ed[n] = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(c, hw), dur), vs), clip_len);
+        mt[n] = match[b * Nq + n];
+        order[n] = n;
+    }
+    if (sort) {  // stable insertion sort, descending by proposal score
+        for (int i = 1; i < Nq; ++i) {
+            const int oi = order[i];
+            int j = i - 1;
+            while (j >= 0 && pr[order[j]] < pr[oi]) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = oi;
+        }
+    }
+    for (int n = 0; n < Nq; ++n) {
+        const int o = order[n];
+        float* r = rows + ((size_t)b * Nq + n) * 4;
+        r[0] = st[o]; r[1] = ed[o]; r[2] = pr[o]; r[3] = mt[o];
+    }
+}
+
+}  // namespace cone
+
+extern "C" int cone_compose_rows(const float* logits, const float* spans, const float* match,
+                                 const int32_t* duration, const int32_t* video_start, float clip_length, int sort,
+                                 int B, int Nq, float* rows, void* stream) {
+    CONE_REQUIRE(Nq >= 1 && Nq <= 8, "compose_rows: Nq=%d not in [1,8]", Nq);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(cone::compose_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       logits, spans, match, duration, video_start, clip_length, sort, B, Nq, rows);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,365 @@
+"""Coarse-to-fine inference driver on MI355X: the counterpart of ``cone/inference.py``.
+
+Same CLI, same option handling (``cone_amd.config``), same checkpoint / ``opt.json`` inputs, same
+output files (names, JSON / JSONL layout, row format ``[st, ed, proposal, matching, fused]``) and the
+same stdout line ``total model running time:`` -- with stages A-C executed by HIP kernels:
+
+  stage A  (cone/inference.py:241-301)  adapter + renorm over the whole clip arena, frame scores,
+           window max, stable top-k                                  -> ``prefilter``
+  stage B  (cone/inference.py:30-100)   window model + proposal matching on packed windows, gathered
+           by index from device-resident arenas                      -> ``run_windows``
+  stage C  (cone/inference.py:103-217)  4-dp rounding, fusion, dict collapse, 3x NMS, one workgroup
+           per query                                                 -> ``fuse_and_nms``
+
+Data layout in HBM (one split): ``vid_raw`` (sum ctx_l, dv) clip features of all videos back to back
+(``vid_off`` row offsets), ``tok`` (sum Lq, dt) text token features, ``cls`` (nq, dv).  Windows are
+(row0, len) pairs into these arenas -- nothing is padded or copied per window.
+
+Out of scope here: metric tables of standalone_eval (the val split writes the
+prediction files and skips the tables), training-time evaluation hooks.
+"""
+from __future__ import annotations
+
+import io
+import json
+import logging
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import parse_test_options
+from .model import build_model
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------ data
+class FeatureStore:
+    """Device-resident features of one evaluation split (replaces PreFilteringDataset +
+    StartEndDataset of cone/ego4d_mad_dataloader.py for the eval path)."""
+
+    def __init__(self, opt, annotations, video_feats, query_feats, device=None):
+        self.opt = opt
+        self.ann = list(annotations)
+        if opt.data_ratio != 1:
+            self.ann = self.ann[:int(len(self.ann) * opt.data_ratio)]   # dataloader :116-121
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        qids = [r["query_id"] for r in self.ann]
+        if len(set(qids)) != len(qids):
+            raise ValueError("duplicate query_id in the annotation file")
+        self.clip_ids = list(OrderedDict.fromkeys(r["clip_id"] for r in self.ann))
+        self.clip2idx = {c: i for i, c in enumerate(self.clip_ids)}
+        vids = [np.asarray(video_feats[c], dtype=np.float32) for c in self.clip_ids]
+        self.ctx_l = [int(v.shape[0]) for v in vids]
+        self.vid_off = np.concatenate([[0], np.cumsum(self.ctx_l)]).astype(np.int64)
+        self.vid_raw = torch.from_numpy(np.concatenate(vids, 0)).to(dev)
+        toks, clss = [], []
+        for r in self.ann:
+            q = query_feats[r["query_id"]]
+            toks.append(np.asarray(q["token_features"], dtype=np.float32)[:opt.max_q_l])   # :272-273
+            c = np.asarray(q["cls_features"] if "cls_features" in q else q["eot_features"], dtype=np.float32)
+            clss.append(c[0] if c.ndim == 2 else c)                                         # :466-471
+        self.tok_len = [int(t.shape[0]) for t in toks]
+        self.tok_off = np.concatenate([[0], np.cumsum(self.tok_len)]).astype(np.int64)
+        self.tok_raw = torch.from_numpy(np.concatenate(toks, 0)).to(dev)
+        self.cls_raw = torch.from_numpy(np.stack(clss, 0)).to(dev)
+        self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
+
+    @classmethod
+    def from_lmdb(cls, opt):
+        """Read the reference's LMDBs of np.savez blobs (keys ``features`` / ``token_features`` +
+        ``cls_features``|``eot_features``; cone/ego4d_mad_dataloader.py:263-302)."""
+        try:
+            import lmdb
+        except ImportError as e:  # pragma: no cover - lmdb is not in this image
+            raise ImportError("reading the reference LMDB feature stores needs the `lmdb` package") from e
+        if opt.motion_feat_dir != opt.appearance_feat_dir:
+            raise NotImplementedError("separate motion/appearance feature dirs are not used by any shipped script")
+        with open(opt.eval_path) as f:
+            ann = [json.loads(l.strip("\n")) for l in f.readlines()]
+
+        def read_all(path, keys, fields):
+            env = lmdb.open(path, readonly=True, create=False, max_readers=4096 * 8, readahead=False)
+            out = {}
+            with env.begin(buffers=True) as txn:
+                for k in keys:
+                    with io.BytesIO(txn.get(k.encode())) as reader:
+                        dump = np.load(reader, allow_pickle=True)
+                        out[k] = {f: dump[f] for f in fields if f in dump}
+            return out
+
+        vf = {k: v["features"] for k, v in read_all(opt.appearance_feat_dir,
+                                                    OrderedDict.fromkeys(r["clip_id"] for r in ann),
+                                                    ["features"]).items()}
+        qf = read_all(opt.t_feat_dir, [r["query_id"] for r in ann],
+                      ["token_features", "cls_features", "eot_features"])
+        return cls(opt, ann, vf, qf)
+
+
+# ------------------------------------------------------------------------------------ stage A
+@torch.no_grad()
+def prefilter(model, store: FeatureStore, opt):
+    """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window)."""
+    dev = store.device
+    vid_norm = ops.l2_normalize(store.vid_raw, 1e-5)          # PreFilteringDataset :459
+    ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
+    cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)          # :473
+    nq = len(store.ann)
+    win_idx = torch.full((nq, opt.topk_window), -1, dtype=torch.int32, device=dev)
+    by_vid = OrderedDict()
+    for qi, v in enumerate(store.q_vid.tolist()):
+        by_vid.setdefault(v, []).append(qi)
+    for v, qis in by_vid.items():
+        r0, r1 = int(store.vid_off[v]), int(store.vid_off[v + 1])
+        qsel = torch.tensor(qis, dtype=torch.long, device=dev)
+        _, ws = ops.prefilter_scores(ctx[r0:r1], cls_norm.index_select(0, qsel).contiguous(), opt.max_v_l)
+        k = min(opt.topk_window, ws.shape[1])
+        idx, _ = ops.topk_windows(ws, k)
+        win_idx[qsel, :k] = idx
+    store.cls_norm = cls_norm
+    return win_idx
+
+
+def window_table(store: FeatureStore, opt, win_idx):
+    """Eval branch of StartEndDataset.__getitem__ + collate (dataloader :144-159, 229-234, 305-344)
+    as index arithmetic on the device: one row per (query, selected window), in annotation order."""
+    dev = store.device
+    nq, K = win_idx.shape
+    W, S = opt.max_v_l, int(opt.max_v_l / 2)
+    valid = win_idx >= 0
+    q_of = torch.arange(nq, device=dev)[:, None].expand(nq, K)[valid]
+    slot = torch.arange(K, device=dev)[None, :].expand(nq, K)[valid]
+    wi = win_idx[valid].to(torch.int64)
+    ctx_l = torch.tensor(store.ctx_l, device=dev)[torch.from_numpy(store.q_vid).to(dev)][q_of]
+    voff = torch.from_numpy(store.vid_off).to(dev)[torch.from_numpy(store.q_vid).to(dev)][q_of]
+    start = torch.clamp((wi - 1) * S, min=0)
+    end = torch.minimum((wi - 1) * S + W, ctx_l)
+    vlen = end - start
+    # zero-padded length of the reference batch this window would sit in (hazard H3)
+    bid = q_of // opt.eval_bsz
+    nb = (nq + opt.eval_bsz - 1) // opt.eval_bsz
+    pad = torch.zeros(nb, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, vlen, reduce="amax")
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    tok_off = torch.from_numpy(store.tok_off).to(dev)
+    tok_len = torch.tensor(store.tok_len, device=dev)
+    return dict(q_of=q_of, slot=slot, vid_row0=i32(voff + start), vid_len=i32(vlen), video_start=i32(start),
+                pad_len=i32(pad[bid]), txt_row0=i32(tok_off[q_of]), txt_len=i32(tok_len[q_of]), cls_row=i32(q_of))
+
+
+# ------------------------------------------------------------------------------------ stage B
+@torch.no_grad()
+def run_windows(model, store: FeatureStore, opt, wt, chunk=None):
+    """CONE.forward + forward_clip_matching + row composition for every window of ``wt``.
+    Returns rows (Nw, Nq, 4) fp32 [st, ed, proposal, matching] (sorted per window unless
+    --no_sort_results) and the raw model outputs."""
+    if not hasattr(store, "vproj"):
+        # Row-wise input projections are shared by all windows that contain the clip and by all windows
+        # of a query (H12): project each clip / token once.
+        store.vproj = model.project(0, store.vid_raw)                       # raw features: H2
+        store.tproj = model.project(1, ops.l2_normalize(store.tok_raw, 1e-5))  # :274-275
+    if not hasattr(store, "cls_norm"):
+        store.cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)
+    nw = wt["vid_row0"].shape[0]
+    chunk = chunk or int(getattr(opt, "window_batch", 4096))
+    Lq_max = max(store.tok_len)
+    outs = {k: [] for k in ("pred_logits", "pred_spans", "matching", "rows")}
+    for c0 in range(0, nw, chunk):
+        sl = slice(c0, min(c0 + chunk, nw))
+        g = lambda k: wt[k][sl].contiguous()
+        out = model.forward_packed(store.vproj, g("vid_row0"), g("vid_len"), store.tproj, g("txt_row0"),
+                                   g("txt_len"), opt.max_v_l, Lq_max)
+        match = model.clip_matching_gathered(store.cls_norm, g("cls_row"), store.vid_raw, g("vid_row0"),
+                                             g("vid_len"), g("pad_len"), out["pred_spans"])
+        rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, g("vid_len"), g("video_start"),
+                                opt.clip_length, not opt.no_sort_results)
+        outs["pred_logits"].append(out["pred_logits"]); outs["pred_spans"].append(out["pred_spans"])
+        outs["matching"].append(match); outs["rows"].append(rows)
+    return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+
+def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
+    """cone/inference.py:30-100: the window-level submission list (python floats rounded to 4 dp)."""
+    if win_idx is None:
+        win_idx = prefilter(model, store, opt)
+    wt = window_table(store, opt, win_idx)
+    res = run_windows(model, store, opt, wt)
+    rows = res["rows"].cpu().tolist()
+    q_of = wt["q_of"].cpu().tolist()
+    mr_res = []
+    for w, r in enumerate(rows):
+        meta = store.ann[q_of[w]]
+        mr_res.append(dict(query_id=meta["query_id"], query=meta["query"], video_id=meta["video_id"],
+                           clip_id=meta["clip_id"],
+                           pred_relevant_windows=[[float(f"{e:.4f}") for e in row] for row in r]))
+    return mr_res, {}
+
+
+# ------------------------------------------------------------------------------------ stage C
+def _rows_to_lists(rows, n):
+    rows, n = rows.cpu(), n.cpu()
+    out = []
+    for t in range(3):
+        per_q = []
+        for q in range(rows.shape[1]):
+            per_q.append(rows[t, q, :int(n[t, q])].tolist())
+        out.append(per_q)
+    return out  # [fused, proposal, matching][query] -> list of [st, ed, prop, match, fused]
+
+
+def fuse_and_nms(cand, n_valid, opt):
+    rows, n, _ = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
+    return _rows_to_lists(rows, n)
+
+
+def _group_submission(submission, opt):
+    qid2 = OrderedDict()
+    for item in submission:
+        qid = item["query_id"]
+        if qid not in qid2:
+            if opt.dset_name == "ego4d":
+                parts = qid.split("_")
+                assert len(parts) == 2                                          # cone/inference.py:135-136
+                qid2[qid] = {"query_idx": int(parts[1]), "annotation_uid": parts[0], "predicted_times": [],
+                             "clip_uid": item["clip_id"]}
+            else:
+                qid2[qid] = {"query_id": qid, "predicted_times": [], "video_id": item["video_id"]}
+        qid2[qid]["predicted_times"].extend(item["pred_relevant_windows"])
+    return list(qid2.values())
+
+
+def _postprocess(submission, opt):
+    """cone/inference.py:130-202 on a window-level submission list (python rows)."""
+    results = _group_submission(submission, opt)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n_max = max(1, max(len(r["predicted_times"]) for r in results))
+    cand = torch.zeros(len(results), n_max, 4, dtype=torch.float64)
+    nv = torch.zeros(len(results), dtype=torch.int32)
+    for i, r in enumerate(results):
+        pt = r["predicted_times"]
+        nv[i] = len(pt)
+        if pt:
+            cand[i, :len(pt)] = torch.tensor(pt, dtype=torch.float64)
+    lists = fuse_and_nms(cand.to(dev), nv.to(dev), opt)
+    outs = []
+    for t in range(3):
+        lst = []
+        for i, r in enumerate(results):
+            o = r.copy()
+            o["predicted_times"] = lists[t][i]
+            lst.append(o)
+        outs.append(lst)
+    return tuple(outs)
+
+
+def postprocessing_format_ego4d(submission, opt):
+    assert opt.dset_name == "ego4d"
+    return _postprocess(submission, opt)
+
+
+def postprocessing_format_mad(submission, opt):
+    assert opt.dset_name == "mad"
+    return _postprocess(submission, opt)
+
+
+def _save_jsonl(data, path):
+    with open(path, "w") as f:
+        f.write("\n".join(json.dumps(e) for e in data))
+
+
+def write_submissions(opt, fusion, proposal, matching, save_submission_filename):
+    """cone/inference.py:320-331, 386-417."""
+    path = os.path.join(opt.results_dir, save_submission_filename)
+    paths = [path]
+    if opt.dset_name == "mad":
+        _save_jsonl(fusion, path)
+        if opt.save_all or opt.eval_modality != "both":
+            pp, mp = path.replace("preds", "proposal_preds"), path.replace("preds", "matching_preds")
+            _save_jsonl(proposal, pp); _save_jsonl(matching, mp)
+            paths += [pp, mp]
+    else:
+        def dump(res, p):
+            with open(p, "w") as f:
+                json.dump({"version": "1.0", "challenge": "ego4d_nlq_challenge", "results": res}, f)
+        dump(fusion, path)
+        if opt.save_all or opt.eval_modality != "both":
+            pp, mp = path.replace("preds", "proposal_preds"), path.replace("preds", "matching_preds")
+            dump(proposal, pp); dump(matching, mp)
+            paths += [pp, mp]
+    return paths
+
+
+@torch.no_grad()
+def predict_split(model, store: FeatureStore, opt):
+    """Stages A->C entirely on the device; returns the three submission lists and timing marks."""
+    t0 = time.time()
+    win_idx = prefilter(model, store, opt)
+    wt = window_table(store, opt, win_idx)
+    res = run_windows(model, store, opt, wt)
+    torch.cuda.synchronize()
+    t_model = time.time() - t0
+    nq, K = win_idx.shape
+    Nq = model.num_queries
+    rows = res["rows"]
+    cand = torch.zeros(nq, K * Nq, 4, device=rows.device)
+    cand.view(nq, K, Nq, 4)[wt["q_of"], wt["slot"]] = rows
+    n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
+    lists = fuse_and_nms(cand, n_valid, opt)
+    outs = []
+    for t in range(3):
+        lst = []
+        for qi, meta in enumerate(store.ann):
+            if opt.dset_name == "ego4d":
+                parts = meta["query_id"].split("_")
+                assert len(parts) == 2
+                o = {"query_idx": int(parts[1]), "annotation_uid": parts[0], "predicted_times": lists[t][qi],
+                     "clip_uid": meta["clip_id"]}
+            else:
+                o = {"query_id": meta["query_id"], "predicted_times": lists[t][qi], "video_id": meta["video_id"]}
+            lst.append(o)
+        outs.append(lst)
+    return tuple(outs), dict(win_idx=win_idx, windows=wt, model_seconds=t_model, n_windows=int(rows.shape[0]))
+
+
+def eval_epoch(model, store: FeatureStore, opt, save_submission_filename, epoch_i=None, criterion=None,
+               tb_writer=None):
+    """cone/inference.py:227-499 without the metric tables: writes the prediction files and returns
+    ``(None, None, [], latest_file_paths)`` in the reference's result slots."""
+    logger.info("Generate submissions")
+    (fusion, proposal, matching), info = predict_split(model, store, opt)
+    print("total model running time: ", info["model_seconds"])
+    paths = write_submissions(opt, fusion, proposal, matching, save_submission_filename)
+    return None, None, [], paths
+
+
+def setup_model(opt):
+    """cone/inference.py:502-537 (inference part): build, load ``ckpt["model"]``."""
+    model, criterion = build_model(opt)
+    if opt.resume is None:
+        raise ValueError("--resume <ckpt> is required")
+    ckpt = torch.load(opt.resume, map_location="cpu", weights_only=False)
+    model.load_state_dict(ckpt["model"])
+    logger.info(f"Loaded model saved at epoch {ckpt.get('epoch')} from checkpoint: {opt.resume}")
+    return model, criterion, None, None
+
+
+def start_inference(argv=None):
+    """cone/inference.py:540-607."""
+    logging.basicConfig(format="%(asctime)s.%(msecs)03d:%(levelname)s:%(name)s - %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S", level=logging.INFO)
+    opt = parse_test_options(argv)
+    assert opt.eval_path is not None
+    store = FeatureStore.from_lmdb(opt)
+    model, _, _, _ = setup_model(opt)
+    ext = "jsonl" if opt.dset_name == "mad" else "json"
+    fn = f"inference_{opt.dset_name}_{opt.eval_split_name}_{opt.eval_id}_preds.{ext}"
+    logger.info("Starting inference...")
+    return eval_epoch(model, store, opt, fn)
+
+
+if __name__ == "__main__":
+    start_inference()

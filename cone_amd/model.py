@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference ``CONE`` module for inference on MI355X.
+
+Same constructor path (``build_model(args)``), state-dict keys, call signatures, argument
+meaning and output dict as ``cone/model.py:16-152`` -- but ``forward`` /
+``forward_clip_matching`` enqueue the hand-written HIP kernels of libcone_hip.so on the current
+torch stream instead of running torch.nn modules.  Tensors are torch CUDA(HIP) tensors; torch is
+only the allocator / stream owner here.
+
+Not mirrored (out of scope): ``SetCriterion`` and the training-only branches
+(``is_groundtruth`` matching, dropout).  ``build_model`` returns ``(model, None)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import state_dict_spec
+
+_TXT_POS_PREFIX = "txt_position_embed."  # present in checkpoints, unused when use_txt_pos is off
+
+
+def _dim_t_table(d: int) -> torch.Tensor:
+    """temperature ** (2 * (i // 2) / d), fp32, exactly as cone/position_encoding.py:66-67."""
+    dim_t = torch.arange(d, dtype=torch.float32)
+    return 10000 ** (2 * (dim_t // 2) / d)
+
+
+class Workspace:
+    """Grow-only device scratch handed to the C ABI (the library never allocates)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes * 1.05) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class CONE:
+    """Drop-in for the inference surface of the reference ``CONE`` nn.Module."""
+
+    def __init__(self, args):
+        if getattr(args, "use_txt_pos", False):
+            raise NotImplementedError("use_txt_pos is off in every shipped config (cone/config.py:115); "
+                                      "the HIP path implements the zero text position of cone/model.py:106")
+        if getattr(args, "span_loss_type", "l1") != "l1":
+            raise NotImplementedError("only span_loss_type='l1' (cone/config.py:134)")
+        if getattr(args, "pre_norm", False):
+            raise NotImplementedError("only the post-norm transformer (pre_norm=False) is implemented")
+        if getattr(args, "v_motion_feat_dim", None) != getattr(args, "v_appear_feat_dim", None):
+            raise NotImplementedError("motion and appearance features share one source in every shipped script")
+        self.args = args
+        self.num_queries = args.num_queries
+        self.adapter_module = args.adapter_module
+        self.aux_loss = getattr(args, "aux_loss", True)
+        self.n_input_proj = args.n_input_proj
+        self.hidden_dim = args.hidden_dim
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self._handle = None
+        self._sd = None
+        self._ws = Workspace()
+        self.training = False
+
+    # ---- nn.Module look-alikes ---------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference checkpoint's ``ckpt["model"]`` unchanged (cone/inference.py:525-527)."""
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.ConeHipError("cone_amd needs a GPU: there is no CPU execution path")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        spec = state_dict_spec(self.args)
+        sd = OrderedDict()
+        for k, shape in spec.items():
+            if k not in state_dict:
+                if k.startswith(_TXT_POS_PREFIX):
+                    continue
+                raise KeyError(f"missing key in state_dict: {k}")
+            v = state_dict[k]
+            v = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
+            sd[k] = v.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if strict:
+            extra = [k for k in state_dict if k not in spec]
+            if extra:
+                raise KeyError(f"unexpected keys in state_dict: {extra[:5]}")
+        self._sd = sd
+        self._dim_t = _dim_t_table(self.hidden_dim).to(dev)
+        a = self.args
+        w = _lib.Weights()
+        w.hidden_dim, w.nheads, w.dim_ff = a.hidden_dim, a.nheads, a.dim_feedforward
+        w.enc_layers, w.dec_layers, w.num_queries = a.enc_layers, a.dec_layers, a.num_queries
+        w.n_input_proj, w.t_dim, w.v_dim = a.n_input_proj, a.t_feat_dim, a.v_appear_feat_dim
+        w.has_adapter = 1 if a.adapter_module == "linear" else 0
+        p = lambda k: sd[k].data_ptr()
+
+        def lin(dst, prefix):
+            dst.w, dst.b = p(prefix + ".weight"), p(prefix + ".bias")
+
+        def ln(dst, prefix):
+            dst.g, dst.b = p(prefix + ".weight"), p(prefix + ".bias")
+
+        def mha(dst, prefix):
+            dst.in_proj_w, dst.in_proj_b = p(prefix + ".in_proj_weight"), p(prefix + ".in_proj_bias")
+            lin(dst.out_proj, prefix + ".out_proj")
+
+        for i in range(a.n_input_proj):
+            ln(w.vid_proj_ln[i], f"input_vid_proj.{i}.LayerNorm"); lin(w.vid_proj[i], f"input_vid_proj.{i}.net.1")
+            ln(w.txt_proj_ln[i], f"input_txt_proj.{i}.LayerNorm"); lin(w.txt_proj[i], f"input_txt_proj.{i}.net.1")
+        for i in range(a.enc_layers):
+            pre = f"transformer.encoder.layers.{i}"
+            mha(w.enc[i].self_attn, pre + ".self_attn")
+            lin(w.enc[i].linear1, pre + ".linear1"); lin(w.enc[i].linear2, pre + ".linear2")
+            ln(w.enc[i].norm1, pre + ".norm1"); ln(w.enc[i].norm2, pre + ".norm2")
+        for i in range(a.dec_layers):
+            pre = f"transformer.decoder.layers.{i}"
+            mha(w.dec[i].self_attn, pre + ".self_attn"); mha(w.dec[i].cross_attn, pre + ".multihead_attn")
+            lin(w.dec[i].linear1, pre + ".linear1"); lin(w.dec[i].linear2, pre + ".linear2")
+            ln(w.dec[i].norm1, pre + ".norm1"); ln(w.dec[i].norm2, pre + ".norm2"); ln(w.dec[i].norm3, pre + ".norm3")
+        ln(w.dec_norm, "transformer.decoder.norm")
+        w.query_embed = p("query_embed.weight")
+        lin(w.class_embed, "class_embed")
+        for i in range(3):
+            lin(w.span_embed[i], f"span_embed.layers.{i}")
+        lin(w.saliency_proj, "saliency_proj")
+        if w.has_adapter:
+            lin(w.adapter[0], "adapter_layer.layers.0"); lin(w.adapter[1], "adapter_layer.layers.1")
+        w.pos_dim_t = self._dim_t.data_ptr()
+        if self._handle is not None:
+            lib.cone_model_destroy(self._handle)
+            self._handle = None
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        _lib.check(lib.cone_model_create(C.byref(w), C.byref(h)))
+        self._handle = h
+        return self
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.load().cone_model_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _h(self):
+        if self._handle is None:
+            raise _lib.ConeHipError("load_state_dict() must be called before running the model")
+        return self._handle
+
+    @staticmethod
+    def _f32(t):
+        return t.to(dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def _lengths(mask):
+        """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths."""
+        return mask.to(torch.float32).sum(dim=1).to(torch.int32).contiguous()
+
+    # ---- CONE.forward (cone/model.py:82-128) ----------------------------------------------------
+    def forward(self, src_txt, src_txt_mask, src_vid_motion, src_vid_motion_mask, taps: bool = False):
+        lib, h = _lib.load(), self._h()
+        vid, txt = self._f32(src_vid_motion), self._f32(src_txt)
+        B, Lv, _ = vid.shape
+        Lq = txt.shape[1]
+        vlen, qlen = self._lengths(src_vid_motion_mask), self._lengths(src_txt_mask)
+        dev = vid.device
+        nq, nd, d = self.num_queries, self.args.dec_layers, self.hidden_dim
+        logits = torch.empty(B, nq, 2, device=dev)
+        spans = torch.empty(B, nq, 2, device=dev)
+        sal = torch.empty(B, Lv, device=dev)
+        want_aux = self.aux_loss and nd > 1
+        t = _lib.Taps()
+        aux_l = aux_s = mem = hs = None
+        if want_aux:
+            aux_l = torch.empty(nd - 1, B, nq, 2, device=dev)
+            aux_s = torch.empty(nd - 1, B, nq, 2, device=dev)
+            t.aux_logits, t.aux_spans = aux_l.data_ptr(), aux_s.data_ptr()
+        if taps:
+            mem = torch.empty(B, Lv + Lq, d, device=dev)
+            hs = torch.empty(nd, B, nq, d, device=dev)
+            t.memory, t.hs = mem.data_ptr(), hs.data_ptr()
+        nbytes = lib.cone_forward_workspace(h, B, Lv, Lq)
+        ws = self._ws.get(nbytes, dev)
+        _lib.check(lib.cone_forward_windows(h, _lib.ptr(vid), _lib.ptr(vlen), _lib.ptr(txt), _lib.ptr(qlen), B,
+                                            Lv, Lq, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), C.byref(t),
+                                            _lib.ptr(ws), ws.numel(), _lib.stream()))
+        out = {"pred_logits": logits, "pred_spans": spans, "saliency_scores": sal}
+        if want_aux:
+            out["aux_outputs"] = [{"pred_logits": aux_l[i], "pred_spans": aux_s[i]} for i in range(nd - 1)]
+        if taps:
+            out["memory"], out["hs"] = mem, hs
+        return out
+
+    # ---- CONE.forward_clip_matching (cone/model.py:130-152) -------------------------------------
+    def forward_clip_matching(self, src_cls_txt, src_vid_appear, src_vid_appear_mask, proposal=None,
+                              is_groundtruth=False):
+        if is_groundtruth:
+            raise NotImplementedError("ground-truth proposal matching is a training-only branch")
+        lib, h = _lib.load(), self._h()
+        cls, vid, spans = self._f32(src_cls_txt), self._f32(src_vid_appear), self._f32(proposal)
+        B, Lv, _ = vid.shape
+        vlen = self._lengths(src_vid_appear_mask)
+        match = torch.empty(B, self.num_queries, device=vid.device)
+        nbytes = lib.cone_clip_matching_workspace(h, B)
+        ws = self._ws.get(nbytes, vid.device)
+        _lib.check(lib.cone_clip_matching(h, _lib.ptr(cls), _lib.ptr(vid), _lib.ptr(vlen), Lv, _lib.ptr(spans), B,
+                                          _lib.ptr(match), _lib.ptr(ws), ws.numel(), _lib.stream()))
+        return match
+
+    # ---- arena-level entry points used by the eval driver ---------------------------------------
+    def adapter_norm(self, vid_rows):
+        """cone/inference.py:254-258 over any number of clip rows (n, dv)."""
+        lib, h = _lib.load(), self._h()
+        x = self._f32(vid_rows)
+        out = torch.empty_like(x)
+        nbytes = lib.cone_adapter_norm_workspace(h, x.shape[0])
+        ws = self._ws.get(nbytes, x.device)
+        _lib.check(lib.cone_adapter_norm(h, _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                         _lib.stream()))
+        return out
+
+    def project(self, which: int, rows):
+        """input_vid_proj (which=0) / input_txt_proj (which=1) on (n, din) rows -> (n, d)."""
+        lib, h = _lib.load(), self._h()
+        x = self._f32(rows)
+        out = torch.empty(x.shape[0], self.hidden_dim, device=x.device)
+        nbytes = lib.cone_project_workspace(h, which, x.shape[0])
+        ws = self._ws.get(nbytes, x.device)
+        _lib.check(lib.cone_project_tokens(h, which, _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.ptr(ws),
+                                           ws.numel(), _lib.stream()))
+        return out
+
+    def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max):
+        """CONE.forward on windows given by index into projected token arenas."""
+        lib, h = _lib.load(), self._h()
+        B = vid_row0.shape[0]
+        dev = vproj.device
+        nq = self.num_queries
+        logits = torch.empty(B, nq, 2, device=dev)
+        spans = torch.empty(B, nq, 2, device=dev)
+        sal = torch.empty(B, Lv_max, device=dev)
+        nbytes = lib.cone_forward_packed_workspace(h, B, Lv_max, Lq_max)
+        ws = self._ws.get(nbytes, dev)
+        i32 = torch.int32
+        _lib.check(lib.cone_forward_packed(h, _lib.ptr(vproj), _lib.ptr(vid_row0, i32), _lib.ptr(vid_len, i32),
+                                           _lib.ptr(tproj), _lib.ptr(txt_row0, i32), _lib.ptr(txt_len, i32), B,
+                                           Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), None,
+                                           _lib.ptr(ws), ws.numel(), _lib.stream()))
+        return {"pred_logits": logits, "pred_spans": spans, "saliency_scores": sal}
+
+    def clip_matching_gathered(self, cls, cls_row, vid, vid_row0, vid_len, pad_len, spans):
+        lib, h = _lib.load(), self._h()
+        B = vid_row0.shape[0]
+        match = torch.empty(B, self.num_queries, device=vid.device)
+        nbytes = lib.cone_clip_matching_workspace(h, B)
+        ws = self._ws.get(nbytes, vid.device)
+        i32 = torch.int32
+        _lib.check(lib.cone_clip_matching_gathered(h, _lib.ptr(cls), _lib.ptr(cls_row, i32), _lib.ptr(vid),
+                                                   _lib.ptr(vid_row0, i32), _lib.ptr(vid_len, i32),
+                                                   _lib.ptr(pad_len, i32), _lib.ptr(spans), B, _lib.ptr(match),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream()))
+        return match
+
+
+def build_model(args):
+    """``build_model(args) -> (model, criterion)`` of cone/model.py:468-521; the criterion is
+    training-only and not part of this package, so ``None`` is returned in its place."""
+    return CONE(args), None

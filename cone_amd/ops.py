@@ -1,0 +1,124 @@
+"""Thin Python wrappers over the stage A / stage C entry points of libcone_hip.so.
+
+Function names follow the reference (``temporal_nms`` = utils/temporal_nms.py:25,
+``l2_normalize`` = utils/basic_utils.py:97, ...).  Everything executes in HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.ConeHipError("cone_amd needs a GPU: there is no CPU execution path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """x / (||x|| + eps) along the last dim (utils/basic_utils.py:97-99)."""
+    lib = _lib.load()
+    x2 = x.to(torch.float32).contiguous().view(-1, x.shape[-1])
+    out = torch.empty_like(x2)
+    _lib.check(lib.cone_l2_normalize_rows(_lib.ptr(x2), x2.shape[0], x2.shape[1], eps, _lib.ptr(out),
+                                          _lib.stream()))
+    return out.view(x.shape)
+
+
+def num_windows(ctx_l: int, max_v_l: int) -> int:
+    return math.ceil(ctx_l / int(max_v_l / 2)) + 1
+
+
+def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int):
+    """cone/inference.py:284-296 for all queries of one video.
+
+    vid_ctx (ctx_l, dv) adapted+normalised clip features, cls_txt (nq, dv).
+    Returns (frame_scores (nq, ctx_l), window_scores (nq, num_window))."""
+    lib = _lib.load()
+    ctx_l, dv = vid_ctx.shape
+    nq = cls_txt.shape[0]
+    W, S = max_v_l, int(max_v_l / 2)
+    nw = num_windows(ctx_l, max_v_l)
+    fs = torch.empty(nq, ctx_l, device=vid_ctx.device)
+    ws = torch.empty(nq, nw, device=vid_ctx.device)
+    _lib.check(lib.cone_prefilter_scores(_lib.ptr(vid_ctx, torch.float32), ctx_l, dv,
+                                         _lib.ptr(cls_txt, torch.float32), nq, W, S, _lib.ptr(fs), _lib.ptr(ws),
+                                         _lib.stream()))
+    return fs, ws
+
+
+def topk_windows(win_scores: torch.Tensor, k: int):
+    """First k of the stable descending sort of each row (cone/inference.py:297-299, H6)."""
+    lib = _lib.load()
+    nq, nw = win_scores.shape
+    idx = torch.empty(nq, k, dtype=torch.int32, device=win_scores.device)
+    val = torch.empty(nq, k, device=win_scores.device)
+    _lib.check(lib.cone_topk_windows(_lib.ptr(win_scores, torch.float32), nq, nw, k, _lib.ptr(idx), _lib.ptr(val),
+                                     _lib.stream()))
+    return idx, val
+
+
+def compose_rows(logits, spans, match, duration, video_start, clip_length: float, sort: bool = True):
+    """cone/inference.py:47-82 -> (B, Nq, 4) fp32 rows [st, ed, prob, match]."""
+    lib = _lib.load()
+    B, Nq = match.shape
+    rows = torch.empty(B, Nq, 4, device=match.device)
+    _lib.check(lib.cone_compose_rows(_lib.ptr(logits, torch.float32), _lib.ptr(spans, torch.float32),
+                                     _lib.ptr(match, torch.float32), _lib.ptr(duration, torch.int32),
+                                     _lib.ptr(video_start, torch.int32), float(clip_length), 1 if sort else 0, B, Nq,
+                                     _lib.ptr(rows), _lib.stream()))
+    return rows
+
+
+def fuse_nms(cand: torch.Tensor, n_valid: torch.Tensor, nms_thd: float, max_before: int, max_after: int):
+    """Rounding + fusion + dict collapse + 3x NMS for nq queries (cone/inference.py:83,103-127,205-217).
+
+    cand (nq, n_max, 4) fp32 (or fp64 rows that are already rounded), n_valid (nq,) int32.  Returns
+      rows (3, nq, max_after, 5) fp64, n (3, nq) int32, idx (3, nq, max_after) int32
+    in the order fused / proposal / matching."""
+    lib = _lib.load()
+    nq, n_max, _ = cand.shape
+    dev = cand.device
+    rows = torch.zeros(3, nq, max_after, 5, dtype=torch.float64, device=dev)
+    n = torch.zeros(3, nq, dtype=torch.int32, device=dev)
+    idx = torch.full((3, nq, max_after), -1, dtype=torch.int32, device=dev)
+    fn = lib.cone_fuse_nms_f64 if cand.dtype == torch.float64 else lib.cone_fuse_nms
+    _lib.check(fn(_lib.ptr(cand), _lib.ptr(n_valid, torch.int32), nq, n_max, float(nms_thd), int(max_before),
+                  int(max_after), _lib.ptr(rows), _lib.ptr(n), _lib.ptr(idx), _lib.stream()))
+    return rows, n, idx
+
+
+def temporal_nms(predictions, nms_thd, max_after_nms=100):
+    """utils/temporal_nms.py:25-74: list of [st, ed, score] -> kept list, same order/values."""
+    if len(predictions) == 1:
+        return predictions
+    if len(predictions) == 0:
+        return []
+    lib = _lib.load()
+    dev = _dev()
+    pred = torch.tensor([[float(p[0]), float(p[1]), float(p[2])] for p in predictions], dtype=torch.float64,
+                        device=dev)
+    n = pred.shape[0]
+    k = min(max_after_nms, n)
+    keep = torch.full((max(k, 1),), -1, dtype=torch.int32, device=dev)
+    kn = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.cone_temporal_nms(_lib.ptr(pred), n, float(nms_thd), int(k), _lib.ptr(keep), _lib.ptr(kn),
+                                     _lib.stream()))
+    cnt = int(kn.item())
+    keep = keep[:cnt].tolist()
+    return [[predictions[i][0], predictions[i][1], predictions[i][2]] for i in keep]
+
+
+def matcher_cost(pred_logits, pred_spans, tgt_spans, cost_span=10.0, cost_giou=1.0, cost_class=4.0):
+    """cone/matcher.py:61-95 for one target span per window; returns (cost (B,Nq), argmin (B,))."""
+    lib = _lib.load()
+    B, Nq, _ = pred_spans.shape
+    cost = torch.empty(B, Nq, device=pred_spans.device)
+    best = torch.empty(B, dtype=torch.int32, device=pred_spans.device)
+    _lib.check(lib.cone_matcher_cost(_lib.ptr(pred_logits, torch.float32), _lib.ptr(pred_spans, torch.float32),
+                                     _lib.ptr(tgt_spans, torch.float32), B, Nq, cost_span, cost_giou, cost_class,
+                                     _lib.ptr(cost), _lib.ptr(best), _lib.stream()))
+    return cost, best

@@ -1,0 +1,209 @@
+/*
+ * cone_hip.h -- C ABI of libcone_hip.so: the MI355X (gfx950) implementation of CONE's
+ * coarse-to-fine inference hot path.
+ *
+ * The reference (houzhijian/CONE) has no FFI: the path is plain Python calling torch.nn.
+ * Each entry point below therefore names the reference *Python* site it replaces
+ * (file:line relative to the reference repository).  A maintainer binds these with
+ * ctypes (cone_amd/_lib.py is that binding).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer to fp32 / int32 / fp64 memory owned by the
+ *     caller (torch tensors), row-major, densely packed unless a stride is given;
+ *     cone_weights pointers may be host or device (copied once at cone_model_create);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on
+ *     it, nothing synchronises, nothing allocates (scratch comes in through `ws`);
+ *   - return value 0 = success, negative = error (CONE_E_*), text in cone_last_error();
+ *     nothing throws across the ABI;
+ *   - a cone_model is immutable after creation: one handle may be used from several
+ *     streams/threads concurrently as long as each call has its own workspace.
+ */
+#ifndef CONE_HIP_H
+#define CONE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONE_HIP_ABI_VERSION 1
+
+#define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
+#define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
+#define CONE_E_WORKSPACE (-3) /* workspace too small             */
+
+#define CONE_MAX_LAYERS 8
+#define CONE_MAX_PROJ 3
+
+typedef struct cone_model cone_model;
+
+/* torch.nn.Linear: weight [out][in], bias [out] */
+typedef struct { const float* w; const float* b; } cone_linear_w;
+/* torch.nn.LayerNorm: weight, bias (eps 1e-5) */
+typedef struct { const float* g; const float* b; } cone_ln_w;
+/* torch.nn.MultiheadAttention: packed in_proj [3d][d] rows Wq|Wk|Wv, in_proj_bias [3d] */
+typedef struct { const float* in_proj_w; const float* in_proj_b; cone_linear_w out_proj; } cone_mha_w;
+typedef struct { cone_mha_w self_attn; cone_linear_w linear1, linear2; cone_ln_w norm1, norm2; } cone_enc_layer_w;
+typedef struct {
+    cone_mha_w self_attn, cross_attn;
+    cone_linear_w linear1, linear2;
+    cone_ln_w norm1, norm2, norm3;
+} cone_dec_layer_w;
+
+/* The tensors of CONE.state_dict() (cone/model.py:19-80) that inference reads. */
+typedef struct {
+    int32_t hidden_dim, nheads, dim_ff, enc_layers, dec_layers, num_queries;
+    int32_t n_input_proj, t_dim, v_dim, has_adapter;
+    cone_ln_w vid_proj_ln[CONE_MAX_PROJ]; cone_linear_w vid_proj[CONE_MAX_PROJ]; /* input_vid_proj.{i} */
+    cone_ln_w txt_proj_ln[CONE_MAX_PROJ]; cone_linear_w txt_proj[CONE_MAX_PROJ]; /* input_txt_proj.{i} */
+    cone_enc_layer_w enc[CONE_MAX_LAYERS];   /* transformer.encoder.layers.{i} */
+    cone_dec_layer_w dec[CONE_MAX_LAYERS];   /* transformer.decoder.layers.{i} */
+    cone_ln_w dec_norm;                      /* transformer.decoder.norm        */
+    const float* query_embed;                /* query_embed.weight [Nq][d]      */
+    cone_linear_w class_embed;               /* [2][d]                          */
+    cone_linear_w span_embed[3];             /* span_embed.layers.{0,1,2}       */
+    cone_linear_w saliency_proj;             /* [1][d]                          */
+    cone_linear_w adapter[2];                /* adapter_layer.layers.{0,1}      */
+    const float* pos_dim_t;                  /* [d] temperature**(2*(i//2)/d), cone/position_encoding.py:66-67 */
+} cone_weights;
+
+const char* cone_last_error(void);
+int cone_abi_version(void);
+
+/* build_model + load_state_dict (cone/model.py:468-521, cone/inference.py:525-527). */
+int cone_model_create(const cone_weights* w, cone_model** out);
+void cone_model_destroy(cone_model* m);
+
+/* ------------------------------------------------------------------ stage A: pre-filter */
+
+/* A2, cone/inference.py:254-258: out = adapter(x)+x, then out /= ||out||_2 (no eps), row-wise.
+ * x,out (n_rows, v_dim).  ws >= cone_adapter_norm_workspace(m, n_rows) bytes. */
+size_t cone_adapter_norm_workspace(const cone_model* m, int64_t n_rows);
+int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* x / (||x||_2 + eps) row-wise: l2_normalize_np_array (utils/basic_utils.py:97-99). */
+int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, float* out, void* stream);
+
+/* A3+A4, cone/inference.py:284-296: frame_scores[q][f] = <vid[f], txt[q]>;
+ * win_scores[q][i] = max(frame_scores[q][max((i-1)S,0) : min((i-1)S+W, ctx_l)]),
+ * num_window = ceil(ctx_l/S)+1.  vid (ctx_l,dv), txt (nq,dv), frame_scores (nq,ctx_l) scratch+output,
+ * win_scores (nq,num_window). */
+int64_t cone_num_windows(int64_t ctx_l, int W);
+int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq,
+                          int W, int S, float* frame_scores, float* win_scores, void* stream);
+
+/* A4, cone/inference.py:297-299 (+ [:topk], cone/ego4d_mad_dataloader.py:146): the first k entries
+ * of the descending sort of each row of win_scores (nq,num_window); ties -> lower window index
+ * first (stable order).  idx (nq,k) int32, val (nq,k) fp32 (val may be NULL). */
+int cone_topk_windows(const float* win_scores, int nq, int64_t num_window, int k,
+                      int32_t* idx, float* val, void* stream);
+
+/* --------------------------------------------------------- stage B: intra-window model */
+
+/* A6, cone/model.py:100-101 (input_vid_proj / input_txt_proj): row-wise LN->Linear->ReLU->LN->Linear.
+ * which: 0 = video (v_dim in), 1 = text (t_dim in).  x (n_rows,din), out (n_rows,d). */
+size_t cone_project_workspace(const cone_model* m, int which, int64_t n_rows);
+int cone_project_tokens(const cone_model* m, int which, const float* x, int64_t n_rows, float* out,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* Optional taps for parity bisecting; any pointer may be NULL. */
+typedef struct {
+    float* memory;     /* (B, Lv_pad+Lq_pad, d): encoder output, valid tokens only, rest 0 */
+    float* hs;         /* (dec_layers, B, Nq, d): decoder outputs after decoder.norm         */
+    float* aux_logits; /* (dec_layers-1, B, Nq, 2)                                          */
+    float* aux_spans;  /* (dec_layers-1, B, Nq, 2)                                          */
+} cone_taps;
+
+/* A6-A11, CONE.forward (cone/model.py:82-128) on zero-padded tensors exactly as
+ * prepare_batch_inputs delivers them: vid (B,Lv_pad,v_dim), txt (B,Lq_pad,t_dim); masks are prefix
+ * masks given as valid lengths vid_len[B], txt_len[B] (int32, device).
+ * Outputs: logits (B,Nq,2), spans (B,Nq,2) = sigmoid(center,width), saliency (B,Lv_pad)
+ * (entries at padded clips are written as 0; the reference leaves them unspecified/unused). */
+size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad);
+int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len,
+                         const float* txt, const int32_t* txt_len, int B, int Lv_pad, int Lq_pad,
+                         float* logits, float* spans, float* saliency, const cone_taps* taps,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* Same computation on already-projected token arenas (cone_project_tokens outputs), windows given
+ * by index: window b = vproj rows [vid_row0[b], +vid_len[b]) followed by tproj rows
+ * [txt_row0[b], +txt_len[b]).  This is how the eval driver avoids re-projecting the clips shared by
+ * overlapping windows and the text replicated across a query's windows.
+ * Lv_max/Lq_max bound the lengths (host-known); saliency is (B, Lv_max). */
+size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max);
+int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
+                        const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
+                        const int32_t* txt_len, int B, int Lv_max, int Lq_max,
+                        float* logits, float* spans, float* saliency, const cone_taps* taps,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* A12, CONE.forward_clip_matching (cone/model.py:130-152,178-210).  Gathered form:
+ * proposal n of window b averages rows [s,e) of the window's clips vid[vid_row0[b] + ...] where
+ * rows >= vid_len[b] count as the zero padding of a (pad_len[b])-long tensor (hazard H3):
+ * mean = sum(rows s..min(e,vid_len)-1) / (min(e,pad_len[b]) - s).
+ * cls (n_cls,dv) rows selected by cls_row[b]; spans (B,Nq,2) (center,width); match (B,Nq). */
+size_t cone_clip_matching_workspace(const cone_model* m, int B);
+int cone_clip_matching_gathered(const cone_model* m, const float* cls, const int32_t* cls_row,
+                                const float* vid, const int32_t* vid_row0, const int32_t* vid_len,
+                                const int32_t* pad_len, const float* spans, int B, float* match,
+                                void* ws, size_t ws_bytes, void* stream);
+/* Padded form with the reference's signature: cls (B,dv), vid (B,Lv_pad,dv). */
+int cone_clip_matching(const cone_model* m, const float* cls, const float* vid, const int32_t* vid_len,
+                       int Lv_pad, const float* spans, int B, float* match,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* A13, cone/inference.py:47-82: rows[b][n] = [st, ed, softmax(logits)[0], match] with
+ * (st,ed) = (cxw->xx(spans) * duration[b] + video_start[b]) * clip_length in fp32, each window's
+ * Nq rows sorted by proposal score (stable, descending) when sort != 0.  rows (B,Nq,4) fp32. */
+int cone_compose_rows(const float* logits, const float* spans, const float* match,
+                      const int32_t* duration, const int32_t* video_start, float clip_length,
+                      int sort, int B, int Nq, float* rows, void* stream);
+
+/* ------------------------------------------------------------ stage C: fusion + NMS */
+
+/* A13 rounding + A14 + A15 for nq queries at once (cone/inference.py:83,103-127,205-217;
+ * utils/temporal_nms.py:25-74), all in fp64 like the reference's Python floats:
+ *   cand (nq,n_max,4) fp32 rows [st,ed,prop,match], n_valid[q] rows used per query;
+ *   every number -> float(f"{x:.4f}"); min-max fusion; dict collapse on (st,ed);
+ *   for score_idx in (2 fused, 0 proposal, 1 matching): stable sort desc, [:max_before],
+ *   greedy NMS (pseudo-IoU, strict >), stop at max_after; nms_thd == -1 -> top max_after.
+ * out_rows (3,nq,max_after,5) fp64 rows [st,ed,prop,match,fused]; out_n (3,nq) int32;
+ * out_idx (3,nq,max_after) int32 = index into the query's cand rows (first occurrence of the key). */
+int cone_fuse_nms(const float* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
+                  int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
+                  void* stream);
+
+/* Same on fp64 candidate rows (e.g. rows that went through Python and are already rounded; the
+ * rounding is idempotent on them). */
+int cone_fuse_nms_f64(const double* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
+                      int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
+                      void* stream);
+
+/* temporal_nms (utils/temporal_nms.py:25-74) on one list: pred (n,3) fp64 [st,ed,score];
+ * keep_idx (max_after) indices into pred in output order, keep_n (1). */
+int cone_temporal_nms(const double* pred, int n, double nms_thd, int max_after,
+                      int32_t* keep_idx, int32_t* keep_n, void* stream);
+
+/* A17, HungarianMatcher cost matrix for one target per window (cone/matcher.py:61-95):
+ * C[b][n] = cost_span*L1(span_n, tgt_b) - cost_giou*GIoU - cost_class*softmax(logits)[0].
+ * logits (B,Nq,2), spans (B,Nq,2) cxw, tgt (B,2) cxw, cost (B,Nq), best (B) = argmin_n. */
+int cone_matcher_cost(const float* logits, const float* spans, const float* tgt, int B, int Nq,
+                      float cost_span, float cost_giou, float cost_class, float* cost, int32_t* best,
+                      void* stream);
+
+/* -------------------------------------------------------------------- test hooks
+ * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
+/* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256). */
+int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
+                   const float* R, const float* ln_g, const float* ln_b, float* C,
+                   int M, int N, int K, int flags, void* stream);
+int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
+                        int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONE_HIP_H */
