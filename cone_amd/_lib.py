@@ -123,6 +123,9 @@ def load():
         raise ConeHipError(
             f"{LIB_PATH} is missing: build the HIP extension with `python -m cone_amd.build` "
             "(hipcc, gfx950). cone_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; importing torch first makes our DT_NEEDED resolve to that
+    # copy, so the process has ONE HIP runtime and torch's streams / allocations are ours too.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -17,10 +17,13 @@ LIB = os.path.join(HERE, "libcone_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "rowops.hip", "attention.hip", "window_ops.hip", "prefilter.hip",
            "postproc.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# Files whose scalar arithmetic must round operation by operation like the reference's torch / Python
+# code (HIP's __fmul_rn & co. are plain operators and would otherwise be contracted into fma).
+NO_CONTRACT = {"window_ops.hip", "postproc.hip"}
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cone_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "cone_hip.h"), __file__]
     return max(os.path.getmtime(h) for h in hdrs)
 
 
@@ -29,7 +32,8 @@ def _compile(src):
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
         return obj
-    cmd = ["hipcc", *FLAGS, "-c", path, "-o", obj]
+    extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
+    cmd = ["hipcc", *FLAGS, *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -97,8 +97,9 @@ def test_layernorm_matches_torch(n, dim):
     ref = torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-5)
     out = torch.empty(n, dim, device=dev)
     lib = _lib.load()
-    _lib.check(lib.cone_test_layernorm(_lib.ptr(x.to(dev)), _lib.ptr(w.to(dev)), _lib.ptr(b.to(dev)),
-                                       _lib.ptr(out), n, dim, _lib.stream()))
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    _lib.check(lib.cone_test_layernorm(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(out), n, dim,
+                                       _lib.stream()))
     assert maxdiff(out, ref) < 1e-5
 
 
@@ -359,13 +360,15 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path):
         assert got == ref_rank
     mr, _ = inf.compute_mr_results(model, store, opt, win_idx)
     assert len(mr) == len(fx["mr_res"])
-    worst = 0.0
+    worst = worst_sec = 0.0
     for a, b in zip(mr, fx["mr_res"]):
         assert a["query_id"] == b["query_id"]
         ra, rb = np.array(a["pred_relevant_windows"]), np.array(b["pred_relevant_windows"])
-        worst = max(worst, np.abs(ra[:, :3] - rb[:, :3]).max())
-    scale = 1.0 if preset == "ego4d" else 1.0
-    assert worst <= 2.5e-4 * scale, worst      # 4-dp rounded seconds: 1e-4 logits -> <= 2 units in the last place
+        worst = max(worst, np.abs(ra[:, 2] - rb[:, 2]).max())
+        worst_sec = max(worst_sec, np.abs(ra[:, :2] - rb[:, :2]).max())
+    assert worst <= 2e-4, worst                      # proposal probability, after 4-dp rounding
+    # seconds = span * window_len * clip_length: the 1e-4 span tolerance scales accordingly
+    assert worst_sec <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4, worst_sec
     # stage C on the REFERENCE's own window rows reproduces its files exactly
     f2, p2, m2 = (inf.postprocessing_format_mad if preset == "mad" else inf.postprocessing_format_ego4d)(fx["mr_res"], opt)
     ext = "jsonl" if preset == "mad" else "json"
@@ -402,7 +405,7 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
     agree = 0
     for a, b in zip(f1, fo):
         ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
-        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 2.5e-4:
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
             agree += 1
     assert agree >= 0.9 * len(f1), agree      # the rest differ only through 4-dp rounding flips upstream of NMS
     # NMS invariants on our own output
