@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the CONE coarse-to-fine inference hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = stages A->C (pre-filter, top-k windows, Moment-DETR window model, proposal matching,
+fusion, 3x NMS, JSON rows) over BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic split
+(1 000 queries over 50 videos, ctx_l~U[850,950), window_len 90, d 256, top-k 20 => 20 000 windows,
+NMS 0.5) with every feature already resident in HBM.  With N>1 every rank runs its own split of that
+size (weak scaling; queries are independent) and the kept rows are all-gathered to rank 0 over RCCL,
+which formats the JSON rows of all shards.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the fp32-MFMA GEMM tile
+that accumulates the most time -- from hipEvent timings taken around each of its launches inside the
+timed region (cone_prof_*), FLOPs = 2*M*N*K with the M actually processed.  `cpu_baseline` times the
+CPU oracle (a torch-CPU port of the reference path) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cone_amd import _lib, synth  # noqa: E402
+from cone_amd import inference as inf  # noqa: E402
+from cone_amd.config import make_opt  # noqa: E402
+from cone_amd.model import build_model  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
+                2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn_kernel", 4: "frame_score_kernel"}
+
+
+def collect_profile():
+    lib = _lib.load()
+    cap = 1 << 16
+    buf = np.zeros((cap, 5), dtype=np.float64)
+    n = lib.cone_prof_collect(buf.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError(lib.cone_last_error().decode())
+    return buf[:n]
+
+
+def roofline_from_profile(rec):
+    per = {}
+    for kind, a, b, c, ms in rec:
+        k = int(kind)
+        if k > 2:
+            continue
+        d = per.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
+        d["ms"] += ms
+        d["flops"] += 2.0 * a * b * c
+        d["launches"] += 1
+    if not per:
+        return None, {}
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    all_ms = sum(v["ms"] for v in per.values())
+    all_fl = sum(v["flops"] for v in per.values())
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": KERNEL_NAMES[dom], "launches": d["launches"],
+            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+            "flops_per_launch": round(d["flops"] / d["launches"]),
+            "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
+    extra = {KERNEL_NAMES[k]: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in per.items()}
+    for kind in (3, 4):
+        sel = rec[rec[:, 0] == kind]
+        if len(sel):
+            extra[KERNEL_NAMES[kind]] = {"ms": round(float(sel[:, 4].sum()), 3), "launches": int(len(sel))}
+    return roof, extra
+
+
+def cpu_baseline(opt, sd, n_queries, n_videos):
+    """The CPU oracle (torch-CPU port of the reference path) on a bounded sample of the workload."""
+    from oracle import cone_oracle as O
+    ann, vf, qf = synth.make_dataset(opt, n_queries, n_videos, seed=0)
+    torch.set_num_threads(os.cpu_count())
+    t0 = time.time()
+    (_, _, _), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    dt = time.time() - t0
+    nwin = len(mr)
+    return {"value": round(nwin / dt, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "queries_per_s": round(n_queries / dt, 2),
+            "sample": f"{n_queries} queries / {n_videos} videos / {nwin} windows of the same synthetic "
+                      f"Ego4D-NLQ config, oracle eval_epoch end to end in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--videos", type=int, default=50)
+    ap.add_argument("--window_batch", type=int, default=4096)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_queries", type=int, default=100)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
+                   window_batch=args.window_batch)
+    sd = synth.make_state_dict(opt, 0)
+    model, _ = build_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ann, vf, qf = synth.make_dataset(opt, args.queries, args.videos, seed=rank)
+    store = inf.FeatureStore(opt, ann, vf, qf)          # features resident in HBM from here on
+    lib = _lib.load()
+
+    def step():
+        dp = inf.device_pipeline(model, store, opt)
+        rows, n = dp["rows"], dp["n"]
+        if world > 1:   # the one exchange step: kept rows of every shard -> rank 0 (all_gather over RCCL)
+            rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+            n_all = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
+            dist.all_gather_into_tensor(rows_all, rows.contiguous())
+            dist.all_gather_into_tensor(n_all, n.contiguous())
+            if rank == 0:
+                return [inf.format_results(ann, opt, rows_all[r], n_all[r]) for r in range(world)], dp
+            return None, dp
+        return [inf.format_results(ann, opt, rows, n)], dp
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.cone_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, dp = step()
+    fence()
+    dt = time.perf_counter() - t0
+    rec = collect_profile()
+    lib.cone_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_windows = dp["n_windows"]
+
+    if rank == 0:
+        roof, kern = roofline_from_profile(rec)
+        res = {
+            "metric": "windows/sec + queries/sec, Ego4D-NLQ win_len=90 d=256 top-k=20",
+            "value": round(world * n_windows * args.steps / dt, 1),
+            "unit": "windows/s",
+            "queries_per_s": round(world * args.queries * args.steps / dt, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic, "
+                                   f"{args.queries} queries x {args.videos} videos per GPU, window_len=90, d=256, "
+                                   f"topk_window=20, NMS 0.5, {n_windows} windows per GPU per step",
+                       "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture"},
+            "roofline": roof, "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_queries, max(1, args.cpu_queries * args.videos // args.queries))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,8 @@ _SIGNATURES = {
                                     C.c_void_p]),
     "cone_matcher_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_prof_enable": (C.c_int, [C.c_int]),
+    "cone_prof_collect": (C.c_int64, [C.c_void_p, C.c_int64]),
     # cone_test_gemm(A, A2, a2_mod, W, bias, R, ln_g, ln_b, C, M, N, K, flags, stream)
     "cone_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -129,6 +129,7 @@ int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off,
     if (B <= 0) return 0;
     dim3 grid(B, 8), block(256);
     const int nkb = (Lmax + 31) / 32;
+    ProfScope ps(PK_ENC_ATTN, B, Lmax, 0, nullptr, s);
     if (nkb <= 4) hipLaunchKernelGGL(enc_attn_kernel<4>, grid, block, 0, s, QK, V, OUT, off);
     else if (nkb == 5) hipLaunchKernelGGL(enc_attn_kernel<5>, grid, block, 0, s, QK, V, OUT, off);
     else hipLaunchKernelGGL(enc_attn_kernel<6>, grid, block, 0, s, QK, V, OUT, off);

@@ -59,6 +59,15 @@ __device__ __forceinline__ float half_sum(float v) {
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 #endif
 
+// ---------------------------------------------------------------- opt-in launch timing (prof.hip)
+enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4 };
+bool prof_enabled();
+struct ProfScope {
+    ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
+    ~ProfScope();
+    int idx_; hipStream_t s_;
+};
+
 // ---------------------------------------------------------------- GEMM launcher (gemm.hip)
 enum { EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_LN = 4 };
 

@@ -198,9 +198,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         CONE_REQUIRE(a.N == 256 && a.ln_g && a.ln_b, "gemm: LayerNorm epilogue needs N == 256");
         CONE_REQUIRE(!a.A2, "gemm: LayerNorm epilogue with A2 is not instantiated");
         dim3 grid((a.M + 63) / 64, 1);
+        ProfScope ps(PK_GEMM_64x256, a.M, a.N, a.K, a.M_dev, s);
         hipLaunchKernelGGL((gemm_f32_kernel<64, 256, false>), grid, dim3(256), 0, s, a);
     } else {
         dim3 grid((a.M + 127) / 128, (a.N + 127) / 128);
+        ProfScope ps(a.A2 ? PK_GEMM_128x128_A2 : PK_GEMM_128x128, a.M, a.N, a.K, a.M_dev, s);
         if (a.A2) {
             CONE_REQUIRE(a.lda2 % 4 == 0, "gemm: lda2 must be a multiple of 4");
             hipLaunchKernelGGL((gemm_f32_kernel<128, 128, true>), grid, dim3(256), 0, s, a);

@@ -116,6 +116,7 @@ static int launch_frame_scores(const float* vid, int64_t ctx_l, const float* txt
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: 8 workgroups per CU
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
+        ProfScope ps(PK_FRAME_SCORE, ctx_l, 256 * VPL, rem >= 4 ? 4 : (rem >= 2 ? 2 : 1), nullptr, s);
         if (rem >= 4) {
             hipLaunchKernelGGL((frame_score_kernel<VPL, 4, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
                                ctx_l, txt, q0, nq, fs);

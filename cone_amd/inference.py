@@ -121,7 +121,6 @@ def prefilter(model, store: FeatureStore, opt):
         k = min(opt.topk_window, ws.shape[1])
         idx, _ = ops.topk_windows(ws, k)
         win_idx[qsel, :k] = idx
-    store.cls_norm = cls_norm
     return win_idx
 
 
@@ -153,17 +152,22 @@ def window_table(store: FeatureStore, opt, win_idx):
 
 # ------------------------------------------------------------------------------------ stage B
 @torch.no_grad()
-def run_windows(model, store: FeatureStore, opt, wt, chunk=None):
+def project_features(model, store: FeatureStore):
+    """Row-wise work shared by every window that contains a clip and by all windows of a query
+    (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors."""
+    return dict(
+        vproj=model.project(0, store.vid_raw),                               # raw features: H2
+        tproj=model.project(1, ops.l2_normalize(store.tok_raw, 1e-5)),       # dataloader :274-275
+        cls_norm=ops.l2_normalize(store.cls_raw, 1e-5),                      # dataloader :277
+    )
+
+
+@torch.no_grad()
+def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
     """CONE.forward + forward_clip_matching + row composition for every window of ``wt``.
     Returns rows (Nw, Nq, 4) fp32 [st, ed, proposal, matching] (sorted per window unless
     --no_sort_results) and the raw model outputs."""
-    if not hasattr(store, "vproj"):
-        # Row-wise input projections are shared by all windows that contain the clip and by all windows
-        # of a query (H12): project each clip / token once.
-        store.vproj = model.project(0, store.vid_raw)                       # raw features: H2
-        store.tproj = model.project(1, ops.l2_normalize(store.tok_raw, 1e-5))  # :274-275
-    if not hasattr(store, "cls_norm"):
-        store.cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)
+    feats = feats or project_features(model, store)
     nw = wt["vid_row0"].shape[0]
     chunk = chunk or int(getattr(opt, "window_batch", 4096))
     Lq_max = max(store.tok_len)
@@ -171,9 +175,9 @@ def run_windows(model, store: FeatureStore, opt, wt, chunk=None):
     for c0 in range(0, nw, chunk):
         sl = slice(c0, min(c0 + chunk, nw))
         g = lambda k: wt[k][sl].contiguous()
-        out = model.forward_packed(store.vproj, g("vid_row0"), g("vid_len"), store.tproj, g("txt_row0"),
+        out = model.forward_packed(feats["vproj"], g("vid_row0"), g("vid_len"), feats["tproj"], g("txt_row0"),
                                    g("txt_len"), opt.max_v_l, Lq_max)
-        match = model.clip_matching_gathered(store.cls_norm, g("cls_row"), store.vid_raw, g("vid_row0"),
+        match = model.clip_matching_gathered(feats["cls_norm"], g("cls_row"), store.vid_raw, g("vid_row0"),
                                              g("vid_len"), g("pad_len"), out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, g("vid_len"), g("video_start"),
                                 opt.clip_length, not opt.no_sort_results)
@@ -201,14 +205,9 @@ def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
 
 # ------------------------------------------------------------------------------------ stage C
 def _rows_to_lists(rows, n):
-    rows, n = rows.cpu(), n.cpu()
-    out = []
-    for t in range(3):
-        per_q = []
-        for q in range(rows.shape[1]):
-            per_q.append(rows[t, q, :int(n[t, q])].tolist())
-        out.append(per_q)
-    return out  # [fused, proposal, matching][query] -> list of [st, ed, prop, match, fused]
+    """(3, nq, max_after, 5) fp64 + counts -> [fused, proposal, matching][query] -> list of rows."""
+    rows, n = rows.cpu().tolist(), n.cpu().tolist()
+    return [[rows[t][q][:n[t][q]] for q in range(len(n[t]))] for t in range(3)]
 
 
 def fuse_and_nms(cand, n_valid, opt):
@@ -294,25 +293,30 @@ def write_submissions(opt, fusion, proposal, matching, save_submission_filename)
 
 
 @torch.no_grad()
-def predict_split(model, store: FeatureStore, opt):
-    """Stages A->C entirely on the device; returns the three submission lists and timing marks."""
-    t0 = time.time()
+def device_pipeline(model, store: FeatureStore, opt):
+    """Stages A->C on the device only: returns the kept rows per query as tensors
+    (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables."""
     win_idx = prefilter(model, store, opt)
     wt = window_table(store, opt, win_idx)
     res = run_windows(model, store, opt, wt)
-    torch.cuda.synchronize()
-    t_model = time.time() - t0
     nq, K = win_idx.shape
     Nq = model.num_queries
     rows = res["rows"]
     cand = torch.zeros(nq, K * Nq, 4, device=rows.device)
     cand.view(nq, K, Nq, 4)[wt["q_of"], wt["slot"]] = rows
     n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
-    lists = fuse_and_nms(cand, n_valid, opt)
+    out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
+    return dict(rows=out_rows, n=out_n, idx=out_idx, win_idx=win_idx, windows=wt, cand=cand,
+                n_windows=int(rows.shape[0]))
+
+
+def format_results(ann, opt, rows, n):
+    """A16 (cone/inference.py:130-202): the three submission lists from the kept rows."""
+    lists = _rows_to_lists(rows, n)
     outs = []
     for t in range(3):
         lst = []
-        for qi, meta in enumerate(store.ann):
+        for qi, meta in enumerate(ann):
             if opt.dset_name == "ego4d":
                 parts = meta["query_id"].split("_")
                 assert len(parts) == 2
@@ -322,7 +326,17 @@ def predict_split(model, store: FeatureStore, opt):
                 o = {"query_id": meta["query_id"], "predicted_times": lists[t][qi], "video_id": meta["video_id"]}
             lst.append(o)
         outs.append(lst)
-    return tuple(outs), dict(win_idx=win_idx, windows=wt, model_seconds=t_model, n_windows=int(rows.shape[0]))
+    return tuple(outs)
+
+
+@torch.no_grad()
+def predict_split(model, store: FeatureStore, opt):
+    """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info."""
+    t0 = time.time()
+    dp = device_pipeline(model, store, opt)
+    torch.cuda.synchronize()
+    dp["model_seconds"] = time.time() - t0
+    return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
 
 
 def eval_epoch(model, store: FeatureStore, opt, save_submission_filename, epoch_i=None, criterion=None,

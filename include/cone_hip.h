@@ -194,6 +194,16 @@ int cone_matcher_cost(const float* logits, const float* spans, const float* tgt,
                       float cost_span, float cost_giou, float cost_class, float* cost, int32_t* best,
                       void* stream);
 
+/* -------------------------------------------------------------------- measurement
+ * Opt-in per-launch timing with hipEvents on the launch stream (used by bench.py for the roofline
+ * line).  cone_prof_enable(1) clears and starts recording, (0) stops.  After synchronising the
+ * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
+ * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
+ * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, 0); kind 4 = frame-score
+ * stream (ctx_l, dv, queries in the launch).  Returns the record count.  Not thread-safe. */
+int cone_prof_enable(int on);
+int64_t cone_prof_collect(double* out, int64_t max_rec);
+
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256). */
