@@ -226,13 +226,14 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 // ------------------------------------------------------------------------------ packed forward
 struct FwdBuffers {
     int* off;
-    float *X, *POS, *QK, *V, *ATT, *X1, *H, *KD, *VD;
+    float *X, *POS, *XP, *QK, *V, *ATT, *X1, *H, *KD, *VD;
     float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP;
 };
 static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, FwdBuffers& f) {
     const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
     f.off = c.take<int>(B + 1);
-    f.X = c.take<float>(M * 256); f.POS = c.take<float>(M * 256); f.QK = c.take<float>(M * 512);
+    f.X = c.take<float>(M * 256); f.POS = c.take<float>(M * 256); f.XP = c.take<float>(M * 256);
+    f.QK = c.take<float>(M * 512);
     f.V = c.take<float>(M * 256); f.ATT = c.take<float>(M * 256); f.X1 = c.take<float>(M * 256);
     f.H = c.take<float>(M * m->ff);
     f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd);
@@ -265,12 +266,11 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int* Mdev = f.off + B;
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
-    RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, B, Lmax, s));
+    RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
 
     for (int l = 0; l < m->n_enc; ++l) {  // cone/transformer.py:233-246
         const EncLayer& e = m->enc[l];
-        GemmArgs g = G(f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
-        g.A2 = f.POS; g.lda2 = 256;
+        GemmArgs g = G(f.XP, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
         RUN(launch_gemm(g, s));                                                             // q | k = (x+pos) W^T
         RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
         RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
@@ -280,15 +280,15 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         RUN(launch_gemm(G(f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
         g = G(f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
         g.R = f.X1; g.ldr = 256; g.ln_g = e.n2.g; g.ln_b = e.n2.b;
+        g.C2 = f.XP; g.ADD = f.POS;     // and x + pos for the next layer's q/k (or the decoder's keys)
         RUN(launch_gemm(g, s));                                                             // norm2(x + ffn)
     }
     const float* MEM = f.X;
 
     // decoder (cone/transformer.py:296-317, 117-146): memory K/V for all layers in two GEMMs
     {
-        GemmArgs g = G(MEM, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
-        g.A2 = f.POS; g.lda2 = 256;
-        RUN(launch_gemm(g, s));
+        GemmArgs g = G(f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
+        RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
         RUN(launch_gemm(G(MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
     }
     CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
@@ -496,11 +496,16 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
 }
 
 extern "C" int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
-                              const float* R, const float* ln_g, const float* ln_b, float* C, int M, int N, int K,
-                              int flags, void* stream) {
+                              const float* R, const float* ln_g, const float* ln_b, float* C, float* C2,
+                              const float* ADD, int M, int N, int K, int flags, void* stream) {
+    set_gemm_variant((flags >> 8) & 3);   // test hook: bits 8-9 pick the tile family (0 auto)
+    flags &= 0xff;
     GemmArgs g = G(A, K, W, K, bias, C, N, M, nullptr, N, K, flags);
     g.A2 = A2; g.lda2 = K; g.a2_mod = a2_mod; g.R = R; g.ldr = N; g.ln_g = ln_g; g.ln_b = ln_b;
-    return launch_gemm(g, (hipStream_t)stream);
+    g.C2 = C2; g.ADD = ADD;
+    const int rc = launch_gemm(g, (hipStream_t)stream);
+    set_gemm_variant(0);
+    return rc;
 }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                                    int dim, void* stream) {

@@ -60,7 +60,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 #endif
 
 // ---------------------------------------------------------------- opt-in launch timing (prof.hip)
-enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4 };
+enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4,
+                PK_GEMM_ROWS = 5, PK_GEMM_ROWS_A2 = 6 };
 bool prof_enabled();
 struct ProfScope {
     ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
@@ -79,11 +80,13 @@ struct GemmArgs {
     const float* R; int ldr;              // residual (M,N), EPI_RESIDUAL
     const float* ln_g; const float* ln_b; // EPI_LN (N == 256)
     float* C; int ldc;
+    float* C2; const float* ADD;          // optional second output C2 = C + ADD (same ldc), row tile only
     int M; const int* M_dev;              // rows; *M_dev wins when non-null (grid sized by M)
     int N, K;
     int flags;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+void set_gemm_variant(int v);
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
@@ -101,8 +104,8 @@ int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const fl
 // ---------------------------------------------------------------- window_ops.hip
 int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s);
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
-                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, int B, int Lmax,
-                    hipStream_t s);
+                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
+                    int Lmax, hipStream_t s);
 int launch_saliency(const float* MEM, const int* off, const int* vlen, const int* qlen, const float* w,
                     const float* bias, float* sal, int Lv_out, float* mem_tap, int Lq_out, int B, hipStream_t s);
 int launch_proposal_mean(const float* vid, const int* vrow0, const int* vlen, const int* pad_len,

@@ -189,11 +189,271 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-owning tile fed by LDS-DMA:  128 x 256 per workgroup, each of the 4 wavefronts owns 32 COMPLETE
+// 256-wide rows (8 MFMA tiles, 128 accumulator registers; one wave per SIMD, 512-register budget).
+//   * global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write): two 48 KiB buffers,
+//     slab t+1 streams in while slab t is multiplied; the only wait is the vmcnt(0)+barrier that ends
+//     a slab.  Each wave-instruction fills 8 rows x 128 B; LDS rows are unpadded and the 16-byte
+//     chunk index is XOR-swizzled with (row>>1)&7 -- applied to the per-lane SOURCE address and to the
+//     ds_read_b128 address (cdna_hip_programming.md rule 21) -- which makes every 16-lane service
+//     group of the operand reads bank-conflict free.
+//   * operands with ds_read_b128: four consecutive k per lane; the MFMA k index is permuted
+//     (half-wave h takes k = 8s+4h+j), legal because A and B agree; it only reorders the fp32 sum.
+//   * a wave holds whole rows, so bias / ReLU / residual / LayerNorm need no LDS and no barrier:
+//     row moments are 8 in-lane adds, a 4-step DPP reduction and one cross-row exchange.
+//   * optional second output C2 = C + ADD (the next layer's "x + pos" operand), so no GEMM on this
+//     path needs a fused addend on its A operand.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over the 32 lanes that share (lane >> 5); every lane of the half-wave gets the total.
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror  -> all 16 lanes of a row hold the row sum
+    v += __shfl_xor(v, 16, 64);  // the other row of this half-wave
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_rows(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// Sum over all 64 lanes, returned wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);                // row_half_mirror
+    v += dpp_mov<0x140>(v);                // row_mirror: every lane holds its 16-lane row sum
+    v += dpp_mov_rows<0x142, 0xA>(v);      // row_bcast15 into rows 1,3
+    v += dpp_mov_rows<0x143, 0xC>(v);      // row_bcast31 into rows 2,3: lanes 48-63 hold the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+constexpr int RT_BM = 128, RT_BN = 256;
+constexpr int RT_EP_LD = RT_BN + 4;                           // epilogue image row stride (floats)
+constexpr int RT_EP_FLOATS = 4 * 8 * RT_EP_LD;                // 4 waves x 8 rows at a time: 33 KiB
+
+#define GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// RBK = k-depth of one LDS slab (32: one workgroup per CU, 96 KiB of slabs; 16: 48 KiB, two workgroups
+// per CU so that one's prologue / epilogue / store drain overlaps the other's MFMAs).
+template <int RBK>
+struct RowTile {
+    static constexpr int CH = RBK / 4;                               // 16-byte chunks per row
+    static constexpr int ROWS_PER_INST = 64 / CH;                    // rows one wave-instruction fills
+    static constexpr int A_INST = RT_BM / ROWS_PER_INST / 4;         // LDS-DMA instructions per wave, A
+    static constexpr int B_INST = RT_BN / ROWS_PER_INST / 4;         //   ... W
+    static constexpr int SLAB = (RT_BM + RT_BN) * RBK;               // floats
+    static constexpr int LDS_FLOATS = (2 * SLAB > RT_EP_FLOATS) ? 2 * SLAB : RT_EP_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    // chunk swizzle: makes every 16-lane ds_read_b128 service group hit 16 distinct 16-byte slots
+    __device__ static __forceinline__ int swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+};
+
+template <int RBK>
+__global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(GemmArgs p) {
+    using T = RowTile<RBK>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int M = p.M;
+    if (p.M_dev) { int md = *p.M_dev; M = md < M ? md : M; }
+    const int m0 = blockIdx.x * RT_BM;
+    if (m0 >= M) return;
+    const int n0 = blockIdx.y * RT_BN;
+    const int K = p.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- LDS-DMA source offsets: lane L of an instruction -> row (L / CH), physical chunk (L % CH)
+    const float* __restrict__ Ab = p.A + (size_t)m0 * p.lda;
+    const float* __restrict__ Wb = p.W + (size_t)n0 * p.ldw;   // N % 256 == 0: no column clamp
+    int a_off[T::A_INST], b_off[T::B_INST];
+#pragma unroll
+    for (int i = 0; i < T::A_INST; ++i) {
+        const int row = (wave * T::A_INST + i) * T::ROWS_PER_INST + lane / T::CH;
+        const int src_row = (m0 + row < M) ? row : (M - 1 - m0);   // rows past M feed unstored outputs
+        a_off[i] = src_row * p.lda + (((lane % T::CH) ^ T::swz(row)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < T::B_INST; ++i) {
+        const int row = (wave * T::B_INST + i) * T::ROWS_PER_INST + lane / T::CH;
+        b_off[i] = row * p.ldw + (((lane % T::CH) ^ T::swz(row)) << 2);
+    }
+    auto stream_slab = [&](int kt, int buf) {
+        float* base = smem + buf * T::SLAB;
+#pragma unroll
+        for (int i = 0; i < T::A_INST; ++i) GLDS16(Ab + a_off[i] + kt * RBK, base + (wave * T::A_INST + i) * 256);
+#pragma unroll
+        for (int i = 0; i < T::B_INST; ++i)
+            GLDS16(Wb + b_off[i] + kt * RBK, base + RT_BM * RBK + (wave * T::B_INST + i) * 256);
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // operand read addresses: chunk (2s+lh) ^ swz(row); swz only depends on li for both operands
+    constexpr int NS = RBK / 8;              // super-steps (8 k-values each) per slab
+    constexpr int NU = NS * 4;               // units of {2 B fragments, 8 MFMAs}
+    int cs[NS];
+#pragma unroll
+    for (int s4 = 0; s4 < NS; ++s4) cs[s4] = ((2 * s4 + lh) ^ T::swz(li)) << 2;
+    const int a_row = (wave * 32 + li) * RBK;
+    const int b_row = RT_BM * RBK + li * RBK;
+
+    const int nk = K / RBK;
+    stream_slab(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stream_slab(kt + 1, cur ^ 1);
+        const float* sb = smem + cur * T::SLAB;
+        // NU units of {two B fragments, 8 MFMAs on two alternating accumulator tiles}.  The fragments of
+        // unit u+1 are requested right before the MFMAs of unit u and consumed (empty asm = the
+        // compiler's lgkmcnt(0)) right after them: their LDS latency hides under 512 matrix-pipe cycles
+        // and the wait never covers a read that was only just issued.
+        f32x4v a = *reinterpret_cast<const f32x4v*>(sb + a_row + cs[0]);
+        f32x4v b0 = *reinterpret_cast<const f32x4v*>(sb + b_row + cs[0]);
+        f32x4v b1 = *reinterpret_cast<const f32x4v*>(sb + b_row + 32 * RBK + cs[0]);
+        f32x4v n0v = *reinterpret_cast<const f32x4v*>(sb + b_row + 2 * 32 * RBK + cs[0]);
+        f32x4v n1v = *reinterpret_cast<const f32x4v*>(sb + b_row + 3 * 32 * RBK + cs[0]);
+        f32x4v an = a;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int t = (u & 3) * 2;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[t + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < NU) {
+                asm volatile("" : "+v"(n0v), "+v"(n1v));     // fragments of unit u+1 have landed
+                b0 = n0v; b1 = n1v;
+                if (((u + 1) & 3) == 0) { asm volatile("" : "+v"(an)); a = an; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 2 < NU) {
+                    const int s2 = (u + 2) >> 2, t2 = ((u + 2) & 3) * 2;
+                    n0v = *reinterpret_cast<const f32x4v*>(sb + b_row + t2 * 32 * RBK + cs[s2]);
+                    n1v = *reinterpret_cast<const f32x4v*>(sb + b_row + (t2 + 1) * 32 * RBK + cs[s2]);
+                    if (t2 == 0) an = *reinterpret_cast<const f32x4v*>(sb + a_row + cs[s2]);
+                }
+            }
+        }
+        __syncthreads();   // vmcnt(0): slab kt+1 landed; barrier: everyone is done reading slab kt
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // The accumulator layout (a lane owns one column of 16 scattered rows) would cost 128 dword stores per
+    // lane; instead each wave parks 8 complete rows at a time in LDS (free after the last slab) and walks
+    // them with one float4 per lane: bias / ReLU / residual / LayerNorm / C2 act on a whole 1-KiB row per
+    // wave-instruction (fully coalesced); row moments are a DPP wave reduction.
+    const int flags = p.flags;
+    const int mrow0 = m0 + wave * 32;
+    float* ep = smem + wave * (8 * RT_EP_LD);
+    const int c4 = lane * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = bias4, be4 = bias4;
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
+    if (flags & EPI_LN) {
+        g4 = *reinterpret_cast<const float4*>(p.ln_g + c4);
+        be4 = *reinterpret_cast<const float4*>(p.ln_b + c4);
+    }
+    const int rows_here = min(32, M - mrow0);   // wave-uniform, may be <= 0 for a wave past M
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {               // rows 8g .. 8g+7 of this wave = accumulator registers 4g .. 4g+3
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int rr4 = 0; rr4 < 4; ++rr4)
+                ep[(rr4 + 4 * lh) * RT_EP_LD + t * 32 + li] = acc[t][4 * g + rr4];
+        __syncthreads();
+        float4 v[8], rr[8], ad[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int i = min(8 * g + k, rows_here - 1);
+            i = i < 0 ? 0 : i;
+            const size_t m = (size_t)min(mrow0 + i, M - 1);
+            if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + m * p.ldr + n0 + c4);
+            if (p.C2) ad[k] = *reinterpret_cast<const float4*>(p.ADD + m * p.ldc + n0 + c4);
+            v[k] = *reinterpret_cast<const float4*>(ep + k * RT_EP_LD + c4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float4 x = v[k];
+            x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+            if (flags & EPI_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+            if (flags & EPI_RESIDUAL) { x.x += rr[k].x; x.y += rr[k].y; x.z += rr[k].z; x.w += rr[k].w; }
+            if (flags & EPI_LN) {   // N == 256 == BN: the wave holds the complete row
+                const float mean = wave_sum_dpp((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+                const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+                const float var = wave_sum_dpp((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                x.x = d0 * rstd * g4.x + be4.x; x.y = d1 * rstd * g4.y + be4.y;
+                x.z = d2 * rstd * g4.z + be4.z; x.w = d3 * rstd * g4.w + be4.w;
+            }
+            if (8 * g + k < rows_here) {
+                const size_t m = (size_t)(mrow0 + 8 * g + k);
+                *reinterpret_cast<float4*>(p.C + m * p.ldc + n0 + c4) = x;
+                if (p.C2) {
+                    x.x += ad[k].x; x.y += ad[k].y; x.z += ad[k].z; x.w += ad[k].w;
+                    *reinterpret_cast<float4*>(p.C2 + m * p.ldc + n0 + c4) = x;
+                }
+            }
+        }
+    }
+}
+
+static int g_gemm_variant = 0;  // 0 auto, 1 force register-staged tiles, 2/3 force the row tile (test hook A/B)
+static int g_rows_bk = 16;      // slab depth of the row tile: 16 (two workgroups per CU) or 32 (one)
+void set_gemm_variant(int v) {
+    g_gemm_variant = v == 3 ? 2 : v;
+    if (v == 2) g_rows_bk = 16;
+    if (v == 3) g_rows_bk = 32;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     CONE_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4");
     CONE_REQUIRE(!(a.flags & EPI_RESIDUAL) || a.R, "gemm: residual flag without R");
     if (a.M <= 0) return 0;
+    if (a.flags & EPI_LN) CONE_REQUIRE(a.N == 256 && a.ln_g && a.ln_b, "gemm: LayerNorm epilogue needs N == 256");
+    const bool rows_ok = a.N % 256 == 0 && !a.A2;
+    // The tile family is a function of the SHAPE only (never of M), so a row of C is computed by the same
+    // instruction sequence whatever batch it sits in: results are bit-identical across batch compositions.
+    const bool use_rows = rows_ok && g_gemm_variant != 1;
+    const bool need_rows = a.C2 != nullptr;
+    CONE_REQUIRE(!need_rows || (rows_ok && a.ADD), "gemm: second output needs the row tile (N %% 256 == 0, no A2)");
+    if (use_rows || need_rows) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               RowTile<32>::LDS_BYTES));
+            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               RowTile<16>::LDS_BYTES));
+            attr_set = true;
+        }
+        dim3 grid((a.M + RT_BM - 1) / RT_BM, a.N / RT_BN);
+        ProfScope ps(PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);
+        if (g_rows_bk == 32)
+            hipLaunchKernelGGL(gemm_rows_kernel<32>, grid, dim3(256), RowTile<32>::LDS_BYTES, s, a);
+        else
+            hipLaunchKernelGGL(gemm_rows_kernel<16>, grid, dim3(256), RowTile<16>::LDS_BYTES, s, a);
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.flags & EPI_LN) {
         CONE_REQUIRE(a.N == 256 && a.ln_g && a.ln_b, "gemm: LayerNorm epilogue needs N == 256");
         CONE_REQUIRE(!a.A2, "gemm: LayerNorm epilogue with A2 is not instantiated");

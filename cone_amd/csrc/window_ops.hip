@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__
                                                        const int* __restrict__ trow0,
                                                        const int* __restrict__ qlen,
                                                        const int* __restrict__ off,
-                                                       const float* __restrict__ dim_t, float* X, float* POS) {
+                                                       const float* __restrict__ dim_t, float* X, float* POS,
+                                                       float* XP) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -66,14 +67,16 @@ __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__
     }
     reinterpret_cast<float4*>(X + dst)[lane] = x;
     reinterpret_cast<float4*>(POS + dst)[lane] = ps;
+    // x + pos: the q/k operand of the first encoder layer (cone/transformer.py:237)
+    reinterpret_cast<float4*>(XP + dst)[lane] = make_float4(x.x + ps.x, x.y + ps.y, x.z + ps.z, x.w + ps.w);
 }
 
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
-                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, int B, int Lmax,
-                    hipStream_t s) {
+                    const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
+                    int Lmax, hipStream_t s) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(pack_pos_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, vproj, vrow0, vlen, tproj,
-                       trow0, qlen, off, dim_t, X, POS);
+                       trow0, qlen, off, dim_t, X, POS, XP);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -206,10 +206,12 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
 
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
-/* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256). */
+/* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
+ * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning
+ * LDS-DMA tile, 0 = automatic).  Optional second output C2 = C + ADD (row tile only). */
 int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
-                   const float* R, const float* ln_g, const float* ln_b, float* C,
-                   int M, int N, int K, int flags, void* stream);
+                   const float* R, const float* ln_g, const float* ln_b, float* C, float* C2,
+                   const float* ADD, int M, int N, int K, int flags, void* stream);
 int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                         int dim, void* stream);
 

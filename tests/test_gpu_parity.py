@@ -52,6 +52,13 @@ def maxdiff(a, b):
     (257, 256, 1024, 2, False), (64, 256, 768, 0, False), (200, 256, 256, 2 | 4, False),
     (63, 256, 1024, 1 | 2 | 4, False), (517, 512, 256, 0, True), (35, 256, 256, 0, "mod5"),
     (1000, 256, 512, 1 | 4, False),
+    # the 128x256 row-owning LDS-DMA tile, forced (bit 9)
+    (300, 256, 256, 0x200, False), (129, 512, 256, 0x200 | 1, False), (1, 1024, 256, 0x200 | 1, False),
+    (257, 256, 1024, 0x200 | 2, False), (64, 256, 768, 0x200, False), (200, 256, 256, 0x200 | 2 | 4, False),
+    (63, 256, 1024, 0x200 | 1 | 2 | 4, False), (1000, 256, 512, 0x200 | 1 | 4, False),
+    (5000, 512, 256, 0x200 | 2, False), (4097, 256, 256, 2 | 4, False), (3001, 256, 1024, 0x200 | 2 | 4, "c2"),
+    (300, 256, 256, 0x300, False), (257, 256, 1024, 0x300 | 2 | 4, False), (1000, 512, 768, 0x300 | 1, False),
+    (3001, 256, 256, 0x300 | 2 | 4, "c2"),
 ])
 def test_gemm_matches_torch(M, N, K, flags, a2):
     from cone_amd import _lib
@@ -64,6 +71,9 @@ def test_gemm_matches_torch(M, N, K, flags, a2):
     lg, lb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
     A2 = None
     mod = 0
+    want_c2 = a2 == "c2"
+    if want_c2:
+        a2 = False
     if a2 == "mod5":
         A2, mod = torch.randn(5, K, generator=g), 5
     elif a2:
@@ -80,11 +90,15 @@ def test_gemm_matches_torch(M, N, K, flags, a2):
     d = lambda t: None if t is None else t.to(dev).contiguous()
     Ad, Wd, bd, Rd, gd, bd2, A2d = d(A), d(W), d(bias), d(R), d(lg), d(lb), d(A2)
     C = torch.full((M, N), float("nan"), device=dev)
+    ADD = torch.randn(M, N, generator=g).to(dev) if want_c2 else None
+    C2 = torch.full((M, N), float("nan"), device=dev) if want_c2 else None
     _lib.check(lib.cone_test_gemm(_lib.ptr(Ad), _lib.ptr(A2d), mod, _lib.ptr(Wd), _lib.ptr(bd),
                                   _lib.ptr(Rd) if flags & 2 else None, _lib.ptr(gd), _lib.ptr(bd2), _lib.ptr(C),
-                                  M, N, K, flags, _lib.stream()))
+                                  _lib.ptr(C2), _lib.ptr(ADD), M, N, K, flags, _lib.stream()))
     torch.cuda.synchronize()
     assert maxdiff(C, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    if want_c2:
+        assert torch.equal(C2, C + ADD)
 
 
 @pytest.mark.parametrize("n,dim", [(5, 256), (1000, 768), (3, 512), (77, 1024)])
