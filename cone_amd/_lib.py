@@ -70,6 +70,9 @@ _SIGNATURES = {
     "cone_num_windows": (C.c_int64, [C.c_int64, C.c_int]),
     "cone_prefilter_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_prefilter_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cone_topk_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),
     "cone_project_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -288,13 +288,16 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
         const int row = (wave * T::B_INST + i) * T::ROWS_PER_INST + lane / T::CH;
         b_off[i] = row * p.ldw + (((lane % T::CH) ^ T::swz(row)) << 2);
     }
-    auto stream_slab = [&](int kt, int buf) {
+    // piece i of a slab: one wave-instruction (1 KiB) of this wave's share
+    auto stream_piece = [&](int kt, int buf, int i) {
         float* base = smem + buf * T::SLAB;
+        if (i < T::A_INST) GLDS16(Ab + a_off[i] + kt * RBK, base + (wave * T::A_INST + i) * 256);
+        else GLDS16(Wb + b_off[i - T::A_INST] + kt * RBK, base + RT_BM * RBK + (wave * T::B_INST + i - T::A_INST) * 256);
+    };
+    constexpr int NPIECE = T::A_INST + T::B_INST;
+    auto stream_slab = [&](int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < T::A_INST; ++i) GLDS16(Ab + a_off[i] + kt * RBK, base + (wave * T::A_INST + i) * 256);
-#pragma unroll
-        for (int i = 0; i < T::B_INST; ++i)
-            GLDS16(Wb + b_off[i] + kt * RBK, base + RT_BM * RBK + (wave * T::B_INST + i) * 256);
+        for (int i = 0; i < NPIECE; ++i) stream_piece(kt, buf, i);
     };
 
     f32x16 acc[8];
@@ -317,7 +320,10 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stream_slab(kt + 1, cur ^ 1);
+        const bool more = kt + 1 < nk;
+        // The next slab's LDS-DMA pieces are issued one per unit, in the shadow of that unit's MFMAs,
+        // instead of as one burst ahead of the first MFMA (in-order issue would drain the matrix pipe).
+        constexpr int PPU = (NPIECE + 7) / 8 > 0 ? (NPIECE + (RBK / 8) * 4 - 1) / ((RBK / 8) * 4) : 1;   // pieces per unit
         const float* sb = smem + cur * T::SLAB;
         // NU units of {two B fragments, 8 MFMAs on two alternating accumulator tiles}.  The fragments of
         // unit u+1 are requested right before the MFMAs of unit u and consumed (empty asm = the
@@ -339,6 +345,12 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
                 acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[t + 1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int pp = 0; pp < PPU; ++pp)
+                    if (u * PPU + pp < NPIECE) stream_piece(kt + 1, cur ^ 1, u * PPU + pp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (u + 1 < NU) {
                 asm volatile("" : "+v"(n0v), "+v"(n1v));     // fragments of unit u+1 have landed
                 b0 = n0v; b1 = n1v;

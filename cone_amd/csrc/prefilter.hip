@@ -108,6 +108,120 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sc,
     }
 }
 
+// ---- segmented forms: all queries of a split in three launches --------------------------------
+// A group = one video and up to 4 of its queries (the clip rows are read once per group).
+template <int VPL>
+__global__ __launch_bounds__(256) void frame_score_groups_kernel(const float* __restrict__ arena,
+                                                                 const float* __restrict__ cls,
+                                                                 const int64_t* __restrict__ g_row0,
+                                                                 const int* __restrict__ g_ctx_l,
+                                                                 const int* __restrict__ g_q,
+                                                                 const int64_t* __restrict__ q_fs_off,
+                                                                 float* __restrict__ fs) {
+    constexpr int DV = 256 * VPL, RPW = 4;
+    const int g = blockIdx.y;
+    const int ctx_l = g_ctx_l[g];
+    const int lane = threadIdx.x & 63;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    if (wave_id * RPW >= ctx_l) return;
+    const float* vid = arena + g_row0[g] * DV;
+    int qi[4];
+    float4 q[4][VPL];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qi[j] = g_q[g * 4 + j];
+        const int src = qi[j] >= 0 ? qi[j] : g_q[g * 4];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) q[j][v] = reinterpret_cast<const float4*>(cls + (size_t)src * DV)[lane + 64 * v];
+    }
+    for (int r0 = wave_id * RPW; r0 < ctx_l; r0 += n_waves * RPW) {
+        float4 x[RPW][VPL];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = min(r0 + r, ctx_l - 1);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) x[r][v] = reinterpret_cast<const float4*>(vid + (size_t)row * DV)[lane + 64 * v];
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v)
+                    s += (x[r][v].x * q[j][v].x + x[r][v].y * q[j][v].y) + (x[r][v].z * q[j][v].z + x[r][v].w * q[j][v].w);
+                s = wave_sum(s);
+                if (lane == 0 && r0 + r < ctx_l && qi[j] >= 0) fs[q_fs_off[qi[j]] + r0 + r] = s;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void window_max_seg_kernel(const float* __restrict__ fs,
+                                                             const int64_t* __restrict__ q_fs_off,
+                                                             const int64_t* __restrict__ q_win_off,
+                                                             const int* __restrict__ q_ctx_l, int W, int S,
+                                                             float* __restrict__ win) {
+    const int q = blockIdx.y;
+    const int ctx_l = q_ctx_l[q];
+    const int nw = (ctx_l + S - 1) / S + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const int s = max((i - 1) * S, 0), e = min((i - 1) * S + W, ctx_l);
+    const float* f = fs + q_fs_off[q];
+    float m = -INFINITY;
+    for (int t = s; t < e; ++t) m = fmaxf(m, f[t]);
+    win[q_win_off[q] + i] = m;
+}
+
+__global__ __launch_bounds__(256) void topk_seg_kernel(const float* __restrict__ win,
+                                                       const int64_t* __restrict__ q_win_off,
+                                                       const int* __restrict__ q_ctx_l, int S, int k,
+                                                       int32_t* __restrict__ idx) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ float best_v;
+    __shared__ int best_i;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (q_ctx_l[q] + S - 1) / S + 1;
+    const float* row = win + q_win_off[q];
+    float last_v = INFINITY;
+    int last_i = -1;
+    for (int p = 0; p < k; ++p) {
+        if (p >= n) {   // fewer windows than k: pad with -1 (uniform branch)
+            if (tid == 0) idx[(size_t)q * k + p] = -1;
+            continue;
+        }
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < n; j += 256) {
+            const float v = row[j];
+            const bool after = (v < last_v) || (v == last_v && j > last_i);
+            if (after && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_v[0];
+            int i = s_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
+            best_v = v; best_i = i;
+            idx[(size_t)q * k + p] = i == 0x7fffffff ? -1 : i;
+        }
+        __syncthreads();
+        last_v = best_v;
+        last_i = best_i;
+        __syncthreads();
+    }
+}
+
 template <int VPL>
 static int launch_frame_scores(const float* vid, int64_t ctx_l, const float* txt, int nq, float* fs,
                                hipStream_t s) {
@@ -161,6 +275,40 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
     const int64_t nw = (ctx_l + S - 1) / S + 1;
     hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nw + 255) / 256), nq), dim3(256), 0, s,
                        frame_scores, ctx_l, W, S, nw, win_scores);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cone_prefilter_batched(const float* arena, int dv, const float* cls, const int64_t* g_row0,
+                                      const int32_t* g_ctx_l, const int32_t* g_q, int ng, int max_ctx_l,
+                                      const int64_t* q_fs_off, const int64_t* q_win_off, const int32_t* q_ctx_l,
+                                      int nq, int W, int S, float* frame_scores, float* win_scores, int k,
+                                      int32_t* topk_idx, void* stream) {
+    CONE_REQUIRE(arena && cls && g_row0 && g_ctx_l && g_q && q_fs_off && q_win_off && q_ctx_l && frame_scores &&
+                     win_scores && topk_idx, "prefilter_batched: null argument");
+    CONE_REQUIRE(ng > 0 && nq > 0 && max_ctx_l > 0 && W > 0 && S > 0 && k > 0, "prefilter_batched: bad sizes");
+    CONE_REQUIRE(dv == 256 || dv == 512 || dv == 768 || dv == 1024,
+                 "prefilter: feature dim %d not in {256,512,768,1024}", dv);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t bx = ((int64_t)max_ctx_l + 15) / 16;
+    if (bx > 2048) bx = 2048;
+    dim3 grid((unsigned)bx, ng);
+    {
+        cone::ProfScope ps(cone::PK_FRAME_SCORE, max_ctx_l, dv, ng, nullptr, s);
+        switch (dv / 256) {
+            case 1: hipLaunchKernelGGL(cone::frame_score_groups_kernel<1>, grid, dim3(256), 0, s, arena, cls, g_row0, g_ctx_l, g_q, q_fs_off, frame_scores); break;
+            case 2: hipLaunchKernelGGL(cone::frame_score_groups_kernel<2>, grid, dim3(256), 0, s, arena, cls, g_row0, g_ctx_l, g_q, q_fs_off, frame_scores); break;
+            case 3: hipLaunchKernelGGL(cone::frame_score_groups_kernel<3>, grid, dim3(256), 0, s, arena, cls, g_row0, g_ctx_l, g_q, q_fs_off, frame_scores); break;
+            default: hipLaunchKernelGGL(cone::frame_score_groups_kernel<4>, grid, dim3(256), 0, s, arena, cls, g_row0, g_ctx_l, g_q, q_fs_off, frame_scores); break;
+        }
+    }
+    CONE_LAUNCH_CHECK();
+    const int max_nw = (max_ctx_l + S - 1) / S + 1;
+    hipLaunchKernelGGL(cone::window_max_seg_kernel, dim3((max_nw + 255) / 256, nq), dim3(256), 0, s, frame_scores,
+                       q_fs_off, q_win_off, q_ctx_l, W, S, win_scores);
+    CONE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cone::topk_seg_kernel, dim3(nq), dim3(256), 0, s, win_scores, q_win_off, q_ctx_l, S, k,
+                       topk_idx);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -69,6 +69,34 @@ class FeatureStore:
         self.tok_raw = torch.from_numpy(np.concatenate(toks, 0)).to(dev)
         self.cls_raw = torch.from_numpy(np.stack(clss, 0)).to(dev)
         self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
+        self._plan = None
+
+    def prefilter_plan(self):
+        """Static index metadata of the pre-filter (depends on the annotation file only): groups of one
+        video x up to 4 of its queries, and per-query offsets into the flat score buffers."""
+        if self._plan is not None:
+            return self._plan
+        S = int(self.opt.max_v_l / 2)
+        by_vid = OrderedDict()
+        for qi, v in enumerate(self.q_vid.tolist()):
+            by_vid.setdefault(v, []).append(qi)
+        g_row0, g_ctx_l, g_q = [], [], []
+        for v, qis in by_vid.items():
+            for c0 in range(0, len(qis), 4):
+                grp = qis[c0:c0 + 4]
+                g_row0.append(int(self.vid_off[v])); g_ctx_l.append(self.ctx_l[v])
+                g_q.append(grp + [-1] * (4 - len(grp)))
+        q_ctx = np.array([self.ctx_l[v] for v in self.q_vid.tolist()], dtype=np.int64)
+        q_nw = (q_ctx + S - 1) // S + 1
+        dev = self.device
+        t = lambda a, dt: torch.tensor(np.asarray(a), dtype=dt, device=dev)
+        self._plan = dict(
+            g_row0=t(g_row0, torch.int64), g_ctx_l=t(g_ctx_l, torch.int32), g_q=t(g_q, torch.int32).contiguous(),
+            ng=len(g_row0), max_ctx_l=int(max(self.ctx_l)),
+            q_fs_off=t(np.concatenate([[0], np.cumsum(q_ctx)[:-1]]), torch.int64),
+            q_win_off=t(np.concatenate([[0], np.cumsum(q_nw)[:-1]]), torch.int64),
+            q_ctx_l=t(q_ctx, torch.int32), fs_total=int(q_ctx.sum()), win_total=int(q_nw.sum()))
+        return self._plan
 
     @classmethod
     def from_lmdb(cls, opt):
@@ -109,18 +137,7 @@ def prefilter(model, store: FeatureStore, opt):
     vid_norm = ops.l2_normalize(store.vid_raw, 1e-5)          # PreFilteringDataset :459
     ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
     cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)          # :473
-    nq = len(store.ann)
-    win_idx = torch.full((nq, opt.topk_window), -1, dtype=torch.int32, device=dev)
-    by_vid = OrderedDict()
-    for qi, v in enumerate(store.q_vid.tolist()):
-        by_vid.setdefault(v, []).append(qi)
-    for v, qis in by_vid.items():
-        r0, r1 = int(store.vid_off[v]), int(store.vid_off[v + 1])
-        qsel = torch.tensor(qis, dtype=torch.long, device=dev)
-        _, ws = ops.prefilter_scores(ctx[r0:r1], cls_norm.index_select(0, qsel).contiguous(), opt.max_v_l)
-        k = min(opt.topk_window, ws.shape[1])
-        idx, _ = ops.topk_windows(ws, k)
-        win_idx[qsel, :k] = idx
+    win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, store.prefilter_plan(), opt.max_v_l, opt.topk_window)
     return win_idx
 
 

@@ -50,6 +50,25 @@ def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int)
     return fs, ws
 
 
+def prefilter_batched(ctx_arena, cls_norm, plan, max_v_l: int, k: int):
+    """cone/inference.py:276-301 for every query of a split in three launches.  `plan` is the static
+    index metadata built by FeatureStore.prefilter_plan().  Returns (topk_idx (nq,k) int32 with -1
+    padding, frame_scores flat, win_scores flat)."""
+    lib = _lib.load()
+    dev = ctx_arena.device
+    nq = cls_norm.shape[0]
+    fs = torch.empty(plan["fs_total"], device=dev)
+    ws = torch.empty(plan["win_total"], device=dev)
+    idx = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    _lib.check(lib.cone_prefilter_batched(
+        _lib.ptr(ctx_arena, torch.float32), ctx_arena.shape[1], _lib.ptr(cls_norm, torch.float32),
+        _lib.ptr(plan["g_row0"], torch.int64), _lib.ptr(plan["g_ctx_l"], torch.int32),
+        _lib.ptr(plan["g_q"], torch.int32), plan["ng"], plan["max_ctx_l"], _lib.ptr(plan["q_fs_off"], torch.int64),
+        _lib.ptr(plan["q_win_off"], torch.int64), _lib.ptr(plan["q_ctx_l"], torch.int32), nq, max_v_l,
+        int(max_v_l / 2), _lib.ptr(fs), _lib.ptr(ws), k, _lib.ptr(idx), _lib.stream()))
+    return idx, fs, ws
+
+
 def topk_windows(win_scores: torch.Tensor, k: int):
     """First k of the stable descending sort of each row (cone/inference.py:297-299, H6)."""
     lib = _lib.load()

@@ -101,6 +101,19 @@ int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* 
 int cone_topk_windows(const float* win_scores, int nq, int64_t num_window, int k,
                       int32_t* idx, float* val, void* stream);
 
+/* A3+A4 for a whole split in three launches.  The clip features of all videos sit back to back in
+ * `arena` (rows, dv).  A group g = one video (rows g_row0[g] .. +g_ctx_l[g]) and up to 4 of its
+ * queries g_q[g][0..3] (indices into cls (nq,dv); -1 = unused slot), so a video's rows are read once
+ * per group.  Query q writes its frame scores at frame_scores + q_fs_off[q] (q_ctx_l[q] values) and its
+ * window scores at win_scores + q_win_off[q]; topk_idx (nq,k) receives the first k windows of the
+ * stable descending order, padded with -1 when the video has fewer than k windows.
+ * max_ctx_l bounds every ctx_l (host-known, sizes the grid). */
+int cone_prefilter_batched(const float* arena, int dv, const float* cls, const int64_t* g_row0,
+                           const int32_t* g_ctx_l, const int32_t* g_q, int ng, int max_ctx_l,
+                           const int64_t* q_fs_off, const int64_t* q_win_off, const int32_t* q_ctx_l,
+                           int nq, int W, int S, float* frame_scores, float* win_scores, int k,
+                           int32_t* topk_idx, void* stream);
+
 /* --------------------------------------------------------- stage B: intra-window model */
 
 /* A6, cone/model.py:100-101 (input_vid_proj / input_txt_proj): row-wise LN->Linear->ReLU->LN->Linear.

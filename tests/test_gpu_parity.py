@@ -271,6 +271,33 @@ def test_prefilter_edge_shapes(ctx_l, W, dv, nq):
         assert idx[q].cpu().tolist() == O.rank_windows(ws[q].cpu())[:k]
 
 
+def test_prefilter_batched_equals_per_video_path():
+    """The three-launch segmented pre-filter is bit-identical to the per-video entry points, including
+    videos with fewer windows than topk (padded with -1)."""
+    from cone_amd import inference as inf
+    from cone_amd import ops
+    dev = _gpu()
+    for preset, ctx_range in (("ego4d", (30, 400)), ("mad", (100, 2000))):
+        opt = make_opt(preset, topk_window=7)
+        ann, vf, qf = synth.make_dataset(opt, 23, 5, seed=2, ctx_range=ctx_range)
+        store = inf.FeatureStore(opt, ann, vf, qf)
+        ctx = ops.l2_normalize(store.vid_raw, 1e-5)
+        cls = ops.l2_normalize(store.cls_raw, 1e-5)
+        plan = store.prefilter_plan()
+        idx, fs, ws = ops.prefilter_batched(ctx, cls, plan, opt.max_v_l, opt.topk_window)
+        for qi in range(len(ann)):
+            v = int(store.q_vid[qi])
+            r0, r1 = int(store.vid_off[v]), int(store.vid_off[v + 1])
+            fs1, ws1 = ops.prefilter_scores(ctx[r0:r1], cls[qi:qi + 1].contiguous(), opt.max_v_l)
+            o = int(plan["q_fs_off"][qi]); w = int(plan["q_win_off"][qi])
+            assert torch.equal(fs[o:o + (r1 - r0)], fs1[0])
+            assert torch.equal(ws[w:w + ws1.shape[1]], ws1[0])
+            k = min(opt.topk_window, ws1.shape[1])
+            i1, _ = ops.topk_windows(ws1, k)
+            assert idx[qi, :k].cpu().tolist() == i1[0].cpu().tolist()
+            assert (idx[qi, k:] == -1).all()
+
+
 def test_topk_ties_are_stable():
     from cone_amd import ops
     dev = _gpu()
