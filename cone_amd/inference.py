@@ -71,6 +71,24 @@ class FeatureStore:
         self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
         self._plan = None
 
+    @classmethod
+    def subset(cls, store, lo: int, hi: int):
+        """View of queries [lo, hi) of `store` (annotation order) sharing its device arenas -- the
+        per-rank shard of a query-sharded multi-GPU run."""
+        sub = cls.__new__(cls)
+        sub.opt, sub.device = store.opt, store.device
+        sub.ann = store.ann[lo:hi]
+        sub.clip_ids, sub.clip2idx, sub.ctx_l, sub.vid_off = store.clip_ids, store.clip2idx, store.ctx_l, store.vid_off
+        sub.vid_raw = store.vid_raw
+        t0, t1 = int(store.tok_off[lo]), int(store.tok_off[hi])
+        sub.tok_raw = store.tok_raw[t0:t1]
+        sub.tok_len = store.tok_len[lo:hi]
+        sub.tok_off = store.tok_off[lo:hi + 1] - t0
+        sub.cls_raw = store.cls_raw[lo:hi]
+        sub.q_vid = store.q_vid[lo:hi]
+        sub._plan = None
+        return sub
+
     def prefilter_plan(self):
         """Static index metadata of the pre-filter (depends on the annotation file only): groups of one
         video x up to 4 of its queries, and per-query offsets into the flat score buffers."""

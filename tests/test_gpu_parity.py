@@ -457,3 +457,30 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
         for i in range(len(pt)):
             for j in range(i + 1, len(pt)):
                 assert O.compute_temporal_iou(pt[i], pt[j]) <= opt.nms_thd
+
+
+def test_distributed_drivers_single_rank_equal_plain_pipeline():
+    """Window- and query-sharded drivers (RCCL backend, world_size 1 on the one-GPU box) reproduce the
+    plain pipeline bit for bit; the 2-rank exchange logic itself is covered on gloo in
+    tests/test_parallel_cpu.py."""
+    import torch.distributed as dist
+    from cone_amd import inference as inf
+    from cone_amd import parallel as par
+    model, _, _ = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(opt, 11, 3, seed=21, ctx_range=(100, 300))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    plain, _ = inf.predict_split(model, store, opt)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for mode in ("window", "query"):
+            got = par.predict_split_distributed(model, store, opt, mode=mode)
+            assert got == plain, mode
+        # a query shard in the middle of the split sees the right arenas
+        sub = inf.FeatureStore.subset(store, 3, 8)
+        part, _ = inf.predict_split(model, sub, opt)
+        assert part[0] == plain[0][3:8]
+    finally:
+        dist.destroy_process_group()
