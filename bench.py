@@ -128,8 +128,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    # Host side of the step is launch glue + list building: a large intra-op pool only adds wake-up latency
+    # (torch.distributed.run sets OMP_NUM_THREADS=1 for the same reason); cpu_baseline() sizes its own pool.
+    torch.set_num_threads(1)
     dist = None
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with a single rank)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -145,7 +149,7 @@ def main():
     def step():
         dp = inf.device_pipeline(model, store, opt)
         rows, n = dp["rows"], dp["n"]
-        if world > 1:   # the one exchange step: kept rows of every shard -> rank 0 (all_gather over RCCL)
+        if use_dist:    # the one exchange step: kept rows of every shard -> rank 0 (all_gather over RCCL)
             rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
             n_all = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
             dist.all_gather_into_tensor(rows_all, rows.contiguous())
@@ -157,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +176,7 @@ def main():
     dt = time.perf_counter() - t0
     rec = collect_profile()
     lib.cone_prof_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,7 +202,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_queries, max(1, args.cpu_queries * args.videos // args.queries))
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

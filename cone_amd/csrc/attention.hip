@@ -22,7 +22,7 @@ namespace cone {
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
 
 template <int NKB>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
+__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
                                                        const float* __restrict__ V,   // (M,256)
                                                        float* __restrict__ OUT,       // (M,256)
                                                        const int* __restrict__ off) {
@@ -76,27 +76,29 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
                     sc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], qv[t], sc[kb], 0, 0, 0);
             }
         }
-        // softmax over keys: registers (half of each key block) + the other half-wave
+        // softmax over keys: registers (half of each key block) + the other half-wave.  Only the last key
+        // block can hold padding; exp(s - m) is one fma + one v_exp_f32 (exp2((s - m) * log2 e)).
         float m = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
             if (kb < nkb) {
+                if (kb == nkb - 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + acc_row(r, lane);
-                    const float s = key < L ? sc[kb][r] : -INFINITY;
-                    sc[kb][r] = s;
-                    m = fmaxf(m, s);
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + acc_row(r, lane) >= L) sc[kb][r] = -INFINITY;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[kb][r]);
             }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m2 = m * 1.4426950408889634f;
         float l = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
             if (kb < nkb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = expf(sc[kb][r] - m);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], 1.4426950408889634f, -m2));
                     sc[kb][r] = e;
                     l += e;
                 }

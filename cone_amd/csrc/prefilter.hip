@@ -265,6 +265,21 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
                  "prefilter: feature dim %d not in {256,512,768,1024}", dv);
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (nq >= 8 && ctx_l < (1ll << 31)) {
+        // Many queries over one video: frame_scores (nq, ctx_l) = txt . vid^T is a GEMM whose "weight"
+        // operand is the clip arena itself ([N = ctx_l][K = dv], read once for all queries) -- the
+        // fp32-MFMA tile instead of nq/4 VALU passes over the features (BASELINE config 5).
+        cone::GemmArgs g{};
+        g.A = txt; g.lda = dv; g.W = vid; g.ldw = dv; g.C = frame_scores; g.ldc = (int)ctx_l;
+        g.M = nq; g.N = (int)ctx_l; g.K = dv;
+        rc = cone::launch_gemm(g, s);
+        if (rc) return rc;
+        const int64_t nwg = (ctx_l + S - 1) / S + 1;
+        hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nwg + 255) / 256), nq), dim3(256), 0, s,
+                           frame_scores, ctx_l, W, S, nwg, win_scores);
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
     switch (dv / 256) {
         case 1: rc = cone::launch_frame_scores<1>(vid, ctx_l, txt, nq, frame_scores, s); break;
         case 2: rc = cone::launch_frame_scores<2>(vid, ctx_l, txt, nq, frame_scores, s); break;

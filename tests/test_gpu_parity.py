@@ -253,7 +253,8 @@ def test_stage_a_matches_reference_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("ctx_l,W,dv,nq", [(1, 90, 256, 1), (44, 90, 256, 3), (45, 90, 256, 2), (91, 90, 256, 5),
-                                           (1000, 125, 512, 7), (5000, 125, 512, 1), (333, 90, 768, 2)])
+                                           (1000, 125, 512, 7), (5000, 125, 512, 1), (333, 90, 768, 2),
+                                           (3000, 125, 512, 64), (777, 90, 256, 9), (4096, 125, 512, 33)])
 def test_prefilter_edge_shapes(ctx_l, W, dv, nq):
     from cone_amd import ops
     dev = _gpu()
