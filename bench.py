@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--videos", type=int, default=50)
-    ap.add_argument("--window_batch", type=int, default=4096)
+    ap.add_argument("--window_batch", type=int, default=32768)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_queries", type=int, default=400)
     args = ap.parse_args()

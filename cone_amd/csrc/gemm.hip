@@ -253,7 +253,8 @@ struct RowTile {
     static constexpr int A_INST = RT_BM / ROWS_PER_INST / 4;         // LDS-DMA instructions per wave, A
     static constexpr int B_INST = RT_BN / ROWS_PER_INST / 4;         //   ... W
     static constexpr int SLAB = (RT_BM + RT_BN) * RBK;               // floats
-    static constexpr int LDS_FLOATS = (2 * SLAB > RT_EP_FLOATS) ? 2 * SLAB : RT_EP_FLOATS;
+    static constexpr int NBUF = RBK == 16 ? 3 : 2;                   // slabs in the LDS ring
+    static constexpr int LDS_FLOATS = (NBUF * SLAB > RT_EP_FLOATS) ? NBUF * SLAB : RT_EP_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     // chunk swizzle: makes every 16-lane ds_read_b128 service group hit 16 distinct 16-byte slots
     __device__ static __forceinline__ int swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
@@ -316,14 +317,23 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
     const int b_row = RT_BM * RBK + li * RBK;
 
     const int nk = K / RBK;
+    // Ring of NBUF slabs.  With 3 slabs the LDS-DMA of slab kt+2 is issued while slab kt is multiplied and
+    // is only waited for one slab later, with a COUNTED vmcnt and a raw s_barrier (a __syncthreads() would
+    // drain it with vmcnt(0)): the DMA gets a full slab of MFMA time to land.
+    constexpr int AHEAD = T::NBUF - 1;
     stream_slab(0, 0);
-    __syncthreads();
+    if (AHEAD == 2 && nk > 1) stream_slab(1, 1);
+    if (AHEAD == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
+        const int cur = kt % T::NBUF;
+        const int nxt = (kt + AHEAD) % T::NBUF;
+        const bool more = kt + AHEAD < nk;
         // The next slab's LDS-DMA pieces are issued one per unit, in the shadow of that unit's MFMAs,
         // instead of as one burst ahead of the first MFMA (in-order issue would drain the matrix pipe).
-        constexpr int PPU = (NPIECE + 7) / 8 > 0 ? (NPIECE + (RBK / 8) * 4 - 1) / ((RBK / 8) * 4) : 1;   // pieces per unit
+        constexpr int PPU = (NPIECE + (RBK / 8) * 4 - 1) / ((RBK / 8) * 4);   // pieces per unit
         const float* sb = smem + cur * T::SLAB;
         // NU units of {two B fragments, 8 MFMAs on two alternating accumulator tiles}.  The fragments of
         // unit u+1 are requested right before the MFMAs of unit u and consumed (empty asm = the
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
             if (more) {
 #pragma unroll
                 for (int pp = 0; pp < PPU; ++pp)
-                    if (u * PPU + pp < NPIECE) stream_piece(kt + 1, cur ^ 1, u * PPU + pp);
+                    if (u * PPU + pp < NPIECE) stream_piece(kt + AHEAD, nxt, u * PPU + pp);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (u + 1 < NU) {
@@ -364,7 +374,13 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
                 }
             }
         }
-        __syncthreads();   // vmcnt(0): slab kt+1 landed; barrier: everyone is done reading slab kt
+        // slab kt+1 must have landed (all but the pieces of slab kt+2 just issued), then everyone is done
+        // reading slab kt
+        __builtin_amdgcn_sched_barrier(0);
+        if (AHEAD == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
 
 static int g_gemm_variant = 0;  // 0 auto, 1 force register-staged tiles, 2/3 force the row tile (test hook A/B)
 static int g_rows_bk = 16;      // slab depth of the row tile: 16 (two workgroups per CU) or 32 (one)
-void set_gemm_variant(int v) {
+void set_gemm_variant(int v) {   // test hook: 1 register-staged square tiles, 2 row tile (default), 3 row tile BK=32
     g_gemm_variant = v == 3 ? 2 : v;
     if (v == 2) g_rows_bk = 16;
     if (v == 3) g_rows_bk = 32;

@@ -204,7 +204,7 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
     --no_sort_results) and the raw model outputs."""
     feats = feats or project_features(model, store)
     nw = wt["vid_row0"].shape[0]
-    chunk = chunk or int(getattr(opt, "window_batch", 4096))
+    chunk = chunk or int(getattr(opt, "window_batch", 32768))
     Lq_max = max(store.tok_len)
     outs = {k: [] for k in ("pred_logits", "pred_spans", "matching", "rows")}
     for c0 in range(0, nw, chunk):

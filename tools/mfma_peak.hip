@@ -30,6 +30,63 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The GEMM inner pattern: 8 MFMAs on 2 accumulators, then consume the fragments requested before them
+// and request the next ones (one-in-flight prefetch), optional barrier every 8 units.
+template <bool BARRIER>
+__global__ __launch_bounds__(256, 2) void kg(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float sm[12288];
+    for (int i = threadIdx.x; i < 12288; i += 256) sm[i] = (float)(i & 1023) * 1e-6f;
+    __syncthreads();
+    f32x16 acc[8];
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* p = sm + (threadIdx.x & 63) * 4;
+    f32x4v a = *reinterpret_cast<const f32x4v*>(p);
+    f32x4v b0 = *reinterpret_cast<const f32x4v*>(p + 256), b1 = *reinterpret_cast<const f32x4v*>(p + 512);
+    f32x4v n0 = *reinterpret_cast<const f32x4v*>(p + 768), n1 = *reinterpret_cast<const f32x4v*>(p + 1024);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = (u & 3) * 2;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[t + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(n0), "+v"(n1));
+            b0 = n0; b1 = n1;
+            __builtin_amdgcn_sched_barrier(0);
+            n0 = *reinterpret_cast<const f32x4v*>(p + ((u * 2 + it) & 7) * 1024);
+            n1 = *reinterpret_cast<const f32x4v*>(p + ((u * 2 + 1 + it) & 7) * 1024 + 256);
+        }
+        if (BARRIER) __syncthreads();
+    }
+    float s = 0.f;
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <bool BARRIER>
+void rung(const char* name, int blocks_per_cu) {
+    float* out;
+    hipMalloc(&out, 256 * 8 * 256 * 4);
+    const int iters = 2500, grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    kg<BARRIER><<<grid, 256>>>(out, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kg<BARRIER><<<grid, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid * 4 * iters * 64 * 4096.0;
+    printf("%-28s waves/SIMD=%d  %.1f TF  (%.2f ms)\n", name, blocks_per_cu, flops / ms / 1e9, ms);
+    hipFree(out);
+}
+
 template <int NACC, bool LDS>
 void run(const char* name, int blocks_per_cu) {
     float* out;
@@ -60,5 +117,9 @@ int main() {
     run<1, false>("1 acc (dependent), bare", 2);
     run<2, true>("2 acc + ds_read_b128/8mfma", 1);
     run<2, true>("2 acc + ds_read_b128/8mfma", 2);
+    rung<false>("gemm pattern, no barrier", 1);
+    rung<false>("gemm pattern, no barrier", 2);
+    rung<true>("gemm pattern + barrier/64", 1);
+    rung<true>("gemm pattern + barrier/64", 2);
     return 0;
 }
