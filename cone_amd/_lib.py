@@ -53,6 +53,10 @@ class Weights(C.Structure):
     ]
 
 
+class Layer0(C.Structure):
+    _fields_ = [("qkv_vid", C.c_void_p), ("qkv_txt", C.c_void_p), ("pos_qk", C.c_void_p), ("max_v_l", C.c_int32)]
+
+
 class Taps(C.Structure):
     _fields_ = [("memory", C.c_void_p), ("hs", C.c_void_p), ("aux_logits", C.c_void_p),
                 ("aux_spans", C.c_void_p)]
@@ -84,7 +88,10 @@ _SIGNATURES = {
     "cone_forward_packed_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "cone_forward_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.POINTER(Taps), C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.POINTER(Taps), C.POINTER(Layer0), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_layer0_pos_rows": (C.c_int64, [C.c_int]),
+    "cone_layer0_pos_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_layer0_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cone_clip_matching_workspace": (C.c_size_t, [C.c_void_p, C.c_int]),
     "cone_clip_matching_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -253,7 +253,7 @@ static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax) {
 static int forward_packed(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
                           const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
                           float* logits, float* spans, float* saliency, const cone_taps* taps, void* ws,
-                          size_t ws_bytes, hipStream_t s) {
+                          size_t ws_bytes, hipStream_t s, const cone_layer0* l0 = nullptr) {
     CONE_REQUIRE(B > 0 && Lv_max > 0 && Lq_max >= 0, "forward: bad sizes B=%d Lv=%d Lq=%d", B, Lv_max, Lq_max);
     const int Lmax = Lv_max + Lq_max;
     CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
@@ -266,13 +266,23 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int* Mdev = f.off + B;
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
-    RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
+    if (l0) {
+        CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
+                     "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
+        RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, l0->qkv_vid, l0->qkv_txt,
+                           l0->pos_qk, f.X, f.POS, f.QK, f.V, B, Lmax, s));
+    } else {
+        RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
+    }
 
     for (int l = 0; l < m->n_enc; ++l) {  // cone/transformer.py:233-246
         const EncLayer& e = m->enc[l];
-        GemmArgs g = G(f.XP, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
-        RUN(launch_gemm(g, s));                                                             // q | k = (x+pos) W^T
-        RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
+        GemmArgs g;
+        if (l > 0 || !l0) {
+            g = G(f.XP, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
+            RUN(launch_gemm(g, s));                                                         // q | k = (x+pos) W^T
+            RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
+        }
         RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
         g = G(f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.X; g.ldr = 256; g.ln_g = e.n1.g; g.ln_b = e.n1.b;
@@ -406,12 +416,35 @@ extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int 
 extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                                    const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
                                    const int32_t* txt_len, int B, int Lv_max, int Lq_max, float* logits,
-                                   float* spans, float* saliency, const cone_taps* taps, void* ws,
-                                   size_t ws_bytes, void* stream) {
+                                   float* spans, float* saliency, const cone_taps* taps, const cone_layer0* l0,
+                                   void* ws, size_t ws_bytes, void* stream) {
     CONE_REQUIRE(m && vproj && tproj && vid_row0 && vid_len && txt_row0 && txt_len && logits && spans && saliency,
                  "forward_packed: null argument");
     return forward_packed(m, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, B, Lv_max, Lq_max, logits, spans,
-                          saliency, taps, ws, ws_bytes, (hipStream_t)stream);
+                          saliency, taps, ws, ws_bytes, (hipStream_t)stream, l0);
+}
+
+extern "C" int64_t cone_layer0_pos_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2; }
+
+extern "C" int cone_layer0_pos_table(const cone_model* m, int max_v_l, float* pos_qk, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    CONE_REQUIRE(m && pos_qk && max_v_l >= 1 && max_v_l <= 192, "layer0_pos_table: bad argument");
+    const int64_t rows = cone_layer0_pos_rows(max_v_l);
+    Carver c(ws, ws_bytes);
+    float* pr = c.take<float>((size_t)rows * 256);
+    if (!c.ok) { set_error("layer0_pos_table: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    RUN(launch_pos_rows(m->dim_t, max_v_l, pr, s));
+    // pos W_q^T | pos W_k^T, no bias (the bias travels with the clip / token rows)
+    return launch_gemm(G(pr, 256, m->enc[0].sa.in_w, 256, nullptr, pos_qk, 512, (int)rows, nullptr, 512, 256), s);
+}
+
+extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv,
+                                   void* stream) {
+    CONE_REQUIRE(m && proj_rows && qkv && n_rows < (1ll << 31), "layer0_project: bad argument");
+    if (n_rows <= 0) return 0;
+    return launch_gemm(G(proj_rows, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, qkv, 768, (int)n_rows, nullptr,
+                         768, 256), (hipStream_t)stream);
 }
 
 extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad) {

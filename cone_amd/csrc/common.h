@@ -106,6 +106,10 @@ int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipSt
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                     const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
                     int Lmax, hipStream_t s);
+int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
+int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
+                   const int* qlen, const int* off, const float* dim_t, const float* qkv_vid, const float* qkv_txt,
+                   const float* pos_qk, float* X, float* POS, float* QK, float* V, int B, int Lmax, hipStream_t s);
 int launch_saliency(const float* MEM, const int* off, const int* vlen, const int* qlen, const float* w,
                     const float* bias, float* sal, int Lv_out, float* mem_tap, int Lq_out, int B, hipStream_t s);
 int launch_proposal_mean(const float* vid, const int* vrow0, const int* vlen, const int* pad_len,

@@ -81,6 +81,87 @@ int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const
     return 0;
 }
 
+// Rows of the sine position table for every (window length Lv, position p): row Lv(Lv-1)/2 + p.
+__global__ __launch_bounds__(256) void pos_rows_kernel(const float* __restrict__ dim_t, int max_v_l, float* out) {
+    const int lv = blockIdx.y + 1;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= lv) return;
+    const float xe = __fmul_rn(__fdiv_rn((float)(p + 1), __fadd_rn((float)lv, 1e-6f)), 6.283185307179586f);
+    const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
+    float4 ps;
+    ps.x = sinf(__fdiv_rn(xe, dt.x)); ps.y = cosf(__fdiv_rn(xe, dt.y));
+    ps.z = sinf(__fdiv_rn(xe, dt.z)); ps.w = cosf(__fdiv_rn(xe, dt.w));
+    reinterpret_cast<float4*>(out + ((size_t)(lv * (lv - 1) / 2 + p)) * 256)[lane] = ps;
+}
+
+int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(pos_rows_kernel, dim3((max_v_l + 3) / 4, max_v_l), dim3(256), 0, s, dim_t, max_v_l, out);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// pack_pos_kernel + the first encoder layer's in_proj by gather: the q|k|v rows of a token are
+//   video clip  : qkv_vid[clip] (= vproj W^T + b, computed once per CLIP) + pos_qk[Lv, p] (= pos W_qk^T, a
+//                 static table) on the q|k part -- (x + pos) W^T = x W^T + pos W^T, rows independent;
+//   text token  : qkv_txt[token] (once per TOKEN of the query, shared by its windows).
+// Replaces two M-row GEMMs (10 % of the window model's FLOPs) by an HBM-bound gather.
+__global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ vproj,
+                                                      const int* __restrict__ vrow0,
+                                                      const int* __restrict__ vlen,
+                                                      const float* __restrict__ tproj,
+                                                      const int* __restrict__ trow0,
+                                                      const int* __restrict__ qlen,
+                                                      const int* __restrict__ off,
+                                                      const float* __restrict__ dim_t,
+                                                      const float* __restrict__ qkv_vid,
+                                                      const float* __restrict__ qkv_txt,
+                                                      const float* __restrict__ pos_qk, float* X, float* POS,
+                                                      float* QK, float* V) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int lv = vlen[b], lq = qlen[b];
+    if (p >= lv + lq) return;
+    const size_t row = (size_t)(off[b] + p);
+    float4 x, ps, q0, q1, vv;
+    if (p < lv) {
+        const size_t src = (size_t)(vrow0[b] + p);
+        x = reinterpret_cast<const float4*>(vproj + src * 256)[lane];
+        const float xe = __fmul_rn(__fdiv_rn((float)(p + 1), __fadd_rn((float)lv, 1e-6f)), 6.283185307179586f);
+        const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
+        ps.x = sinf(__fdiv_rn(xe, dt.x)); ps.y = cosf(__fdiv_rn(xe, dt.y));
+        ps.z = sinf(__fdiv_rn(xe, dt.z)); ps.w = cosf(__fdiv_rn(xe, dt.w));
+        const float4* qs = reinterpret_cast<const float4*>(qkv_vid + src * 768);
+        const float4* pq = reinterpret_cast<const float4*>(pos_qk + (size_t)(lv * (lv - 1) / 2 + p) * 512);
+        const float4 a0 = qs[lane], a1 = qs[64 + lane], t0 = pq[lane], t1 = pq[64 + lane];
+        q0 = make_float4(a0.x + t0.x, a0.y + t0.y, a0.z + t0.z, a0.w + t0.w);
+        q1 = make_float4(a1.x + t1.x, a1.y + t1.y, a1.z + t1.z, a1.w + t1.w);
+        vv = qs[128 + lane];
+    } else {
+        const size_t src = (size_t)(trow0[b] + p - lv);
+        x = reinterpret_cast<const float4*>(tproj + src * 256)[lane];
+        ps = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* qs = reinterpret_cast<const float4*>(qkv_txt + src * 768);
+        q0 = qs[lane]; q1 = qs[64 + lane]; vv = qs[128 + lane];
+    }
+    reinterpret_cast<float4*>(X + row * 256)[lane] = x;
+    reinterpret_cast<float4*>(POS + row * 256)[lane] = ps;
+    reinterpret_cast<float4*>(QK + row * 512)[lane] = q0;
+    reinterpret_cast<float4*>(QK + row * 512)[64 + lane] = q1;
+    reinterpret_cast<float4*>(V + row * 256)[lane] = vv;
+}
+
+int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
+                   const int* qlen, const int* off, const float* dim_t, const float* qkv_vid, const float* qkv_txt,
+                   const float* pos_qk, float* X, float* POS, float* QK, float* V, int B, int Lmax, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pack_l0_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, vproj, vrow0, vlen, tproj, trow0,
+                       qlen, off, dim_t, qkv_vid, qkv_txt, pos_qk, X, POS, QK, V);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 // saliency_proj on the video part of memory (cone/model.py:119-122) scattered to (B, Lv_out);
 // optional copy of the packed memory into the padded (B, Lv_out + Lq_out, 256) tap.
 __global__ __launch_bounds__(256) void saliency_kernel(const float* __restrict__ MEM, const int* __restrict__ off,

@@ -190,11 +190,12 @@ def window_table(store: FeatureStore, opt, win_idx):
 def project_features(model, store: FeatureStore):
     """Row-wise work shared by every window that contains a clip and by all windows of a query
     (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors."""
-    return dict(
-        vproj=model.project(0, store.vid_raw),                               # raw features: H2
-        tproj=model.project(1, ops.l2_normalize(store.tok_raw, 1e-5)),       # dataloader :274-275
-        cls_norm=ops.l2_normalize(store.cls_raw, 1e-5),                      # dataloader :277
-    )
+    vproj = model.project(0, store.vid_raw)                                 # raw features: H2
+    tproj = model.project(1, ops.l2_normalize(store.tok_raw, 1e-5))         # dataloader :274-275
+    feats = dict(vproj=vproj, tproj=tproj, cls_norm=ops.l2_normalize(store.cls_raw, 1e-5))  # :277
+    if getattr(store.opt, "layer0_cache", True):
+        feats["l0"] = model.layer0_cache(vproj, tproj, store.opt.max_v_l)
+    return feats
 
 
 @torch.no_grad()
@@ -211,7 +212,7 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
         sl = slice(c0, min(c0 + chunk, nw))
         g = lambda k: wt[k][sl].contiguous()
         out = model.forward_packed(feats["vproj"], g("vid_row0"), g("vid_len"), feats["tproj"], g("txt_row0"),
-                                   g("txt_len"), opt.max_v_l, Lq_max)
+                                   g("txt_len"), opt.max_v_l, Lq_max, l0=feats.get("l0"))
         match = model.clip_matching_gathered(feats["cls_norm"], g("cls_row"), store.vid_raw, g("vid_row0"),
                                              g("vid_len"), g("pad_len"), out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, g("vid_len"), g("video_start"),

@@ -103,6 +103,7 @@ class CONE:
             if extra:
                 raise KeyError(f"unexpected keys in state_dict: {extra[:5]}")
         self._sd = sd
+        self._pos_qk = None
         self._dim_t = _dim_t_table(self.hidden_dim).to(dev)
         a = self.args
         w = _lib.Weights()
@@ -250,9 +251,30 @@ class CONE:
                                            ws.numel(), _lib.stream()))
         return out
 
-    def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max):
+    def layer0_cache(self, vproj, tproj, max_v_l: int):
+        """First encoder layer's in_proj hoisted out of the window loop: q|k|v rows once per clip and per
+        text token (cone_layer0_project) + the static pos W_qk^T table (built once per model)."""
+        lib, h = _lib.load(), self._h()
+        dev = vproj.device
+        if getattr(self, "_pos_qk", None) is None or self._pos_qk[0] != max_v_l:
+            rows = lib.cone_layer0_pos_rows(max_v_l)
+            tab = torch.empty(rows, 2 * self.hidden_dim, device=dev)
+            ws = self._ws.get(rows * self.hidden_dim * 4 + 4096, dev)
+            _lib.check(lib.cone_layer0_pos_table(h, max_v_l, _lib.ptr(tab), _lib.ptr(ws), ws.numel(), _lib.stream()))
+            self._pos_qk = (max_v_l, tab)
+        qv = torch.empty(vproj.shape[0], 3 * self.hidden_dim, device=dev)
+        qt = torch.empty(tproj.shape[0], 3 * self.hidden_dim, device=dev)
+        _lib.check(lib.cone_layer0_project(h, _lib.ptr(vproj), vproj.shape[0], _lib.ptr(qv), _lib.stream()))
+        _lib.check(lib.cone_layer0_project(h, _lib.ptr(tproj), tproj.shape[0], _lib.ptr(qt), _lib.stream()))
+        return dict(qkv_vid=qv, qkv_txt=qt, pos_qk=self._pos_qk[1], max_v_l=max_v_l)
+
+    def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None):
         """CONE.forward on windows given by index into projected token arenas."""
         lib, h = _lib.load(), self._h()
+        l0s = None
+        if l0 is not None:
+            l0s = _lib.Layer0(l0["qkv_vid"].data_ptr(), l0["qkv_txt"].data_ptr(), l0["pos_qk"].data_ptr(),
+                              l0["max_v_l"])
         B = vid_row0.shape[0]
         dev = vproj.device
         nq = self.num_queries
@@ -265,6 +287,7 @@ class CONE:
         _lib.check(lib.cone_forward_packed(h, _lib.ptr(vproj), _lib.ptr(vid_row0, i32), _lib.ptr(vid_len, i32),
                                            _lib.ptr(tproj), _lib.ptr(txt_row0, i32), _lib.ptr(txt_len, i32), B,
                                            Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), None,
+                                           C.byref(l0s) if l0s is not None else None,
                                            _lib.ptr(ws), ws.numel(), _lib.stream()))
         return {"pred_logits": logits, "pred_spans": spans, "saliency_scores": sal}
 

@@ -146,12 +146,23 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
  * [txt_row0[b], +txt_len[b]).  This is how the eval driver avoids re-projecting the clips shared by
  * overlapping windows and the text replicated across a query's windows.
  * Lv_max/Lq_max bound the lengths (host-known); saliency is (B, Lv_max). */
+/* Optional cache of the FIRST encoder layer's in_proj, which is row-wise like the input projections:
+ * (x + pos) W^T + b = (x W^T + b) + pos W^T.  qkv_vid (n_clips, 3d) / qkv_txt (n_tokens, 3d) =
+ * cone_layer0_project of the projected arenas (once per clip / per text token instead of once per
+ * window row); pos_qk (cone_layer0_pos_rows(max_v_l), 2d) = cone_layer0_pos_table (static per model):
+ * row Lv(Lv-1)/2 + p holds PositionEmbeddingSine(Lv, p) [W_q | W_k]^T.  With it, layer 0's q|k|v
+ * rows are gathered instead of multiplied (two M-row GEMMs, ~10 % of the FLOPs, become a copy). */
+typedef struct { const float* qkv_vid; const float* qkv_txt; const float* pos_qk; int32_t max_v_l; } cone_layer0;
+int64_t cone_layer0_pos_rows(int max_v_l);
+int cone_layer0_pos_table(const cone_model* m, int max_v_l, float* pos_qk, void* ws, size_t ws_bytes, void* stream);
+int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* stream);
+
 size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max);
 int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                         const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
                         const int32_t* txt_len, int B, int Lv_max, int Lq_max,
                         float* logits, float* spans, float* saliency, const cone_taps* taps,
-                        void* ws, size_t ws_bytes, void* stream);
+                        const cone_layer0* l0 /* may be NULL */, void* ws, size_t ws_bytes, void* stream);
 
 /* A12, CONE.forward_clip_matching (cone/model.py:130-152,178-210).  Gathered form:
  * proposal n of window b averages rows [s,e) of the window's clips vid[vid_row0[b] + ...] where
