@@ -68,9 +68,10 @@ _SIGNATURES = {
     "cone_model_create": (C.c_int, [C.POINTER(Weights), C.POINTER(C.c_void_p)]),
     "cone_model_destroy": (None, [C.c_void_p]),
     "cone_adapter_norm_workspace": (C.c_size_t, [C.c_void_p, C.c_int64]),
-    "cone_adapter_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+    "cone_adapter_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
-    "cone_l2_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "cone_l2_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
     "cone_num_windows": (C.c_int64, [C.c_int64, C.c_int]),
     "cone_prefilter_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),

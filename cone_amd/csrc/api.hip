@@ -375,8 +375,8 @@ extern "C" void cone_model_destroy(cone_model* m) {
 extern "C" size_t cone_adapter_norm_workspace(const cone_model* m, int64_t n_rows) {
     return align_up((size_t)n_rows * 256 * 4, 256) + align_up((size_t)n_rows * m->dv * 4, 256);
 }
-extern "C" int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out, void* ws,
-                                 size_t ws_bytes, void* stream) {
+extern "C" int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out, int renorm,
+                                 void* ws, size_t ws_bytes, void* stream) {
     CONE_REQUIRE(m && x && out, "adapter_norm: null argument");
     CONE_REQUIRE(n_rows > 0 && n_rows < (1ll << 31), "adapter_norm: bad row count");
     hipStream_t s = (hipStream_t)stream;
@@ -390,14 +390,17 @@ extern "C" int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_
     float* y = c.take<float>((size_t)n_rows * m->dv);
     if (!c.ok) { set_error("adapter_norm: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     RUN(launch_gemm(G(x, m->dv, m->adapter[0].w, m->dv, m->adapter[0].b, h, 256, (int)n_rows, nullptr, 256, m->dv, EPI_RELU), s));
-    GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, y, m->dv, (int)n_rows, nullptr, m->dv, 256, EPI_RESIDUAL);
+    GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, renorm ? y : out, m->dv, (int)n_rows, nullptr, m->dv,
+                   256, EPI_RESIDUAL);
     g.R = x; g.ldr = m->dv;
     RUN(launch_gemm(g, s));
+    if (!renorm) return 0;                       // run_on_video/cone_localizator.py:135-138 keeps the raw sum
     return launch_l2norm(y, n_rows, m->dv, 0.f, out, s);
 }
 
-extern "C" int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, float* out, void* stream) {
-    return launch_l2norm(x, n_rows, dim, eps, out, (hipStream_t)stream);
+extern "C" int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, int clamp, float* out,
+                                      void* stream) {
+    return launch_l2norm(x, n_rows, dim, eps, out, (hipStream_t)stream, clamp);
 }
 
 extern "C" size_t cone_project_workspace(const cone_model* m, int which, int64_t n_rows) {

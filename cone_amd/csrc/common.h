@@ -91,7 +91,7 @@ void set_gemm_variant(int v);
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
                      int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s);
-int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s);
+int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s, int clamp = 0);
 // out[m][n] = act(<X[m], W[n]> + b[n]), n < nout <= 2, K = 256; act 0 none, 1 sigmoid
 int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float* out, int ldo,
                   int64_t n_rows, int nout, int act, hipStream_t s);

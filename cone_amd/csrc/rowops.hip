@@ -67,7 +67,7 @@ int launch_layernorm(const float* x, int ldx, const float* g, const float* b, fl
 
 // out = x / (||x||_2 + eps): utils/basic_utils.py:97-99 (eps=1e-5), cone/inference.py:257 (eps=0).
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
-                                                     float eps, float* out) {
+                                                     float eps, int clamp, float* out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
             s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
         }
     }
-    const float nrm = sqrtf(wave_sum(s)) + eps;
+    // clamp = 0: x / (||x|| + eps) (l2_normalize_np_array);  clamp = 1: x / max(||x||, eps) (F.normalize)
+    const float nrm = clamp ? fmaxf(sqrtf(wave_sum(s)), eps) : sqrtf(wave_sum(s)) + eps;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
@@ -95,11 +96,11 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
     }
 }
 
-int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s) {
+int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s, int clamp) {
     CONE_REQUIRE(dim % 4 == 0 && dim <= 1024, "l2norm: dim=%d must be a multiple of 4 and <= 1024", dim);
     if (n_rows <= 0) return 0;
     hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, n_rows, dim, eps,
-                       out);
+                       clamp, out);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -229,15 +229,16 @@ class CONE:
         return match
 
     # ---- arena-level entry points used by the eval driver ---------------------------------------
-    def adapter_norm(self, vid_rows):
-        """cone/inference.py:254-258 over any number of clip rows (n, dv)."""
+    def adapter_norm(self, vid_rows, renorm: bool = True):
+        """cone/inference.py:254-258 over any number of clip rows (n, dv); renorm=False keeps
+        adapter(x)+x un-normalised (run_on_video/cone_localizator.py:135-138)."""
         lib, h = _lib.load(), self._h()
         x = self._f32(vid_rows)
         out = torch.empty_like(x)
         nbytes = lib.cone_adapter_norm_workspace(h, x.shape[0])
         ws = self._ws.get(nbytes, x.device)
-        _lib.check(lib.cone_adapter_norm(h, _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                         _lib.stream()))
+        _lib.check(lib.cone_adapter_norm(h, _lib.ptr(x), x.shape[0], _lib.ptr(out), 1 if renorm else 0, _lib.ptr(ws),
+                                         ws.numel(), _lib.stream()))
         return out
 
     def project(self, which: int, rows):

@@ -18,13 +18,14 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def l2_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """x / (||x|| + eps) along the last dim (utils/basic_utils.py:97-99)."""
+def l2_normalize(x: torch.Tensor, eps: float = 1e-5, clamp: bool = False) -> torch.Tensor:
+    """x / (||x|| + eps) along the last dim (utils/basic_utils.py:97-99); with clamp=True
+    x / max(||x||, eps), i.e. torch.nn.functional.normalize (run_on_video/cone_localizator.py:129)."""
     lib = _lib.load()
     x2 = x.to(torch.float32).contiguous().view(-1, x.shape[-1])
     out = torch.empty_like(x2)
-    _lib.check(lib.cone_l2_normalize_rows(_lib.ptr(x2), x2.shape[0], x2.shape[1], eps, _lib.ptr(out),
-                                          _lib.stream()))
+    _lib.check(lib.cone_l2_normalize_rows(_lib.ptr(x2), x2.shape[0], x2.shape[1], eps, 1 if clamp else 0,
+                                          _lib.ptr(out), _lib.stream()))
     return out.view(x.shape)
 
 

@@ -78,14 +78,17 @@ void cone_model_destroy(cone_model* m);
 
 /* ------------------------------------------------------------------ stage A: pre-filter */
 
-/* A2, cone/inference.py:254-258: out = adapter(x)+x, then out /= ||out||_2 (no eps), row-wise.
+/* A2, cone/inference.py:254-258: out = adapter(x)+x, then (renorm != 0) out /= ||out||_2 (no eps), row-wise;
+ * renorm == 0 is the single-video localizer's form (run_on_video/cone_localizator.py:135-138).
  * x,out (n_rows, v_dim).  ws >= cone_adapter_norm_workspace(m, n_rows) bytes. */
 size_t cone_adapter_norm_workspace(const cone_model* m, int64_t n_rows);
-int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out,
+int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_rows, float* out, int renorm,
                       void* ws, size_t ws_bytes, void* stream);
 
-/* x / (||x||_2 + eps) row-wise: l2_normalize_np_array (utils/basic_utils.py:97-99). */
-int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, float* out, void* stream);
+/* Row-wise L2 normalisation.  clamp == 0: x / (||x||_2 + eps) = l2_normalize_np_array
+ * (utils/basic_utils.py:97-99); clamp != 0: x / max(||x||_2, eps) = torch.nn.functional.normalize
+ * (run_on_video/cone_localizator.py:129-133). */
+int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, int clamp, float* out, void* stream);
 
 /* A3+A4, cone/inference.py:284-296: frame_scores[q][f] = <vid[f], txt[q]>;
  * win_scores[q][i] = max(frame_scores[q][max((i-1)S,0) : min((i-1)S+W, ctx_l)]),

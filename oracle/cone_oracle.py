@@ -385,6 +385,45 @@ def postprocess(submission, opt):
     return fusion, proposal, matching
 
 
+# ------------------------------------------------------- single-video localizer
+def localizer_predict(sd, opt, video_feats, text_token_feats, text_cls_feat):
+    """``CONELocalizator.predict_moment`` (run_on_video/cone_localizator.py:121-221).  Differences from
+    the dataset path that are part of the contract: F.normalize (x / max(||x||, eps)) on clips and tokens,
+    the adapted features are NOT re-normalised and the cls vector is used raw for the window ranking,
+    every window is padded to (max_v_l, max_q_l), spans scale by max_v_l (not the window's length),
+    rows are not sorted per window, NMS runs on the fused score only ([:100], 0.5, keep 5)."""
+    sd = as_torch_sd(sd)
+    W, K = opt.max_v_l, opt.topk_window
+    v = F.normalize(video_feats.float(), dim=-1, eps=1e-5)
+    tok = F.normalize(text_token_feats.float(), dim=-1, eps=1e-5)
+    av = mlp(v, sd, "adapter_layer", 2) + v if opt.adapter_module == "linear" else v
+    ranks = rank_windows(window_scores(frame_scores(av, text_cls_feat.float()), W))
+    widx = ranks[:K]
+    assert len(widx) == K, "the reference feeds all-padding windows to the model for short videos (NaN)"
+    dv, dt = v.shape[1], tok.shape[1]
+    vid = torch.zeros(K, W, dv); vmask = torch.zeros(K, W)
+    txt = torch.zeros(K, opt.max_q_l, dt); tmask = torch.zeros(K, opt.max_q_l)
+    cls = torch.zeros(K, dv)
+    starts = []
+    for i, w in enumerate(widx):
+        s, e = window_bounds(w, v.shape[0], W)
+        vid[i, :e - s] = v[s:e]; vmask[i, :e - s] = 1
+        txt[i, :tok.shape[0]] = tok; tmask[i, :tok.shape[0]] = 1
+        cls[i] = text_cls_feat
+        starts.append(s)
+    out = cone_forward(sd, opt, txt, tmask, vid, vmask)
+    match = clip_matching(sd, opt, cls, vid, vmask, out["pred_spans"])
+    prob = F.softmax(out["pred_logits"], -1)[..., 0]
+    total = []
+    for i in range(K):
+        spans = (span_cxw_to_xx(out["pred_spans"][i]) * W + starts[i]) * opt.clip_length
+        rows = torch.cat([spans, prob[i][:, None], match[i][:, None]], dim=1).tolist()
+        total.extend(round4_rows(rows))
+    rd = score_fusion(total)
+    moments = sorted([[k[0], k[1], val[2]] for k, val in rd.items()], key=lambda x: x[2], reverse=True)
+    return temporal_nms(moments[:100], 0.5, 5)
+
+
 # ------------------------------------------------------------------- A17 (matcher cost)
 def matcher_cost(opt_costs, pred_logits, pred_spans, tgt_spans):
     """cone/matcher.py:61-95 cost matrix C = span*L1 + giou*(-GIoU) + class*(-p_fg).

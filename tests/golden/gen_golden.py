@@ -312,6 +312,41 @@ def gen_matcher(name, seed):
     print("wrote", name)
 
 
+def gen_localizer(name, seed):
+    """run_on_video CONELocalizator.predict_moment on two synthetic videos (ckpt loading bypassed)."""
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__(d or {}, **kw)
+            self.__dict__ = self
+
+    ed.EasyDict = EasyDict
+    sys.modules.setdefault("easydict", ed)
+    import run_on_video.cone_localizator as loc
+    a = loc.args
+    opt = ref_opt("ego4d", clip_length=a.clip_length, topk_window=a.topk_window)
+    model, cks = ref_model(opt, seed)
+    obj = object.__new__(loc.CONELocalizator)
+    obj.device = "cpu"
+    obj.localizator = model
+    obj.slide_window_size = int(a.max_v_l / 2)
+    obj.max_v_l = a.max_v_l
+    rng = np.random.default_rng(6000 + seed)
+    cases = []
+    for ctx_l, lq in ((901, 11), (1033, 20)):
+        vid = rng.standard_normal((ctx_l, 256), dtype=np.float32) * 3
+        tok = rng.standard_normal((lq, 768), dtype=np.float32)
+        cls = rng.standard_normal((256,), dtype=np.float32)
+        with StableSort():
+            out = obj.predict_moment(torch.from_numpy(vid), (torch.from_numpy(tok), torch.from_numpy(cls)))
+        cases.append(dict(ctx_l=ctx_l, lq=lq, out=out))
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(dict(weight_seed=seed, weight_checksum=cks, input_seed=6000 + seed,
+                       clip_length=a.clip_length, topk_window=a.topk_window, cases=cases), f)
+    print("wrote", name)
+
+
 def main():
     torch.manual_seed(0)
     gen_stage_b("stageB_ego4d", "ego4d", 0, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17])
@@ -323,6 +358,7 @@ def main():
     gen_e2e("e2e_mad", "mad", 1, 6, 2, (500, 800), topk_window=5)
     gen_stage_c("stageC", 0)
     gen_matcher("matcher", 0)
+    gen_localizer("localizer", 0)
 
 
 if __name__ == "__main__":

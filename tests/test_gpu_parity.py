@@ -502,3 +502,24 @@ def test_layer0_gather_cache_equals_gemm_path():
         outs.append(inf.run_windows(model, store, opt, wt))
     for k in ("pred_logits", "pred_spans"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < TOL, k     # measured ~3e-5 on logits of magnitude 10
+
+
+def test_localizer_matches_reference_golden(golden_dir):
+    """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
+    from cone_amd.localizator import CONELocalizator
+    with open(os.path.join(golden_dir, "localizer.json")) as f:
+        fx = json.load(f)
+    opt = make_opt("ego4d", clip_length=fx["clip_length"], topk_window=fx["topk_window"])
+    sd = synth.make_state_dict(opt, fx["weight_seed"])
+    loc = CONELocalizator(state_dict={k: torch.from_numpy(v) for k, v in sd.items()})
+    rng = np.random.default_rng(fx["input_seed"])
+    for case in fx["cases"]:
+        vid = rng.standard_normal((case["ctx_l"], 256), dtype=np.float32) * 3
+        tok = rng.standard_normal((case["lq"], 768), dtype=np.float32)
+        cls = rng.standard_normal((256,), dtype=np.float32)
+        got = loc.predict_moment(torch.from_numpy(vid), (torch.from_numpy(tok), torch.from_numpy(cls)))
+        ref = np.array(case["out"])
+        assert len(got) == len(ref)
+        got = np.array(got)
+        assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-4 * 90 * fx["clip_length"] + 1e-4     # seconds
+        assert np.abs(got[:, 2] - ref[:, 2]).max() < 2e-3                                        # fused (min-max normalised)

@@ -144,3 +144,22 @@ def test_matcher_cost_matches_reference(golden_dir):
                            torch.from_numpy(fx["spans"][b:b + 1]), torch.from_numpy(fx["tgt"][b:b + 1]))
         assert np.abs(C.numpy() - fx["C"][b]).max() < 1e-5
         assert int(C[:, 0].argmin()) == int(fx["idx_i"][b][0])      # 1 target -> LSAP == argmin
+
+
+def test_localizer_matches_reference(golden_dir):
+    """run_on_video CONELocalizator.predict_moment."""
+    with open(os.path.join(golden_dir, "localizer.json")) as f:
+        fx = json.load(f)
+    opt = make_opt("ego4d", clip_length=fx["clip_length"], topk_window=fx["topk_window"])
+    sd = synth.make_state_dict(opt, fx["weight_seed"])
+    assert synth.state_dict_checksum(sd) == fx["weight_checksum"]
+    rng = np.random.default_rng(fx["input_seed"])
+    for case in fx["cases"]:
+        vid = rng.standard_normal((case["ctx_l"], 256), dtype=np.float32) * 3
+        tok = rng.standard_normal((case["lq"], 768), dtype=np.float32)
+        cls = rng.standard_normal((256,), dtype=np.float32)
+        with torch.no_grad():
+            got = O.localizer_predict(sd, opt, torch.from_numpy(vid), torch.from_numpy(tok), torch.from_numpy(cls))
+        ref = case["out"]
+        assert len(got) == len(ref)
+        assert np.abs(np.array(got) - np.array(ref)).max() < 1e-3
