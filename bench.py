@@ -38,7 +38,7 @@ from cone_amd.model import build_model  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn_kernel", 4: "frame_score_kernel",
-                5: "gemm_rows_kernel<16>", 6: "gemm_rows_kernel<32>"}
+                5: "gemm_rows_kernel<16>", 6: "gemm_rows_kernel<32>", 7: "dec_cross_kernel"}
 GEMM_KINDS = (0, 1, 2, 5, 6)
 
 
@@ -77,7 +77,7 @@ def roofline_from_profile(rec):
             "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
     extra = {KERNEL_NAMES[k]: {"ms": round(v["ms"], 3), "launches": v["launches"],
                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in per.items()}
-    for kind in (3, 4):
+    for kind in (3, 4, 7):
         sel = rec[rec[:, 0] == kind]
         if len(sel):
             extra[KERNEL_NAMES[kind]] = {"ms": round(float(sel[:, 4].sum()), 3), "launches": int(len(sel))}

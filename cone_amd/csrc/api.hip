@@ -41,6 +41,8 @@ struct cone_model {
     const float* dim_t = nullptr;
     // derived: the cross-attention K / V projections of all decoder layers stacked along N
     cone::Linear dec_k, dec_v;
+    // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
+    const float* dec_vT[CONE_MAX_LAYERS] = {};
 };
 
 namespace cone {
@@ -124,7 +126,7 @@ static int build_model(const cone_weights* w, cone_model** out) {
             set_error("model_create: a required weight pointer is null");
             return CONE_E_INVALID;
         }
-    const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64;
+    const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64 + (size_t)m->n_dec * d * d;
     hipError_t e = hipMalloc((void**)&m->arena, (ab.total + stacked) * sizeof(float));
     if (e != hipSuccess) {
         delete m;
@@ -165,6 +167,23 @@ static int build_model(const cone_weights* w, cone_model** out) {
     }
     m->dec_k = {kw, kb};
     m->dec_v = {vw, vb};
+    {   // W_v^T per decoder layer (host transpose; 256 KiB each, once per model)
+        std::vector<float> h(d * d), ht(d * d);
+        for (int i = 0; i < m->n_dec; ++i) {
+            float* dst = m->arena + cur; cur += d * d;
+            e = hipMemcpy(h.data(), m->dec[i].ca.in_w + 2 * d * d, d * d * sizeof(float), hipMemcpyDeviceToHost);
+            for (size_t o = 0; o < d; ++o)
+                for (size_t c = 0; c < d; ++c) ht[c * d + o] = h[o * d + c];
+            if (e == hipSuccess) e = hipMemcpy(dst, ht.data(), d * d * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(m->arena);
+                delete m;
+                set_error("model_create: transposing decoder V weights failed: %s", hipGetErrorString(e));
+                return CONE_E_HIP;
+            }
+            m->dec_vT[i] = dst;
+        }
+    }
     *out = m;
     return 0;
 }
@@ -224,6 +243,8 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 }
 
 // ------------------------------------------------------------------------------ packed forward
+static int g_dec_fold = 1;   // test hook (cone_test_set_option "dec_fold"): 0 = separate K/V GEMMs + small_attn
+
 struct FwdBuffers {
     int* off;
     float *X, *POS, *XP, *QK, *V, *ATT, *X1, *H, *KD, *VD;
@@ -295,8 +316,10 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     }
     const float* MEM = f.X;
 
-    // decoder (cone/transformer.py:296-317, 117-146): memory K/V for all layers in two GEMMs
-    {
+    // decoder (cone/transformer.py:296-317, 117-146).  Default: the memory K / V projections are folded into
+    // the cross-attention kernel (dec_cross.hip); otherwise memory K/V for all layers in two GEMMs.
+    const bool fold = g_dec_fold && dec_cross_supported(m->nq, Lmax);
+    if (!fold) {
         GemmArgs g = G(f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
         RUN(launch_gemm(G(MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
@@ -315,8 +338,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         g = G(f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, T, nullptr, 256, 256);
         g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
         RUN(launch_gemm(g, s));
-        RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
-                              m->nq, Lmax, s));
+        if (fold)
+            RUN(launch_dec_cross(f.DQ, f.XP, MEM, f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B,
+                                 m->nq, Lmax, s));
+        else
+            RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
+                                  m->nq, Lmax, s));
         g = G(f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT1; g.ldr = 256; g.ln_g = dl.n2.g; g.ln_b = dl.n2.b;
         RUN(launch_gemm(g, s));
@@ -529,6 +556,13 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
     CONE_LAUNCH_CHECK();
     return cone_clip_matching_gathered(m, cls, nullptr, vid, vrow0, vid_len, padl, spans, B, match,
                                        (char*)ws + c.cur, ws_bytes - c.cur, stream);
+}
+
+extern "C" int cone_test_set_option(const char* name, int value) {
+    CONE_REQUIRE(name, "set_option: null name");
+    if (!strcmp(name, "dec_fold")) { cone::g_dec_fold = value != 0; return 0; }
+    cone::set_error("set_option: unknown option '%s'", name);
+    return CONE_E_INVALID;
 }
 
 extern "C" int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,

@@ -61,7 +61,7 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 
 // ---------------------------------------------------------------- opt-in launch timing (prof.hip)
 enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4,
-                PK_GEMM_ROWS = 5, PK_GEMM_ROWS_A2 = 6 };
+                PK_GEMM_ROWS = 5, PK_GEMM_ROWS_A2 = 6, PK_DEC_CROSS = 7 };
 bool prof_enabled();
 struct ProfScope {
     ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
@@ -98,6 +98,10 @@ int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float
 
 // ---------------------------------------------------------------- attention.hip
 int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
+// fused decoder cross-attention with the memory K/V projections folded in (dec_cross.hip)
+bool dec_cross_supported(int nq, int Lmax);
+int launch_dec_cross(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
+                     const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax, hipStream_t s);
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 

@@ -1,0 +1,260 @@
+// Fused decoder cross-attention (cone/transformer.py:308-311 -> nn.MultiheadAttention) for NQ query slots
+// per window, with the memory K / V projections folded into the 8*NQ (slot, head) pairs:
+//
+//   score[p][j] = (q_p * s) . (W_k,h (mem_j + pos_j) + b_k,h)  =  qk_p . (mem_j + pos_j) + const_p
+//       with qk_p = W_k,h^T (q_p * s)  (256-vector); const_p is the same for every key of the pair and
+//       drops out of the softmax;
+//   out_p = sum_j P[p][j] (W_v,h mem_j + b_v,h) = W_v,h (sum_j P[p][j] mem_j) + b_v,h       (sum_j P = 1).
+//
+// So the two M-row GEMMs that project every memory token to K and V for every decoder layer (12 % of the
+// window model's FLOPs) are replaced by 4 small per-window stages, all VALU + LDS (no padding waste: 40 pairs
+// and ~101 keys do not fill 32x32 MFMA tiles well):
+//   0. qk_p for the 40 pairs            (thread = column c, W_k read coalesced)
+//   A. scores: lane = key, wave = 10 pairs; mem+pos rows staged through LDS in 32-column chunks
+//   B. softmax per pair (all keys of a pair live in one wave)
+//   C. ctx_p = sum_j P[p][j] mem_j      (lane = 4 columns, wave = 10 pairs, mem rows read coalesced)
+//   D. out = W_v,h ctx_p + b_v          (thread = output column, W_v^T read coalesced)
+// Results equal the unfused path up to fp32 re-association (~1e-6 relative).
+#include "common.h"
+
+namespace cone {
+
+template <int CTRL>
+__device__ __forceinline__ float dppx(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppx_rows(float v, float identity) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wsum(float v) {
+    v += dppx<0xB1>(v); v += dppx<0x4E>(v); v += dppx<0x141>(v); v += dppx<0x140>(v);
+    v += dppx_rows<0x142, 0xA>(v, 0.f);
+    v += dppx_rows<0x143, 0xC>(v, 0.f);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wmax(float v) {
+    v = fmaxf(v, dppx<0xB1>(v)); v = fmaxf(v, dppx<0x4E>(v)); v = fmaxf(v, dppx<0x141>(v)); v = fmaxf(v, dppx<0x140>(v));
+    // quad_perm / mirrors with bound_ctrl read 0 for nothing here (all lanes valid); row broadcasts keep
+    // the old value (-inf identity) on rows that do not receive
+    v = fmaxf(v, dppx_rows<0x142, 0xA>(v, -INFINITY));
+    v = fmaxf(v, dppx_rows<0x143, 0xC>(v, -INFINITY));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NQ, int NKL>
+struct DecCrossCfg {
+    static constexpr int NP = 8 * NQ;                 // (slot, head) pairs of one window
+    static constexpr int PPW = 2 * NQ;                // pairs per wave
+    static constexpr int PPWP = (PPW + 3) / 4 * 4;    //   padded to whole float4s in the P image
+    static constexpr int NPP = 4 * PPWP;
+    static constexpr int KP = 64 * NKL;               // key capacity
+    static constexpr int TILE_LD = 36;                // 32 columns + 4 pad: conflict-free ds_read_b128 per key
+    static constexpr int UNION = KP * (NPP > TILE_LD ? NPP : TILE_LD);
+    static constexpr int LDS_FLOATS = NP * 32 + NP * 256 + UNION;
+};
+
+template <int NQ, int NKL>
+__global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restrict__ DQ,
+                                                           const float* __restrict__ XP,
+                                                           const float* __restrict__ X,
+                                                           const int* __restrict__ off,
+                                                           const float* __restrict__ Wk,
+                                                           const float* __restrict__ WvT,
+                                                           const float* __restrict__ bv, float* __restrict__ OUT) {
+    using C = DecCrossCfg<NQ, NKL>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qs = smem;                       // [NP][32]   scaled queries, pair p = s*8 + h
+    float* qkf = smem + C::NP * 32;         // [NP][256]  folded keys-side queries; later ctx
+    float* tile = qkf + C::NP * 256;        // [KP][36]   mem+pos chunk; later P [KP][NPP]
+    const int b = blockIdx.x;
+    const int t0 = off[b];
+    const int L = min(off[b + 1] - t0, C::KP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- q * sqrt(1/32) into LDS as [pair = s*8+h][32]
+    for (int i = tid; i < NQ * 256; i += 256) {
+        const int s = i >> 8, o = i & 255;
+        qs[(s * 8 + (o >> 5)) * 32 + (o & 31)] = DQ[(size_t)(b * NQ + s) * 256 + o] * 0.17677669529663687f;
+    }
+    __syncthreads();
+
+    // ---- stage 0: qkf[p][c] = sum_d qs[p][d] * Wk[h*32+d][c], thread = column c
+    for (int h = 0; h < 8; ++h) {
+        float a[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) a[s] = 0.f;
+        const float* wcol = Wk + (size_t)h * 32 * 256 + tid;
+#pragma unroll 2
+        for (int d4 = 0; d4 < 8; ++d4) {
+            const float w0 = wcol[(d4 * 4 + 0) * 256], w1 = wcol[(d4 * 4 + 1) * 256];
+            const float w2 = wcol[(d4 * 4 + 2) * 256], w3 = wcol[(d4 * 4 + 3) * 256];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                const float4 q4 = *reinterpret_cast<const float4*>(qs + (s * 8 + h) * 32 + d4 * 4);
+                a[s] += (q4.x * w0 + q4.y * w1) + (q4.z * w2 + q4.w * w3);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) qkf[(s * 8 + h) * 256 + tid] = a[s];
+    }
+
+    // ---- stage A: scores.  lane = key (NKL keys per lane), wave = PPW pairs.
+    float sc[NKL][C::PPW];
+#pragma unroll
+    for (int kk = 0; kk < NKL; ++kk)
+#pragma unroll
+        for (int pp = 0; pp < C::PPW; ++pp) sc[kk][pp] = 0.f;
+    constexpr int TPASS = C::KP / 32;                       // staging passes: 32 key rows per pass
+    typedef float f4v __attribute__((ext_vector_type(4)));     // (float4 struct copies lower to memcpy -> scratch)
+    f4v pf[TPASS];
+    const int srow = tid >> 3, spart = tid & 7;
+#define DC_FETCH(ch_)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TPASS; ++i) {                                                     \
+        int r = srow + 32 * i;                                                                              \
+        r = r < L ? r : L - 1;                                                                              \
+        pf[i] = *reinterpret_cast<const f4v*>(XP + (size_t)(t0 + r) * 256 + (ch_) * 32 + spart * 4);     \
+    }
+#define DC_STASH()                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TPASS; ++i)                                                       \
+        *reinterpret_cast<f4v*>(tile + (srow + 32 * i) * C::TILE_LD + spart * 4) = pf[i];
+    DC_FETCH(0)
+    DC_STASH()
+    __syncthreads();                                        // tile(0) and qkf complete
+    for (int ch = 0; ch < 8; ++ch) {
+        if (ch < 7) { DC_FETCH(ch + 1) }                    // in flight during this chunk's FMAs
+#pragma unroll 2
+        for (int c4 = 0; c4 < 8; ++c4) {
+            float4 xk[NKL];
+#pragma unroll
+            for (int kk = 0; kk < NKL; ++kk)
+                xk[kk] = *reinterpret_cast<const float4*>(tile + (lane + 64 * kk) * C::TILE_LD + c4 * 4);
+#pragma unroll
+            for (int pp = 0; pp < C::PPW; ++pp) {
+                const float4 qv = *reinterpret_cast<const float4*>(qkf + (wave * C::PPW + pp) * 256 + ch * 32 + c4 * 4);
+#pragma unroll
+                for (int kk = 0; kk < NKL; ++kk)
+                    sc[kk][pp] += (xk[kk].x * qv.x + xk[kk].y * qv.y) + (xk[kk].z * qv.z + xk[kk].w * qv.w);
+            }
+        }
+        __syncthreads();                                    // everyone is done reading this chunk
+        if (ch < 7) {
+            DC_STASH()
+            __syncthreads();
+        }
+    }
+#undef DC_FETCH
+#undef DC_STASH
+
+    // ---- stage B: softmax over the keys of each pair -> P[key][wave*PPWP + pp]  (aliases the tile)
+    float* P = tile;
+#pragma unroll
+    for (int pp = 0; pp < C::PPW; ++pp) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < NKL; ++kk) {
+            if (lane + 64 * kk >= L) sc[kk][pp] = -INFINITY;
+            m = fmaxf(m, sc[kk][pp]);
+        }
+        m = wmax(m);
+        const float m2 = m * 1.4426950408889634f;
+        float l = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKL; ++kk) {
+            sc[kk][pp] = __builtin_amdgcn_exp2f(fmaf(sc[kk][pp], 1.4426950408889634f, -m2));
+            l += sc[kk][pp];
+        }
+        const float inv = 1.0f / wsum(l);
+#pragma unroll
+        for (int kk = 0; kk < NKL; ++kk) P[(lane + 64 * kk) * C::NPP + wave * C::PPWP + pp] = sc[kk][pp] * inv;
+    }
+    __syncthreads();
+
+    // ---- stage C: ctx[p][c] = sum_j P[j][p] * mem[j][c]; lane = 4 columns, wave = its PPW pairs
+    float4 ctx[C::PPW];
+#pragma unroll
+    for (int pp = 0; pp < C::PPW; ++pp) ctx[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xrow = X + (size_t)t0 * 256 + lane * 4;
+    for (int j0 = 0; j0 < L; j0 += 4) {
+        float4 x4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + u, L - 1);
+            x4[u] = *reinterpret_cast<const float4*>(xrow + (size_t)j * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u < L) {
+                float pv[C::PPWP];
+#pragma unroll
+                for (int i = 0; i < C::PPWP / 4; ++i) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(P + (j0 + u) * C::NPP + wave * C::PPWP + 4 * i);
+                    pv[4 * i] = t4.x; pv[4 * i + 1] = t4.y; pv[4 * i + 2] = t4.z; pv[4 * i + 3] = t4.w;
+                }
+#pragma unroll
+                for (int pp = 0; pp < C::PPW; ++pp) {
+                    ctx[pp].x = fmaf(pv[pp], x4[u].x, ctx[pp].x); ctx[pp].y = fmaf(pv[pp], x4[u].y, ctx[pp].y);
+                    ctx[pp].z = fmaf(pv[pp], x4[u].z, ctx[pp].z); ctx[pp].w = fmaf(pv[pp], x4[u].w, ctx[pp].w);
+                }
+            }
+        }
+    }
+    float* ctxs = qkf;                                       // qkf is dead since the last stage-A barrier
+#pragma unroll
+    for (int pp = 0; pp < C::PPW; ++pp)
+        *reinterpret_cast<float4*>(ctxs + (wave * C::PPW + pp) * 256 + lane * 4) = ctx[pp];
+    __syncthreads();
+
+    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o
+    {
+        float o[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) o[s] = 0.f;
+        const int h = tid >> 5;
+        const float* wcol = WvT + tid;
+#pragma unroll 4
+        for (int c4 = 0; c4 < 64; ++c4) {
+            const float w0 = wcol[(c4 * 4 + 0) * 256], w1 = wcol[(c4 * 4 + 1) * 256];
+            const float w2 = wcol[(c4 * 4 + 2) * 256], w3 = wcol[(c4 * 4 + 3) * 256];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                const float4 cx = *reinterpret_cast<const float4*>(ctxs + (s * 8 + h) * 256 + c4 * 4);
+                o[s] += (cx.x * w0 + cx.y * w1) + (cx.z * w2 + cx.w * w3);
+            }
+        }
+        const float bias = bv[tid];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) OUT[(size_t)(b * NQ + s) * 256 + tid] = o[s] + bias;
+    }
+}
+
+template <int NQ, int NKL>
+static int launch_one(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
+                      const float* WvT, const float* bv, float* OUT, int B, hipStream_t s) {
+    using C = DecCrossCfg<NQ, NKL>;
+    static bool attr = false;
+    if (!attr) {
+        CONE_CHECK_HIP(hipFuncSetAttribute((const void*)dec_cross_kernel<NQ, NKL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4));
+        attr = true;
+    }
+    hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL>), dim3(B), dim3(256), C::LDS_FLOATS * 4, s, DQ, XP, X, off, Wk, WvT,
+                       bv, OUT);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+bool dec_cross_supported(int nq, int Lmax) { return nq == 5 && Lmax <= 192; }
+
+int launch_dec_cross(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
+                     const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax, hipStream_t s) {
+    CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
+    if (B <= 0) return 0;
+    ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
+    if (Lmax <= 128) return launch_one<5, 2>(DQ, XP, X, off, Wk, WvT, bv, OUT, B, s);
+    return launch_one<5, 3>(DQ, XP, X, off, Wk, WvT, bv, OUT, B, s);
+}
+
+}  // namespace cone

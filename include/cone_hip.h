@@ -227,12 +227,16 @@ int cone_matcher_cost(const float* logits, const float* spans, const float* tgt,
  * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
  * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
  * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, 0); kind 4 = frame-score
- * stream (ctx_l, dv, queries in the launch).  Returns the record count.  Not thread-safe. */
+ * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile without / with fused
+ * addend (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq).  Returns the record count.  Not thread-safe. */
 int cone_prof_enable(int on);
 int64_t cone_prof_collect(double* out, int64_t max_rec);
 
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
+/* Process-wide A/B switches for the parity tests.  "dec_fold" (default 1): decoder cross-attention with the
+ * memory K/V projections folded into one kernel per layer; 0 = two stacked K/V GEMMs + per-head attention. */
+int cone_test_set_option(const char* name, int value);
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
  * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning
  * LDS-DMA tile, 0 = automatic).  Optional second output C2 = C + ADD (row tile only). */

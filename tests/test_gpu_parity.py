@@ -504,6 +504,36 @@ def test_layer0_gather_cache_equals_gemm_path():
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < TOL, k     # measured ~3e-5 on logits of magnitude 10
 
 
+@pytest.mark.parametrize("preset", ["ego4d", "mad"])
+def test_fused_decoder_cross_attention_equals_unfused(preset):
+    """dec_cross.hip folds the memory K/V projections into the cross-attention (q.(W_k x) = (W_k^T q).x, the key
+    bias cancels in the softmax, sum_j P_j (W_v x_j + b_v) = W_v (sum_j P_j x_j) + b_v): same math as the two
+    stacked GEMMs + per-head attention up to fp32 re-association.  mad exercises the 192-key variant."""
+    model, opt, _ = get_model(preset, 0 if preset == "ego4d" else 1)
+    rng = np.random.default_rng(11)
+    B = 23
+    lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
+    lens_v[0], lens_v[1] = opt.max_v_l, 1
+    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
+    lens_q[0], lens_q[1] = opt.max_q_l, 1
+    inp = gi.stage_b_inputs(opt, 123, lens_v, lens_q)
+    dev = _gpu()
+    g = lambda a: torch.from_numpy(a).to(dev)
+    from cone_amd import _lib
+    lib = _lib.load()
+    outs = []
+    try:
+        for fold in (1, 0):
+            _lib.check(lib.cone_test_set_option(b"dec_fold", fold))
+            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+            outs.append({k: o[k].cpu() for k in ("pred_logits", "pred_spans", "hs")})
+    finally:
+        _lib.check(lib.cone_test_set_option(b"dec_fold", 1))
+    assert lib.cone_test_set_option(b"no_such_option", 1) != 0
+    for k in ("pred_logits", "pred_spans", "hs"):
+        assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator
