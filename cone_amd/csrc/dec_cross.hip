@@ -19,6 +19,9 @@
 
 namespace cone {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));   // (float4 struct copies lower to memcpy -> scratch)
+
 template <int CTRL>
 __device__ __forceinline__ float dppx(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -81,34 +84,35 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
     }
     __syncthreads();
 
-    // ---- stage 0: qkf[p][c] = sum_d qs[p][d] * Wk[h*32+d][c], thread = column c
+    // ---- stage 0: qkf[p][c] = sum_d qs[p][d] * Wk[h*32+d][c], thread = column c.  Packed fp32 FMAs
+    // (v_pk_fma_f32): even / odd d accumulate in the two halves, summed at the end.
     for (int h = 0; h < 8; ++h) {
-        float a[NQ];
+        f2v a[NQ];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) a[s] = 0.f;
+        for (int s = 0; s < NQ; ++s) a[s] = f2v{0.f, 0.f};
         const float* wcol = Wk + (size_t)h * 32 * 256 + tid;
 #pragma unroll 2
         for (int d4 = 0; d4 < 8; ++d4) {
-            const float w0 = wcol[(d4 * 4 + 0) * 256], w1 = wcol[(d4 * 4 + 1) * 256];
-            const float w2 = wcol[(d4 * 4 + 2) * 256], w3 = wcol[(d4 * 4 + 3) * 256];
+            const f2v w01 = {wcol[(d4 * 4 + 0) * 256], wcol[(d4 * 4 + 1) * 256]};
+            const f2v w23 = {wcol[(d4 * 4 + 2) * 256], wcol[(d4 * 4 + 3) * 256]};
 #pragma unroll
             for (int s = 0; s < NQ; ++s) {
-                const float4 q4 = *reinterpret_cast<const float4*>(qs + (s * 8 + h) * 32 + d4 * 4);
-                a[s] += (q4.x * w0 + q4.y * w1) + (q4.z * w2 + q4.w * w3);
+                const f4v q4 = *reinterpret_cast<const f4v*>(qs + (s * 8 + h) * 32 + d4 * 4);
+                a[s] = __builtin_elementwise_fma(q4.xy, w01, a[s]);
+                a[s] = __builtin_elementwise_fma(q4.zw, w23, a[s]);
             }
         }
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) qkf[(s * 8 + h) * 256 + tid] = a[s];
+        for (int s = 0; s < NQ; ++s) qkf[(s * 8 + h) * 256 + tid] = a[s].x + a[s].y;
     }
 
     // ---- stage A: scores.  lane = key (NKL keys per lane), wave = PPW pairs.
-    float sc[NKL][C::PPW];
+    f2v sc2[NKL][C::PPW];                                    // even / odd column partial sums
 #pragma unroll
     for (int kk = 0; kk < NKL; ++kk)
 #pragma unroll
-        for (int pp = 0; pp < C::PPW; ++pp) sc[kk][pp] = 0.f;
+        for (int pp = 0; pp < C::PPW; ++pp) sc2[kk][pp] = f2v{0.f, 0.f};
     constexpr int TPASS = C::KP / 32;                       // staging passes: 32 key rows per pass
-    typedef float f4v __attribute__((ext_vector_type(4)));     // (float4 struct copies lower to memcpy -> scratch)
     f4v pf[TPASS];
     const int srow = tid >> 3, spart = tid & 7;
 #define DC_FETCH(ch_)                                                                                      \
@@ -127,16 +131,18 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
         if (ch < 7) { DC_FETCH(ch + 1) }                    // in flight during this chunk's FMAs
 #pragma unroll 2
         for (int c4 = 0; c4 < 8; ++c4) {
-            float4 xk[NKL];
+            f4v xk[NKL];
 #pragma unroll
             for (int kk = 0; kk < NKL; ++kk)
-                xk[kk] = *reinterpret_cast<const float4*>(tile + (lane + 64 * kk) * C::TILE_LD + c4 * 4);
+                xk[kk] = *reinterpret_cast<const f4v*>(tile + (lane + 64 * kk) * C::TILE_LD + c4 * 4);
 #pragma unroll
             for (int pp = 0; pp < C::PPW; ++pp) {
-                const float4 qv = *reinterpret_cast<const float4*>(qkf + (wave * C::PPW + pp) * 256 + ch * 32 + c4 * 4);
+                const f4v qv = *reinterpret_cast<const f4v*>(qkf + (wave * C::PPW + pp) * 256 + ch * 32 + c4 * 4);
 #pragma unroll
-                for (int kk = 0; kk < NKL; ++kk)
-                    sc[kk][pp] += (xk[kk].x * qv.x + xk[kk].y * qv.y) + (xk[kk].z * qv.z + xk[kk].w * qv.w);
+                for (int kk = 0; kk < NKL; ++kk) {
+                    sc2[kk][pp] = __builtin_elementwise_fma(xk[kk].xy, qv.xy, sc2[kk][pp]);
+                    sc2[kk][pp] = __builtin_elementwise_fma(xk[kk].zw, qv.zw, sc2[kk][pp]);
+                }
             }
         }
         __syncthreads();                                    // everyone is done reading this chunk
@@ -150,6 +156,11 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
 
     // ---- stage B: softmax over the keys of each pair -> P[key][wave*PPWP + pp]  (aliases the tile)
     float* P = tile;
+    float sc[NKL][C::PPW];
+#pragma unroll
+    for (int kk = 0; kk < NKL; ++kk)
+#pragma unroll
+        for (int pp = 0; pp < C::PPW; ++pp) sc[kk][pp] = sc2[kk][pp].x + sc2[kk][pp].y;
 #pragma unroll
     for (int pp = 0; pp < C::PPW; ++pp) {
         float m = -INFINITY;
@@ -173,30 +184,30 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage C: ctx[p][c] = sum_j P[j][p] * mem[j][c]; lane = 4 columns, wave = its PPW pairs
-    float4 ctx[C::PPW];
+    f4v ctx[C::PPW];
 #pragma unroll
-    for (int pp = 0; pp < C::PPW; ++pp) ctx[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = 0; pp < C::PPW; ++pp) ctx[pp] = f4v{0.f, 0.f, 0.f, 0.f};
     const float* xrow = X + (size_t)t0 * 256 + lane * 4;
     for (int j0 = 0; j0 < L; j0 += 4) {
-        float4 x4[4];
+        f4v x4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = min(j0 + u, L - 1);
-            x4[u] = *reinterpret_cast<const float4*>(xrow + (size_t)j * 256);
+            x4[u] = *reinterpret_cast<const f4v*>(xrow + (size_t)j * 256);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (j0 + u < L) {
-                float pv[C::PPWP];
+                f4v pv[C::PPWP / 4];
 #pragma unroll
-                for (int i = 0; i < C::PPWP / 4; ++i) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(P + (j0 + u) * C::NPP + wave * C::PPWP + 4 * i);
-                    pv[4 * i] = t4.x; pv[4 * i + 1] = t4.y; pv[4 * i + 2] = t4.z; pv[4 * i + 3] = t4.w;
-                }
+                for (int i = 0; i < C::PPWP / 4; ++i)
+                    pv[i] = *reinterpret_cast<const f4v*>(P + (j0 + u) * C::NPP + wave * C::PPWP + 4 * i);
 #pragma unroll
                 for (int pp = 0; pp < C::PPW; ++pp) {
-                    ctx[pp].x = fmaf(pv[pp], x4[u].x, ctx[pp].x); ctx[pp].y = fmaf(pv[pp], x4[u].y, ctx[pp].y);
-                    ctx[pp].z = fmaf(pv[pp], x4[u].z, ctx[pp].z); ctx[pp].w = fmaf(pv[pp], x4[u].w, ctx[pp].w);
+                    const float p = pv[pp >> 2][pp & 3];
+                    const f2v p2 = {p, p};
+                    ctx[pp].xy = __builtin_elementwise_fma(p2, x4[u].xy, ctx[pp].xy);
+                    ctx[pp].zw = __builtin_elementwise_fma(p2, x4[u].zw, ctx[pp].zw);
                 }
             }
         }
@@ -204,29 +215,30 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
     float* ctxs = qkf;                                       // qkf is dead since the last stage-A barrier
 #pragma unroll
     for (int pp = 0; pp < C::PPW; ++pp)
-        *reinterpret_cast<float4*>(ctxs + (wave * C::PPW + pp) * 256 + lane * 4) = ctx[pp];
+        *reinterpret_cast<f4v*>(ctxs + (wave * C::PPW + pp) * 256 + lane * 4) = ctx[pp];
     __syncthreads();
 
     // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o
     {
-        float o[NQ];
+        f2v o[NQ];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) o[s] = 0.f;
+        for (int s = 0; s < NQ; ++s) o[s] = f2v{0.f, 0.f};
         const int h = tid >> 5;
         const float* wcol = WvT + tid;
 #pragma unroll 4
         for (int c4 = 0; c4 < 64; ++c4) {
-            const float w0 = wcol[(c4 * 4 + 0) * 256], w1 = wcol[(c4 * 4 + 1) * 256];
-            const float w2 = wcol[(c4 * 4 + 2) * 256], w3 = wcol[(c4 * 4 + 3) * 256];
+            const f2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
+            const f2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
 #pragma unroll
             for (int s = 0; s < NQ; ++s) {
-                const float4 cx = *reinterpret_cast<const float4*>(ctxs + (s * 8 + h) * 256 + c4 * 4);
-                o[s] += (cx.x * w0 + cx.y * w1) + (cx.z * w2 + cx.w * w3);
+                const f4v cx = *reinterpret_cast<const f4v*>(ctxs + (s * 8 + h) * 256 + c4 * 4);
+                o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
+                o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
             }
         }
         const float bias = bv[tid];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) OUT[(size_t)(b * NQ + s) * 256 + tid] = o[s] + bias;
+        for (int s = 0; s < NQ; ++s) OUT[(size_t)(b * NQ + s) * 256 + tid] = (o[s].x + o[s].y) + bias;
     }
 }
 
