@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
 #pragma unroll
         for (int s = 0; s < NQ; ++s) a[s] = f2v{0.f, 0.f};
         const float* wcol = Wk + (size_t)h * 32 * 256 + tid;
-#pragma unroll 2
-        for (int d4 = 0; d4 < 8; ++d4) {
+#pragma unroll
+        for (int d4 = 0; d4 < 8; ++d4) {      // 32 W_k loads in flight per thread: this stage is L2-latency bound
             const f2v w01 = {wcol[(d4 * 4 + 0) * 256], wcol[(d4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(d4 * 4 + 2) * 256], wcol[(d4 * 4 + 3) * 256]};
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
         for (int s = 0; s < NQ; ++s) o[s] = f2v{0.f, 0.f};
         const int h = tid >> 5;
         const float* wcol = WvT + tid;
-#pragma unroll 4
+#pragma unroll 8
         for (int c4 = 0; c4 < 64; ++c4) {
             const f2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};

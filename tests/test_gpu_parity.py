@@ -534,6 +534,35 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
         assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
 
 
+@pytest.mark.parametrize("ctx_l,W,dv,nq,k,world", [(901, 90, 256, 3, 20, 8), (131, 90, 256, 2, 5, 8),
+                                                     (200_003, 125, 512, 3, 30, 8), (50_000, 125, 512, 16, 30, 4)])
+def test_ctx_sharded_prefilter_is_bit_exact(ctx_l, W, dv, nq, k, world):
+    """one long video sharded along ctx_l (W-S halo), local stable top-k, k pairs per query
+    exchanged and merged == the single-GPU rank list, scores bit-identical (virtual ranks on one GPU; the
+    exchange itself is covered by the gloo tests)."""
+    from cone_amd import ops, parallel as par
+    dev = _gpu()
+    g = torch.Generator().manual_seed(ctx_l)
+    vid = torch.randn(ctx_l, dv, generator=g)
+    vid = (vid / vid.norm(dim=1, keepdim=True)).to(dev)
+    vid[ctx_l // 2] = vid[ctx_l // 3]                  # exact ties across shards
+    cls = torch.randn(nq, dv, generator=g)
+    cls = (cls / cls.norm(dim=1, keepdim=True)).to(dev)
+    _, ws = ops.prefilter_scores(vid, cls, W)
+    ref_idx, ref_val = ops.topk_windows(ws, min(k, ws.shape[1]))
+    ws_fn = lambda v, c, w: ops.prefilter_scores(v, c, w)[1]
+    vals, idxs = [], []
+    for r in range(world):
+        sh = par.ctx_shard(ctx_l, W, r, world)
+        v, i = par.local_window_topk(vid[sh[2]:sh[3]].contiguous(), sh, cls, W, k, ws_fn, ops.topk_windows)
+        vals.append(v)
+        idxs.append(i)
+    idx, val = par.merge_topk(torch.cat(vals, 1), torch.cat(idxs, 1), k, ops.topk_windows)
+    n = ref_idx.shape[1]
+    assert torch.equal(idx[:, :n], ref_idx) and torch.equal(val[:, :n], ref_val)
+    assert (idx[:, n:] == -1).all()
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator

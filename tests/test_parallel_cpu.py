@@ -109,3 +109,75 @@ def test_two_rank_gloo_window_and_query_sharding():
         p.join(timeout=240)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out.get(timeout=5) == "ok"
+
+
+# ---------------------------------------------------------------------------- ctx-sharded pre-filter
+def _cpu_window_scores(v, c, W):
+    return torch.stack([O.window_scores(O.frame_scores(v, c[q]), W) for q in range(c.shape[0])])
+
+
+def _cpu_topk(x, k):
+    val, idx = torch.sort(x, dim=1, descending=True, stable=True)
+    return idx[:, :k].to(torch.int32), val[:, :k]
+
+
+def _prefilter_case(ctx_l, W, seed, nq=3, dv=16):
+    g = torch.Generator().manual_seed(seed)
+    vid = torch.randn(ctx_l, dv, generator=g)
+    vid = (vid * 4).round() / 4          # coarse values -> many exactly tied frame / window scores (H6)
+    cls = (torch.randn(nq, dv, generator=g) * 2).round() / 2
+    return vid, cls
+
+
+def test_ctx_shard_geometry():
+    for W in (90, 125):
+        S = int(W / 2)
+        for ctx_l in (1, S - 1, S, S + 1, W, W + 1, 901, 5000):
+            nw = O.num_windows(ctx_l, W)
+            for world in (1, 2, 3, 8):
+                sh = [par.ctx_shard(ctx_l, W, r, world) for r in range(world)]
+                assert sh[0][0] == 0 and sh[-1][1] == nw
+                for w_lo, w_hi, f_lo, f_hi in sh:
+                    for i in range(w_lo, w_hi):          # every owned window lies inside the rank's clip rows
+                        a, b = O.window_bounds(i, ctx_l, W)
+                        assert f_lo <= a and b <= f_hi, (ctx_l, W, world, i)
+                    if w_hi > w_lo:
+                        assert f_lo % S == 0
+                        assert f_hi - f_lo <= (w_hi - w_lo + 1) * S + W   # halo only, never the whole video
+
+
+def _ctx_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for W, ctx_l, k in ((90, 901, 20), (90, 1, 5), (90, 44, 5), (90, 46, 3), (90, 333, 5), (125, 700, 30),
+                            (125, 2000, 7)):
+            vid, cls = _prefilter_case(ctx_l, W, seed=ctx_l + W)
+            w_lo, w_hi, f_lo, f_hi = par.ctx_shard(ctx_l, W, rank, world)
+            idx, val = par.prefilter_ctx_sharded(vid[f_lo:f_hi].clone(), ctx_l, cls, W, k,
+                                                 window_scores_fn=_cpu_window_scores, topk_fn=_cpu_topk)
+            full = _cpu_window_scores(vid, cls, W)
+            for q in range(cls.shape[0]):
+                ref = O.rank_windows(full[q])[:k]
+                got = idx[q].tolist()
+                assert got[:len(ref)] == ref, (W, ctx_l, k, q, got, ref)
+                assert all(g == -1 for g in got[len(ref):])
+                assert torch.equal(val[q, :len(ref)], full[q][ref])
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ctx_sharded_prefilter_equals_full_rank_list(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctx_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(timeout=5) == "ok"
