@@ -52,6 +52,21 @@ def collect_profile():
     return buf[:n]
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/
+    r01_pmc_traffic.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
+    runs; counters cannot be read from inside the process).  Same averaging as `achieved`: over all launches of
+    the kernel in a step."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)["cone::" + kernel]
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+
+
 def roofline_from_profile(rec):
     per = {}
     for kind, a, b, c, ms in rec:
@@ -75,6 +90,7 @@ def roofline_from_profile(rec):
             "avg_launch_ms": round(d["ms"] / d["launches"], 4),
             "flops_per_launch": round(d["flops"] / d["launches"]),
             "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
+    roof.update(pmc_traffic(KERNEL_NAMES[dom]))
     extra = {KERNEL_NAMES[k]: {"ms": round(v["ms"], 3), "launches": v["launches"],
                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in per.items()}
     for kind in (3, 4, 7):

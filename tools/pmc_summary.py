@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise the three rocprofv3 PMC passes of bench.py (FETCH_SIZE / WRITE_SIZE / MFMA busy, each collected
+in its own run as /opt/skills/guides/MI355X_MICROARCH.md prescribes) into a CSV + the JSON bench.py reads for
+`roofline.traffic`.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv \
+              -d gpurun_out/pmc_mfma -o m -- python3 bench.py ...
+    python tools/pmc_summary.py gpurun_out profiles/r01_pmc
+
+Corrections (guide, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B
+requests at 64 B, so reads are doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path):
+    per = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+src, dst = sys.argv[1], sys.argv[2]
+f = load(f"{src}/pmc_fetch/f_counter_collection.csv")
+w = load(f"{src}/pmc_write/w_counter_collection.csv")
+m = load(f"{src}/pmc_mfma/m_counter_collection.csv")
+rows, traffic = [], {}
+for k in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
+    if "cone::" not in k:
+        continue
+    fv, wv = f[k]["FETCH_SIZE"], w.get(k, {}).get("WRITE_SIZE", [0.0])
+    mm = m.get(k, {})
+    busy = sum(mm.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0]))
+    act = sum(mm.get("GRBM_GUI_ACTIVE", [0.0]))
+    rd = 2.0 * 1024 * sum(fv) / len(fv)
+    wr = 1024 * sum(wv) / len(wv)
+    util = 100.0 * (busy / 1024) / (act / 8) if act else 0.0
+    rows.append((k, len(fv), rd, wr, rd + wr, util))
+    traffic[k] = {"launches": len(fv), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                  "hbm_bytes_per_launch": rd + wr, "mfma_busy_pct": round(util, 1)}
+with open(dst + "_counters.csv", "w") as o:
+    o.write("kernel,launches,hbm_read_bytes_per_launch(2xFETCH_SIZE),hbm_write_bytes_per_launch,hbm_bytes_per_launch,"
+            "mfma_busy_pct\n")
+    for r in rows:
+        o.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.1f}\n")
+with open(dst + "_traffic.json", "w") as o:
+    json.dump(traffic, o, indent=1, sort_keys=True)
+print(open(dst + "_counters.csv").read())
