@@ -91,6 +91,14 @@ def roofline_from_profile(rec):
             "flops_per_launch": round(d["flops"] / d["launches"]),
             "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
     roof.update(pmc_traffic(KERNEL_NAMES[dom]))
+    shapes = {}
+    for kind, a, b, c, ms in rec:       # the dominant kernel by (N, K): which layers pull the average down
+        if int(kind) == dom and a >= 65536:
+            d2 = shapes.setdefault(f"N{int(b)}_K{int(c)}", [0.0, 0.0, 0])
+            d2[0] += 2.0 * a * b * c
+            d2[1] += ms
+            d2[2] += 1
+    roof["by_shape_tflops"] = {k: [round(v[0] / (v[1] * 1e-3) / 1e12, 1), v[2]] for k, v in sorted(shapes.items())}
     extra = {KERNEL_NAMES[k]: {"ms": round(v["ms"], 3), "launches": v["launches"],
                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in per.items()}
     for kind in (3, 4, 7):

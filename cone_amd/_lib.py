@@ -111,6 +111,10 @@ _SIGNATURES = {
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_prof_enable": (C.c_int, [C.c_int]),
     "cone_prof_collect": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "cone_eval_recall": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_eval_window_recall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_void_p]),
     "cone_test_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     # cone_test_gemm(A, A2, a2_mod, W, bias, R, ln_g, ln_b, C, C2, ADD, M, N, K, flags, stream)
     "cone_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

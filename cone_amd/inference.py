@@ -72,6 +72,7 @@ class FeatureStore:
         self.cls_raw = torch.from_numpy(np.stack(clss, 0)).to(dev)
         self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
         self._plan = None
+        self._index = None
 
     @classmethod
     def subset(cls, store, lo: int, hi: int):
@@ -89,7 +90,19 @@ class FeatureStore:
         sub.cls_raw = store.cls_raw[lo:hi]
         sub.q_vid = store.q_vid[lo:hi]
         sub._plan = None
+        sub._index = None
         return sub
+
+    def index_tensors(self):
+        """Static per-query index metadata on the device (depends on the annotation file only)."""
+        if getattr(self, "_index", None) is None:
+            dev = self.device
+            qv = torch.from_numpy(self.q_vid).to(dev)
+            self._index = dict(q_ctx_l=torch.tensor(self.ctx_l, device=dev)[qv],
+                               q_vid_off=torch.from_numpy(self.vid_off).to(dev)[qv],
+                               tok_off=torch.from_numpy(np.ascontiguousarray(self.tok_off)).to(dev),
+                               tok_len=torch.tensor(self.tok_len, device=dev))
+        return self._index
 
     def prefilter_plan(self):
         """Static index metadata of the pre-filter (depends on the annotation file only): groups of one
@@ -167,12 +180,11 @@ def window_table(store: FeatureStore, opt, win_idx):
     dev = store.device
     nq, K = win_idx.shape
     W, S = opt.max_v_l, int(opt.max_v_l / 2)
-    valid = win_idx >= 0
-    q_of = torch.arange(nq, device=dev)[:, None].expand(nq, K)[valid]
-    slot = torch.arange(K, device=dev)[None, :].expand(nq, K)[valid]
-    wi = win_idx[valid].to(torch.int64)
-    ctx_l = torch.tensor(store.ctx_l, device=dev)[torch.from_numpy(store.q_vid).to(dev)][q_of]
-    voff = torch.from_numpy(store.vid_off).to(dev)[torch.from_numpy(store.q_vid).to(dev)][q_of]
+    q_of, slot = (win_idx >= 0).nonzero(as_tuple=True)       # row-major; the one host sync of the table
+    wi = win_idx[q_of, slot].to(torch.int64)
+    st = store.index_tensors()
+    ctx_l = st["q_ctx_l"][q_of]
+    voff = st["q_vid_off"][q_of]
     start = torch.clamp((wi - 1) * S, min=0)
     end = torch.minimum((wi - 1) * S + W, ctx_l)
     vlen = end - start
@@ -181,8 +193,7 @@ def window_table(store: FeatureStore, opt, win_idx):
     nb = (nq + opt.eval_bsz - 1) // opt.eval_bsz
     pad = torch.zeros(nb, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, vlen, reduce="amax")
     i32 = lambda t: t.to(torch.int32).contiguous()
-    tok_off = torch.from_numpy(store.tok_off).to(dev)
-    tok_len = torch.tensor(store.tok_len, device=dev)
+    tok_off, tok_len = st["tok_off"], st["tok_len"]
     return dict(q_of=q_of, slot=slot, vid_row0=i32(voff + start), vid_len=i32(vlen), video_start=i32(start),
                 pad_len=i32(pad[bid]), txt_row0=i32(tok_off[q_of]), txt_len=i32(tok_len[q_of]), cls_row=i32(q_of))
 

@@ -221,6 +221,22 @@ int cone_matcher_cost(const float* logits, const float* spans, const float* tgt,
                       float cost_span, float cost_giou, float cost_class, float* cost, int32_t* best,
                       void* stream);
 
+/* -------------------------------------------------------------------- metrics on the device
+ * Recall@K / IoU counts from the kept rows (layout of cone_fuse_nms: rows (nq, max_after, 5) fp64 [st, ed, ...],
+ * n (nq) valid rows) and one target span per query gt (nq, 2) fp64 seconds -- device pointers.  thresholds /
+ * topk are HOST arrays (<= 8 / <= 16 entries).  hits (n_thr, n_topk) int64 on the device: number of queries
+ * with a prediction of IoU > threshold among their first K rows; top1_iou (nq) fp64: IoU of the first row.
+ * mode 0 = standalone_eval/evaluate_ego4d_nlq.py:41-60,93-103 (float64, union clamped at 0);
+ * mode 1 = standalone_eval/evaluate_mad.py:33-38,87-104 (float32 arithmetic, thresholds as fp32). */
+int cone_eval_recall(const double* rows, const int32_t* n, const double* gt, int nq, int max_after,
+                     const double* thresholds, int n_thr, const int32_t* topk, int n_topk, int mode,
+                     int64_t* hits, double* top1_iou, void* stream);
+/* Window pre-filter recall, standalone_eval/evaluate_pre_filtered_window.py:45-66: win_idx (nq, k) int32 ranked
+ * windows (-1 padded), gt (nq, 2) fp64 seconds; hits (n_topk) int64 = queries whose first K windows contain
+ * one of floor(start/S) .. ceil(end/S), start/end in clips (seconds / clip_length), S = slide. */
+int cone_eval_window_recall(const int32_t* win_idx, int nq, int k, const double* gt, double clip_length,
+                            int slide, const int32_t* topk, int n_topk, int64_t* hits, void* stream);
+
 /* -------------------------------------------------------------------- measurement
  * Opt-in per-launch timing with hipEvents on the launch stream (used by bench.py for the roofline
  * line).  cone_prof_enable(1) clears and starts recording, (0) stops.  After synchronising the

@@ -520,3 +520,88 @@ def eval_epoch(sd, opt, ann, video_feats, query_feats):
         ranks, _ = prefilter(sd, opt, ann, video_feats, query_feats)
         mr = compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks)
     return postprocess(mr, opt), ranks, mr
+
+
+# ------------------------------------------------------------------ metrics
+def ego4d_ground_truth_table(ground_truth):
+    """standalone_eval/evaluate_ego4d_nlq.py:67-77 -- {(clip_uid, annotation_uid): annotation}."""
+    table = {}
+    for video in ground_truth["videos"]:
+        for clip in video["clips"]:
+            for ann in clip["annotations"]:
+                table[(clip["clip_uid"], ann["annotation_uid"])] = ann
+    return table
+
+
+def iou_f64(pred, gt):
+    """standalone_eval/evaluate_ego4d_nlq.py:41-60 for one target: numpy doubles, union clamped at 0,
+    plain division (0/0 -> nan, x/0 -> inf)."""
+    pred = np.asarray(pred, dtype=np.float64)
+    ps, pe = pred[:, 0], pred[:, 1]
+    inter = np.maximum(0.0, np.minimum(pe, gt[1]) - np.maximum(ps, gt[0]))
+    union = np.maximum(0.0, np.maximum(pe, gt[1]) - np.minimum(ps, gt[0]))
+    with np.errstate(all="ignore"):
+        return 1.0 * inter / union
+
+
+def evaluate_nlq_performance_ego4d(predictions, ground_truth, thresholds, topK):
+    """standalone_eval/evaluate_ego4d_nlq.py:63-115 -> (results (n_thr, n_topK) float64, mIoU float64).
+    mIoU averages the IoU of the first prediction of every query."""
+    table = ego4d_ground_truth_table(ground_truth)
+    hits = np.zeros((len(thresholds), len(topK), len(predictions)), dtype=bool)
+    top1 = []
+    for qi, p in enumerate(predictions):
+        key = (p["clip_uid"], p["annotation_uid"])
+        assert key in table, "Instance not present!"
+        q = table[key]["language_queries"][p["query_idx"]]
+        ov = iou_f64(p["predicted_times"], (q["clip_start_sec"], q["clip_end_sec"]))
+        top1.append(ov[0])
+        for t, thr in enumerate(thresholds):
+            for r, k in enumerate(topK):
+                hits[t, r, qi] = bool((ov > thr)[:k].any())
+    return hits.mean(axis=-1), np.mean(np.asarray(top1).reshape(-1, 1))
+
+
+def iou_f32(candidates, gt):
+    """standalone_eval/evaluate_mad.py:33-38 -- torch fp32: inter clamped at 0, union NOT clamped."""
+    start, end = candidates[:, 0].float(), candidates[:, 1].float()
+    s, e = gt[0].float(), gt[1].float()
+    inter = torch.minimum(end, e) - torch.maximum(start, s)
+    union = torch.maximum(end, e) - torch.minimum(start, s)
+    return inter.clamp(min=0) / union
+
+
+def evaluate_nlq_performance_mad(submission, ground_truth, thresholds, topK):
+    """standalone_eval/evaluate_mad.py:61-107 -> (n_topK, n_thr) float32 tensor."""
+    truth = {d["query_id"]: d["timestamps"] for d in ground_truth}
+    assert set(truth) == {e["query_id"] for e in submission}
+    thr = torch.as_tensor(thresholds, dtype=torch.float32)
+    ks = [int(k) for k in topK]
+    out = torch.zeros(len(ks), len(thr))
+    for e in submission:
+        iou = iou_f32(torch.tensor(e["predicted_times"][:max(ks)]), torch.tensor(truth[e["query_id"]]))
+        over = iou[:, None] > thr[None, :]
+        for i, k in enumerate(ks):
+            out[i] += over[:k].any(dim=0)
+    out /= len(submission)
+    return out
+
+
+def windows_selection(query_id2windowidx, ground_truth, topK, clip_length, max_v_l):
+    """standalone_eval/evaluate_pre_filtered_window.py:30-72 -> (n_topK,) float32 tensor: is any of the first
+    r ranked windows one of the windows floor(start/S) .. ceil(end/S) that contain the target?"""
+    S = int(max_v_l / 2)
+    ks = [int(k) for k in topK]
+    out = torch.zeros(len(ks))
+    truth = {}
+    for m in ground_truth:
+        start, end = m["timestamps"][0] / clip_length, m["timestamps"][1] / clip_length
+        truth[m["query_id"]] = (math.floor(start / S), math.ceil(end / S) + 1)
+    assert set(truth) == set(query_id2windowidx)
+    for qid, ranks in query_id2windowidx.items():
+        lo, hi = truth[qid]
+        inside = [lo <= w < hi for w in ranks[:max(ks)]]
+        for i, k in enumerate(ks):
+            out[i] += float(any(inside[:k]))
+    out /= len(query_id2windowidx)
+    return out

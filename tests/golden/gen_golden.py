@@ -347,8 +347,105 @@ def gen_localizer(name, seed):
     print("wrote", name)
 
 
+def metric_inputs(seed, nq=48):
+    """Synthetic submissions + ground truth for the metric evaluators (also used by the tests to rebuild
+    device inputs): per query 1..9 rows [st, ed, prop, match, fused] at 4 decimals, with exact-threshold,
+    disjoint, contained and degenerate (zero-length on a zero-length target) cases mixed in."""
+    rng = np.random.default_rng(seed)
+    preds, gts = [], []
+    for q in range(nq):
+        g0 = round(float(rng.uniform(0, 400)), 4)
+        g1 = round(g0 + float(rng.uniform(1, 60)), 4)
+        n = int(rng.integers(1, 10))
+        rows = []
+        for i in range(n):
+            kind = rng.integers(0, 6)
+            if kind == 0:                      # near the target
+                s0 = g0 + float(rng.uniform(-20, 20)); e0 = s0 + float(rng.uniform(0.5, 70))
+            elif kind == 1:                    # far away
+                s0 = g1 + float(rng.uniform(50, 90)); e0 = s0 + float(rng.uniform(1, 30))
+            elif kind == 2:                    # IoU exactly 0.5 / 0.3 of an integer-length target (strict > must fail)
+                s0 = g0; e0 = g0 + (g1 - g0) * (0.5 if i % 2 else 0.3)
+            elif kind == 3:                    # contains the target
+                s0 = g0 - float(rng.uniform(0, 5)); e0 = g1 + float(rng.uniform(0, 5))
+            elif kind == 4:                    # identical
+                s0, e0 = g0, g1
+            else:                              # zero length
+                s0 = e0 = g0 + float(rng.uniform(0, 10))
+            rows.append([round(s0, 4), round(e0, 4), round(float(rng.uniform(0, 1)), 4),
+                         round(float(rng.uniform(-1, 1)), 4), round(float(rng.uniform(0, 2)), 4)])
+        preds.append(rows)
+        gts.append([g0, g1])
+    # degenerate pair: zero-length target hit by a zero-length prediction -> 0/0
+    gts[3] = [7.0, 7.0]                 # (kept off rank 1 so that mIoU stays finite; numpy gives nan > thr == False)
+    while len(preds[3]) < 3:
+        preds[3].append([1.0, 2.0, .1, .1, .1])
+    preds[3][1][:2] = [7.0, 7.0]
+    gts[5] = [10.0, 20.0]
+    preds[5] = [[10.0, 13.0, .5, .5, .5], [10.0, 15.0, .4, .4, .4], [12.0, 18.0001, .3, .3, .3]]   # 0.3, 0.5, >0.6
+    return preds, gts
+
+
+def gen_metrics(name, seed):
+    """standalone_eval/evaluate_ego4d_nlq.py:63-115, evaluate_mad.py:61-107, evaluate_pre_filtered_window.py:30-72."""
+    import standalone_eval.evaluate_ego4d_nlq as ego4d_eval
+    import standalone_eval.evaluate_mad as mad_eval
+    import standalone_eval.evaluate_pre_filtered_window as window_eval
+    preds, gts = metric_inputs(seed)
+    nq = len(preds)
+    # --- ego4d: nested ground truth, flat predictions
+    gt_json = {"videos": [{"clips": []}]}
+    predictions = []
+    for q in range(nq):
+        clip, ann_uid, qidx = f"clip{q // 5}", f"ann{q // 3}", q % 3
+        clips = gt_json["videos"][0]["clips"]
+        c = next((c for c in clips if c["clip_uid"] == clip), None)
+        if c is None:
+            c = {"clip_uid": clip, "annotations": []}
+            clips.append(c)
+        a = next((a for a in c["annotations"] if a["annotation_uid"] == ann_uid), None)
+        if a is None:
+            a = {"annotation_uid": ann_uid, "language_queries": [None, None, None]}
+            c["annotations"].append(a)
+        a["language_queries"][qidx] = {"clip_start_sec": gts[q][0], "clip_end_sec": gts[q][1]}
+        predictions.append({"query_idx": qidx, "annotation_uid": ann_uid, "predicted_times": preds[q], "clip_uid": clip})
+    for c in gt_json["videos"][0]["clips"]:
+        for a in c["annotations"]:
+            a["language_queries"] = [x if x is not None else {"clip_start_sec": 0.0, "clip_end_sec": 1.0}
+                                     for x in a["language_queries"]]
+    thr_e, topk_e = [0.3, 0.5], [1, 5, 10, 50, 100]                 # cone/inference.py:422-423
+    with np.errstate(all="ignore"):
+        res_e, miou_e = ego4d_eval.evaluate_nlq_performance(predictions, gt_json, thr_e, topk_e)
+    # --- mad: jsonl-style
+    sub = [{"query_id": f"q{q}", "predicted_times": preds[q], "video_id": f"v{q // 7}"} for q in range(nq)]
+    gt_mad = [{"query_id": f"q{q}", "timestamps": gts[q]} for q in range(nq)]
+    thr_m, topk_m = torch.tensor([0.1, 0.3, 0.5]), torch.tensor([1, 5, 10, 50, 100])    # cone/inference.py:333-334
+    res_m = mad_eval.evaluate_nlq_performance(sub, gt_mad, thr_m, topk_m)
+    # --- window pre-filter recall
+    rng = np.random.default_rng(seed + 1)
+    opt = SimpleNamespace(clip_length=0.535, max_v_l=90)
+    q2w = {}
+    for q in range(nq):
+        nw = int(rng.integers(3, 60))
+        q2w[f"q{q}"] = [int(x) for x in rng.permutation(nw)]
+    topk_w = torch.tensor([1, 5, 10, 30, 50])
+    res_w = window_eval.windows_selection(q2w, gt_mad, topk_w, opt)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(dict(seed=seed, preds=preds, gts=gts,
+                       ego4d=dict(predictions=predictions, ground_truth=gt_json, thresholds=thr_e, topK=topk_e,
+                                  results=np.asarray(res_e).tolist(), mIoU=float(miou_e)),
+                       mad=dict(thresholds=[0.1, 0.3, 0.5], topK=topk_m.tolist(),
+                                results=[[float(x) for x in r] for r in res_m.tolist()]),
+                       window=dict(ranklists=q2w, clip_length=opt.clip_length, max_v_l=opt.max_v_l,
+                                   topK=topk_w.tolist(), results=[float(x) for x in res_w.tolist()])), f)
+    print("wrote", name, "mIoU", float(miou_e))
+
+
 def main():
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        gen_metrics("metrics", 0)
+        return
     gen_stage_b("stageB_ego4d", "ego4d", 0, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17])
     gen_stage_b("stageB_mad", "mad", 1, [125, 62, 3, 125], [25, 6, 11, 18])
     gen_stage_a("stageA_ego4d", "ego4d", 0, [901, 900, 44, 91])
@@ -359,6 +456,7 @@ def main():
     gen_stage_c("stageC", 0)
     gen_matcher("matcher", 0)
     gen_localizer("localizer", 0)
+    gen_metrics("metrics", 0)
 
 
 if __name__ == "__main__":

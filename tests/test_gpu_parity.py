@@ -563,6 +563,82 @@ def test_ctx_sharded_prefilter_is_bit_exact(ctx_l, W, dv, nq, k, world):
     assert (idx[:, n:] == -1).all()
 
 
+def _rows_tensor(preds, dev):
+    A = max(len(p) for p in preds)
+    rows = torch.zeros(len(preds), A, 5, dtype=torch.float64)
+    for q, p in enumerate(preds):
+        rows[q, :len(p)] = torch.tensor(p, dtype=torch.float64)
+    n = torch.tensor([len(p) for p in preds], dtype=torch.int32)
+    return rows.to(dev), n.to(dev)
+
+
+def test_device_metrics_match_reference_golden(golden_dir):
+    """R@K / mIoU / window-recall tables from device-resident rows == the reference's standalone_eval outputs,
+    bit for bit (exact-threshold, 0/0 and fp32-rounding cases are in the fixture)."""
+    from cone_amd import metrics as M
+    with open(os.path.join(golden_dir, "metrics.json")) as f:
+        fx = json.load(f)
+    dev = _gpu()
+    rows, n = _rows_tensor(fx["preds"], dev)
+    gt = torch.tensor(fx["gts"], dtype=torch.float64, device=dev)
+    e = fx["ego4d"]
+    ann = [{"query_id": f"{p['annotation_uid']}_{p['query_idx']}", "clip_id": p["clip_uid"]} for p in e["predictions"]]
+    assert np.array_equal(M.ego4d_targets(ann, e["ground_truth"]), np.asarray(fx["gts"]))
+    res, miou = M.evaluate_nlq_performance_ego4d(rows, n, gt, e["thresholds"], e["topK"])
+    assert res.tolist() == e["results"] and float(miou) == e["mIoU"]
+    m = fx["mad"]
+    got = M.evaluate_nlq_performance_mad(rows, n, gt, m["thresholds"], m["topK"])
+    assert [[float(x) for x in r] for r in got.tolist()] == m["results"]
+    w = fx["window"]
+    K = max(len(v) for v in w["ranklists"].values())
+    wi = torch.full((len(fx["preds"]), K), -1, dtype=torch.int32)
+    for q in range(len(fx["preds"])):
+        r = w["ranklists"][f"q{q}"]
+        wi[q, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    got = M.windows_selection(wi.to(dev), gt, w["topK"], w["clip_length"], w["max_v_l"])
+    assert [float(x) for x in got.tolist()] == w["results"]
+    assert "Rank@1" in M.display_results_ego4d(res, miou, e["thresholds"], e["topK"], title="Fusion")
+
+
+def test_device_metrics_match_oracle_random():
+    from cone_amd import metrics as M
+    rng = np.random.default_rng(3)
+    nq = 3000
+    preds, gts = [], []
+    for q in range(nq):
+        g0 = round(float(rng.uniform(0, 300)), 4)
+        g1 = round(g0 + float(rng.uniform(0.5, 40)), 4)
+        k = int(rng.integers(1, 13))
+        st = np.round(g0 + rng.uniform(-30, 30, k), 4)
+        ed = np.round(st + rng.uniform(0, 50, k), 4)
+        preds.append([[float(a), float(b), 0.1, 0.2, 0.3] for a, b in zip(st, ed)])
+        gts.append([g0, g1])
+    dev = _gpu()
+    rows, n = _rows_tensor(preds, dev)
+    gt = torch.tensor(gts, dtype=torch.float64, device=dev)
+    sub = [{"query_id": f"q{q}", "predicted_times": p} for q, p in enumerate(preds)]
+    gtl = [{"query_id": f"q{q}", "timestamps": g} for q, g in enumerate(gts)]
+    thr, ks = [0.1, 0.3, 0.5], [1, 5, 10, 50, 100]
+    ref = O.evaluate_nlq_performance_mad(sub, gtl, thr, ks)
+    got = M.evaluate_nlq_performance_mad(rows, n, gt, thr, ks)
+    assert torch.equal(got, ref)
+    # ego4d flavour through the oracle's float64 IoU
+    hits, top1 = M.recall_counts(rows, n, gt, [0.3, 0.5], [1, 5], 0)
+    ov = [O.iou_f64(p, g) for p, g in zip(preds, gts)]
+    assert np.array_equal(top1.cpu().numpy(), np.array([o[0] for o in ov]))
+    for t, th in enumerate((0.3, 0.5)):
+        for r, k in enumerate((1, 5)):
+            assert int(hits[t, r]) == sum(bool((o > th)[:k].any()) for o in ov)
+    ranks = {f"q{q}": [int(x) for x in rng.permutation(int(rng.integers(2, 40)))] for q in range(nq)}
+    K = max(len(v) for v in ranks.values())
+    wi = torch.full((nq, K), -1, dtype=torch.int32)
+    for q in range(nq):
+        wi[q, :len(ranks[f"q{q}"])] = torch.tensor(ranks[f"q{q}"], dtype=torch.int32)
+    ref = O.windows_selection(ranks, gtl, [1, 5, 10, 30, 50], 0.535, 90)
+    got = M.windows_selection(wi.to(dev), gt, [1, 5, 10, 30, 50], 0.535, 90)
+    assert torch.equal(got, ref)
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator

@@ -163,3 +163,24 @@ def test_localizer_matches_reference(golden_dir):
         ref = case["out"]
         assert len(got) == len(ref)
         assert np.abs(np.array(got) - np.array(ref)).max() < 1e-3
+
+
+def test_metric_evaluators_match_reference(golden_dir):
+    """standalone_eval: R@K / mIoU tables and the window-recall table, bit-exact."""
+    with open(os.path.join(golden_dir, "metrics.json")) as f:
+        fx = json.load(f)
+    e = fx["ego4d"]
+    res, miou = O.evaluate_nlq_performance_ego4d(e["predictions"], e["ground_truth"], e["thresholds"], e["topK"])
+    assert res.tolist() == e["results"] and float(miou) == e["mIoU"]
+    sub = [{"query_id": f"q{q}", "predicted_times": p} for q, p in enumerate(fx["preds"])]
+    gt = [{"query_id": f"q{q}", "timestamps": g} for q, g in enumerate(fx["gts"])]
+    m = fx["mad"]
+    got = O.evaluate_nlq_performance_mad(sub, gt, m["thresholds"], m["topK"])
+    assert [[float(x) for x in r] for r in got.tolist()] == m["results"]
+    w = fx["window"]
+    got = O.windows_selection(w["ranklists"], gt, w["topK"], w["clip_length"], w["max_v_l"])
+    assert [float(x) for x in got.tolist()] == w["results"]
+    # the fixture really contains the edge cases: an IoU exactly on a threshold and a 0/0
+    ov = O.iou_f64(fx["preds"][5], fx["gts"][5])
+    assert ov[0] == 0.3 and ov[1] == 0.5 and not (ov[:2] > np.array([0.3, 0.5])).any()
+    assert np.isnan(O.iou_f64(fx["preds"][3], fx["gts"][3])[1])
