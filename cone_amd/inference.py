@@ -164,13 +164,14 @@ class FeatureStore:
 
 # ------------------------------------------------------------------------------------ stage A
 @torch.no_grad()
-def prefilter(model, store: FeatureStore, opt):
-    """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window)."""
+def prefilter(model, store: FeatureStore, opt, k=None):
+    """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window);
+    ``k`` overrides opt.topk_window (the window-recall table ranks deeper than the model consumes)."""
     dev = store.device
     vid_norm = ops.l2_normalize(store.vid_raw, 1e-5)          # PreFilteringDataset :459
     ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
     cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)          # :473
-    win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, store.prefilter_plan(), opt.max_v_l, opt.topk_window)
+    win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, store.prefilter_plan(), opt.max_v_l, k or opt.topk_window)
     return win_idx
 
 
@@ -406,15 +407,77 @@ def predict_split(model, store: FeatureStore, opt):
     return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
 
 
+EGO4D_VAL_GT = "data/ego4d_ori_data/nlq_val.json"      # hard-coded by the reference, cone/inference.py:420
+
+
+@torch.no_grad()
+def evaluate_split(model, store: FeatureStore, opt, dp, ground_truth=None, epoch_i=None):
+    """The metric tables of cone/inference.py:332-381 (MAD) / :419-474 (Ego4D) from the device-resident kept
+    rows ``dp`` of device_pipeline -- no JSON round trip, no python loop over queries (cone_amd.metrics).
+    Returns (results, mIoU, results_proposal, mIoU_proposal, results_matching, mIoU_matching, score strings);
+    like the reference's display functions, the returned tables are in percent."""
+    from . import metrics as M
+    dev = store.device
+    rows, n = dp["rows"], dp["n"]
+    if opt.dset_name == "mad":
+        gt = torch.from_numpy(M.jsonl_targets(store.ann)).to(dev)
+        thr, topk, wk = [0.1, 0.3, 0.5], [1, 5, 10, 50, 100], [1, 5, 10, 30, 50, 100, 200]
+    else:
+        if ground_truth is None:
+            with open(getattr(opt, "ego4d_gt_path", None) or EGO4D_VAL_GT) as f:
+                ground_truth = json.load(f)
+        gt = torch.from_numpy(M.ego4d_targets(store.ann, ground_truth)).to(dev)
+        thr, topk, wk = [0.3, 0.5], [1, 5, 10, 50, 100], [1, 5, 10, 30, 50]
+    max_nw = max(-(-c // int(opt.max_v_l / 2)) + 1 for c in store.ctx_l)
+    deep = prefilter(model, store, opt, k=min(max(wk), max_nw))          # the reference ranks every window
+    wres = M.windows_selection(deep, torch.from_numpy(M.jsonl_targets(store.ann)).to(dev), wk, opt.clip_length,
+                               opt.max_v_l)
+    strs = [M.display_window_results(wres, wk, title=f"Window Pre-filtering Epoch {epoch_i}")]
+    out = []
+    for t, name in enumerate(("Fusion", "Proposal", "Matching")):
+        if opt.dset_name == "mad":
+            res, miou = M.evaluate_nlq_performance_mad(rows[t], n[t], gt, thr, topk), None
+            strs.append(M.display_results_mad(res, thr, topk, title=f"{name} Epoch {epoch_i}"))
+        else:
+            res, miou = M.evaluate_nlq_performance_ego4d(rows[t], n[t], gt, thr, topk)
+            strs.append(M.display_results_ego4d(res, miou, thr, topk, title=f"{name} Epoch {epoch_i}"))
+        out += [res * 100, miou]
+    return (*out, strs)
+
+
 def eval_epoch(model, store: FeatureStore, opt, save_submission_filename, epoch_i=None, criterion=None,
-               tb_writer=None):
-    """cone/inference.py:227-499 without the metric tables: writes the prediction files and returns
-    ``(None, None, [], latest_file_paths)`` in the reference's result slots."""
+               tb_writer=None, ground_truth=None):
+    """cone/inference.py:227-499: writes the prediction files; on the splits the reference scores (Ego4D val,
+    MAD val / test) also the metric tables + ``.txt`` file.  Returns the reference's tuple
+    ``(results, mIoU, [window, fusion, proposal, matching score strings], latest_file_paths)`` -- ``(None, None,
+    [], paths)`` when there is nothing to score (the reference ``exit(0)``s there, :476-477)."""
     logger.info("Generate submissions")
     (fusion, proposal, matching), info = predict_split(model, store, opt)
     print("total model running time: ", info["model_seconds"])
     paths = write_submissions(opt, fusion, proposal, matching, save_submission_filename)
-    return None, None, [], paths
+    scored = opt.eval_split_name == "val" or (opt.dset_name == "mad" and opt.eval_split_name == "test")
+    if not scored:
+        print("end of inference on test split")
+        return None, None, [], paths
+    res, miou, res_p, miou_p, res_m, miou_m, strs = evaluate_split(model, store, opt, info, ground_truth, epoch_i)
+    for s_ in strs:
+        print(s_, flush=True)
+    sub_path = os.path.join(opt.results_dir, save_submission_filename)
+    txt = sub_path.replace(".jsonl" if opt.dset_name == "mad" else ".json", ".txt")
+    with open(txt, mode="w", encoding="utf-8") as f:
+        for s_ in (strs[1:] if opt.dset_name == "mad" else strs):       # MAD omits the window table, :376-379
+            f.write(s_)
+    latest = [txt]
+    if opt.eval_modality == "both":
+        out_res, out_miou = res, miou
+        latest.append(sub_path)
+    elif opt.eval_modality == "proposal":
+        out_res, out_miou = res_p, miou_p
+        latest.append(sub_path.replace("preds", "proposal_preds"))
+    else:
+        # the reference tests for "clip", which the CLI cannot produce (H10): "matching" raises there
+        raise UnboundLocalError("eval_modality %r is not scored by the reference" % (opt.eval_modality,))
+    return out_res, (out_miou if opt.dset_name == "ego4d" else None), strs, latest
 
 
 def setup_model(opt):

@@ -420,8 +420,14 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path):
         ref_rows = [json.loads(l) for l in files[fn].split("\n")] if preset == "mad" else json.loads(files[fn])["results"]
         assert json.loads(json.dumps(got)) == ref_rows
     # and the full device pipeline writes files of the same structure
-    _, _, _, paths = inf.eval_epoch(model, store, opt, f"inference_{preset}_test_golden_preds.{ext}")
-    assert len(paths) == 3 and all(os.path.exists(p) for p in paths)
+    res, _, strs, paths = inf.eval_epoch(model, store, opt, f"inference_{preset}_test_golden_preds.{ext}")
+    written = [os.path.join(str(tmp_path), f"inference_{preset}_test_golden_{tag}preds.{ext}")
+               for tag in ("", "proposal_", "matching_")]
+    assert all(os.path.exists(p) for p in written)
+    if preset == "mad":     # the reference scores the MAD test split too (cone/inference.py:332): .txt + tables
+        assert paths[0].endswith(".txt") and paths[1] == written[0] and len(strs) == 4 and res.shape == (5, 3)
+    else:                   # Ego4D test: files only (the reference exits there, :476-477)
+        assert paths == written and res is None
     if preset == "ego4d":
         with open(paths[0]) as fh:
             sub = json.load(fh)
@@ -637,6 +643,61 @@ def test_device_metrics_match_oracle_random():
     ref = O.windows_selection(ranks, gtl, [1, 5, 10, 30, 50], 0.535, 90)
     got = M.windows_selection(wi.to(dev), gt, [1, 5, 10, 30, 50], 0.535, 90)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("preset", ["ego4d", "mad"])
+def test_val_split_ends_with_metric_tables(preset, tmp_path):
+    """eval_epoch on a scored split: prediction files + the .txt tables; the numbers equal the oracle's
+    restatement of standalone_eval applied to the written submission lists and the ranked window lists."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model(preset, 0 if preset == "ego4d" else 1)
+    opt = make_opt(preset, nms_thd=0.5, eval_split_name="val", topk_window=6, eval_bsz=8, save_all=True,
+                   results_dir=str(tmp_path), max_after_nms=20)
+    ann, vf, qf = synth.make_dataset(opt, 31, 4, seed=8, ctx_range=(200, 700))
+    rng = np.random.default_rng(0)
+    for r in ann:                                   # targets inside the video, in seconds
+        a = float(rng.uniform(0, 0.8 * r["duration"]))
+        r["timestamps"] = [round(a, 3), round(a + float(rng.uniform(2, 40)), 3)]
+    gt_json = {"videos": [{"clips": []}]}
+    for r in (ann if preset == "ego4d" else []):    # nested NLQ json of the same targets
+        uid, qidx = r["query_id"].split("_")
+        clips = gt_json["videos"][0]["clips"]
+        c = next((c for c in clips if c["clip_uid"] == r["clip_id"]), None)
+        if c is None:
+            c = {"clip_uid": r["clip_id"], "annotations": []}
+            clips.append(c)
+        a = next((a for a in c["annotations"] if a["annotation_uid"] == uid), None)
+        if a is None:
+            a = {"annotation_uid": uid, "language_queries": {}}
+            c["annotations"].append(a)
+        a["language_queries"][int(qidx)] = {"clip_start_sec": r["timestamps"][0], "clip_end_sec": r["timestamps"][1]}
+    for c in gt_json["videos"][0]["clips"]:
+        for a in c["annotations"]:
+            m = max(a["language_queries"])
+            a["language_queries"] = [a["language_queries"].get(i, {"clip_start_sec": 0.0, "clip_end_sec": 1.0})
+                                     for i in range(m + 1)]
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    ext = "jsonl" if preset == "mad" else "json"
+    fn = f"inference_{preset}_val_t_preds.{ext}"
+    res, miou, strs, paths = inf.eval_epoch(model, store, opt, fn, epoch_i=0, ground_truth=gt_json)
+    assert len(strs) == 4 and paths[0].endswith(".txt") and os.path.exists(paths[0])
+    txt = open(paths[0]).read()
+    assert "Fusion Epoch 0" in txt and ("Window Pre-filtering" in txt) == (preset == "ego4d")
+    sub_path = os.path.join(str(tmp_path), fn)
+    if preset == "mad":
+        sub = [json.loads(l) for l in open(sub_path).read().strip().split("\n")]
+        ref = O.evaluate_nlq_performance_mad(sub, ann, [0.1, 0.3, 0.5], [1, 5, 10, 50, 100])
+        assert torch.equal(res, ref * 100) and miou is None
+        wk = [1, 5, 10, 30, 50, 100, 200]
+    else:
+        sub = json.load(open(sub_path))["results"]
+        ref, ref_miou = O.evaluate_nlq_performance_ego4d(sub, gt_json, [0.3, 0.5], [1, 5, 10, 50, 100])
+        assert np.array_equal(res, ref * 100) and float(miou) == float(ref_miou)
+        wk = [1, 5, 10, 30, 50]
+    deep = inf.prefilter(model, store, opt, k=16).cpu().tolist()
+    ranks = {r["query_id"]: [w for w in deep[i] if w >= 0] for i, r in enumerate(ann)}
+    wref = O.windows_selection(ranks, ann, [k for k in wk if k <= 16], opt.clip_length, opt.max_v_l)
+    assert "Rank@1" in strs[0] and f"{float(wref[0]) * 100:.02f}" in strs[0]
 
 
 def test_localizer_matches_reference_golden(golden_dir):
