@@ -15,8 +15,8 @@ Data layout in HBM (one split): ``vid_raw`` (sum ctx_l, dv) clip features of all
 (``vid_off`` row offsets), ``tok`` (sum Lq, dt) text token features, ``cls`` (nq, dv).  Windows are
 (row0, len) pairs into these arenas -- nothing is padded or copied per window.
 
-Out of scope here: metric tables of standalone_eval (the val split writes the
-prediction files and skips the tables), training-time evaluation hooks.
+Scored splits (Ego4D val, MAD val / test) end with the reference's metric tables, counted on the device
+(``cone_amd.metrics``).  Out of scope here: training-time evaluation hooks.
 """
 from __future__ import annotations
 
@@ -27,6 +27,7 @@ import json
 import logging
 import os
 import time
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -132,7 +133,7 @@ class FeatureStore:
         return self._plan
 
     @classmethod
-    def from_lmdb(cls, opt):
+    def from_lmdb(cls, opt, device=None):
         """Read the reference's LMDBs of np.savez blobs (keys ``features`` / ``token_features`` +
         ``cls_features``|``eot_features``; cone/ego4d_mad_dataloader.py:263-302)."""
         try:
@@ -159,7 +160,71 @@ class FeatureStore:
                                                     ["features"]).items()}
         qf = read_all(opt.t_feat_dir, [r["query_id"] for r in ann],
                       ["token_features", "cls_features", "eot_features"])
-        return cls(opt, ann, vf, qf)
+        return cls(opt, ann, vf, qf, device=device)
+
+    # -- packed arena file: one mmap-able .bin per split instead of an LMDB of compressed npz
+    PACK_MAGIC = b"CONEFS01"
+
+    def save_packed(self, path):
+        """Write the split as ONE file: magic, header length, JSON header (annotation rows, clip ids, row
+        offsets, dims), then the three fp32 arenas at 4 KiB-aligned offsets -- exactly the device layout, so
+        loading is an mmap + one H2D copy per arena (no decompression, no per-query slicing)."""
+        arrs = dict(vid_raw=self.vid_raw.cpu().numpy(), tok_raw=self.tok_raw.cpu().numpy(),
+                    cls_raw=self.cls_raw.cpu().numpy())
+        head = dict(version=1, ann=self.ann, clip_ids=self.clip_ids, ctx_l=self.ctx_l, tok_len=self.tok_len,
+                    arrays={})
+        off = 0
+        for k, a in arrs.items():
+            head["arrays"][k] = dict(offset=off, shape=list(a.shape))
+            off += -(-a.nbytes // 4096) * 4096
+        blob = json.dumps(head).encode()
+        data0 = -(-(16 + len(blob)) // 4096) * 4096
+        with open(path, "wb") as f:
+            f.write(self.PACK_MAGIC + len(blob).to_bytes(8, "little") + blob)
+            for k, a in arrs.items():
+                f.seek(data0 + head["arrays"][k]["offset"])
+                f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+            f.truncate(data0 + off)
+        return path
+
+    @classmethod
+    def from_packed(cls, opt, path, device=None):
+        """Load a split written by save_packed (np.memmap -> device).  The annotation rows travel in the
+        header; opt.data_ratio is applied like the reference's loader (dataloader :116-121)."""
+        with open(path, "rb") as f:
+            if f.read(8) != cls.PACK_MAGIC:
+                raise ValueError(f"{path}: not a packed CONE feature store")
+            n = int.from_bytes(f.read(8), "little")
+            head = json.loads(f.read(n).decode())
+        data0 = -(-(16 + n) // 4096) * 4096
+        mm = {k: np.memmap(path, dtype=np.float32, mode="r", offset=data0 + v["offset"], shape=tuple(v["shape"]))
+              for k, v in head["arrays"].items()}
+        st = cls.__new__(cls)
+        st.opt = opt
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        st.device = dev
+        st.ann = list(head["ann"])
+        nq = len(st.ann) if opt.data_ratio == 1 else int(len(st.ann) * opt.data_ratio)
+        st.ann = st.ann[:nq]
+        st.clip_ids = list(head["clip_ids"])
+        st.clip2idx = {c: i for i, c in enumerate(st.clip_ids)}
+        st.ctx_l = [int(x) for x in head["ctx_l"]]
+        st.vid_off = np.concatenate([[0], np.cumsum(st.ctx_l)]).astype(np.int64)
+        st.tok_len = [int(x) for x in head["tok_len"]][:nq]
+        st.tok_off = np.concatenate([[0], np.cumsum(st.tok_len)]).astype(np.int64)
+        def up(a):      # read-only mapping -> device; on the CPU device take a private copy
+            if dev.type == "cpu":
+                return torch.from_numpy(np.array(a))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)        # "non-writable array": it is only read
+                return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        st.vid_raw = up(mm["vid_raw"])
+        st.tok_raw = up(mm["tok_raw"][:int(st.tok_off[-1])])
+        st.cls_raw = up(mm["cls_raw"][:nq])
+        st.q_vid = np.array([st.clip2idx[r["clip_id"]] for r in st.ann], dtype=np.int64)
+        st._plan = None
+        st._index = None
+        return st
 
 
 # ------------------------------------------------------------------------------------ stage A
@@ -497,7 +562,8 @@ def start_inference(argv=None):
                         datefmt="%Y-%m-%d %H:%M:%S", level=logging.INFO)
     opt = parse_test_options(argv)
     assert opt.eval_path is not None
-    store = FeatureStore.from_lmdb(opt)
+    packed = getattr(opt, "packed_features", None)
+    store = FeatureStore.from_packed(opt, packed) if packed else FeatureStore.from_lmdb(opt)
     model, _, _, _ = setup_model(opt)
     ext = "jsonl" if opt.dset_name == "mad" else "json"
     fn = f"inference_{opt.dset_name}_{opt.eval_split_name}_{opt.eval_id}_preds.{ext}"

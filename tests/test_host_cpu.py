@@ -106,3 +106,34 @@ def test_window_table_matches_oracle_collate():
             assert ann[int(wt["q_of"][w])]["query_id"] == m["query_id"]
             w += 1
     assert w == wt["vid_len"].shape[0]
+
+
+def test_packed_feature_store_round_trip(tmp_path):
+    """one mmap-able arena file per split; loading reproduces the store bit for bit
+    (CPU device: building a store involves no kernel)."""
+    import numpy as np
+    import torch
+    from cone_amd import synth
+    from cone_amd.config import make_opt
+    from cone_amd.inference import FeatureStore
+    opt = make_opt("ego4d")
+    ann, vf, qf = synth.make_dataset(opt, 13, 3, seed=4, ctx_range=(50, 120))
+    cpu = torch.device("cpu")
+    a = FeatureStore(opt, ann, vf, qf, device=cpu)
+    path = a.save_packed(str(tmp_path / "split.conefs"))
+    b = FeatureStore.from_packed(opt, path, device=cpu)
+    assert b.ann == a.ann and b.clip_ids == a.clip_ids and b.ctx_l == a.ctx_l and b.tok_len == a.tok_len
+    for k in ("vid_raw", "tok_raw", "cls_raw"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert np.array_equal(a.vid_off, b.vid_off) and np.array_equal(a.tok_off, b.tok_off)
+    assert np.array_equal(a.q_vid, b.q_vid)
+    # data_ratio keeps a prefix of the queries like the reference's loader
+    half = FeatureStore.from_packed(make_opt("ego4d", data_ratio=0.5), path, device=cpu)
+    assert len(half.ann) == 6 and half.tok_raw.shape[0] == sum(a.tok_len[:6]) and half.cls_raw.shape[0] == 6
+    with open(path, "rb") as f:
+        assert f.read(8) == b"CONEFS01"
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"not a store")
+    import pytest
+    with pytest.raises(ValueError):
+        FeatureStore.from_packed(opt, str(bad), device=cpu)
