@@ -51,25 +51,29 @@ __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restric
     }
 }
 
+// One wave per window: coalesced reads of its <= W frame scores, wave max (exact, order-free).
 __global__ __launch_bounds__(256) void window_max_kernel(const float* __restrict__ fs, int64_t ctx_l, int W,
                                                          int S, int64_t num_window, float* __restrict__ win) {
-    const int q = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= num_window) return;
     const int64_t s = max((i - 1) * S, (int64_t)0);
     const int64_t e = min((i - 1) * S + W, ctx_l);
     const float* f = fs + (size_t)q * ctx_l;
     float m = -INFINITY;
-    for (int64_t t = s; t < e; ++t) m = fmaxf(m, f[t]);
-    win[(size_t)q * num_window + i] = m;
+    for (int64_t t = s + lane; t < e; t += 64) m = fmaxf(m, f[t]);
+    m = wave_max(m);
+    if (lane == 0) win[(size_t)q * num_window + i] = m;
 }
 
 // Stable descending top-k: pass p picks the largest (score, then lowest index) strictly after the
 // previous pick in that order.  One workgroup per score row.
-__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sc, int64_t n, int k,
-                                                   int32_t* __restrict__ idx, float* __restrict__ val) {
-    __shared__ float s_v[4];
-    __shared__ int s_i[4];
+template <int NT>
+__global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ sc, int64_t n, int k,
+                                                  int32_t* __restrict__ idx, float* __restrict__ val) {
+    constexpr int NW = NT / 64;
+    __shared__ float s_v[NW];
+    __shared__ int s_i[NW];
     __shared__ float best_v;
     __shared__ int best_i;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,10 +83,20 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sc,
     for (int p = 0; p < k; ++p) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int64_t j = tid; j < n; j += 256) {
-            const float v = row[j];
-            const bool after = (v < last_v) || (v == last_v && (int)j > last_i);
-            if (after && (v > bv || (v == bv && (int)j < bi))) { bv = v; bi = (int)j; }
+        // 4 independent loads in flight per thread: a pass over a 100k-window row is latency-, not bandwidth-bound
+        for (int64_t j0 = tid; j0 < n; j0 += 4 * NT) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + (int64_t)u * NT;
+                v[u] = j < n ? row[j] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + (int64_t)u * NT;
+                const bool after = (v[u] < last_v) || (v[u] == last_v && (int)j > last_i);
+                if (j < n && after && (v[u] > bv || (v[u] == bv && (int)j < bi))) { bv = v[u]; bi = (int)j; }
+            }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sc,
         if (tid == 0) {
             float v = s_v[0];
             int i = s_i[0];
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
             best_v = v; best_i = i;
             idx[(size_t)q * k + p] = i == 0x7fffffff ? -1 : i;
@@ -275,7 +289,7 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
         rc = cone::launch_gemm(g, s);
         if (rc) return rc;
         const int64_t nwg = (ctx_l + S - 1) / S + 1;
-        hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nwg + 255) / 256), nq), dim3(256), 0, s,
+        hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nwg + 3) / 4), nq), dim3(256), 0, s,
                            frame_scores, ctx_l, W, S, nwg, win_scores);
         CONE_LAUNCH_CHECK();
         return 0;
@@ -288,7 +302,7 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
     }
     if (rc) return rc;
     const int64_t nw = (ctx_l + S - 1) / S + 1;
-    hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nw + 255) / 256), nq), dim3(256), 0, s,
+    hipLaunchKernelGGL(cone::window_max_kernel, dim3((unsigned)((nw + 3) / 4), nq), dim3(256), 0, s,
                        frame_scores, ctx_l, W, S, nw, win_scores);
     CONE_LAUNCH_CHECK();
     return 0;
@@ -332,8 +346,12 @@ extern "C" int cone_topk_windows(const float* win_scores, int nq, int64_t num_wi
                                  float* val, void* stream) {
     CONE_REQUIRE(nq > 0 && num_window > 0 && k > 0 && k <= num_window && num_window < 0x7fffffff,
                  "topk: bad sizes nq=%d num_window=%lld k=%d", nq, (long long)num_window, k);
-    hipLaunchKernelGGL(cone::topk_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, win_scores, num_window, k,
-                       idx, val);
+    if (num_window > 4096)      // long video (MAD scale): 16 waves per row
+        hipLaunchKernelGGL(cone::topk_kernel<1024>, dim3(nq), dim3(1024), 0, (hipStream_t)stream, win_scores,
+                           num_window, k, idx, val);
+    else
+        hipLaunchKernelGGL(cone::topk_kernel<256>, dim3(nq), dim3(256), 0, (hipStream_t)stream, win_scores,
+                           num_window, k, idx, val);
     CONE_LAUNCH_CHECK();
     return 0;
 }
