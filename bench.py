@@ -173,14 +173,14 @@ def main():
     def step():
         dp = inf.device_pipeline(model, store, opt)
         rows, n = dp["rows"], dp["n"]
-        if use_dist:    # the one exchange step: kept rows of every shard -> rank 0 (all_gather over RCCL)
+        if use_dist:    # the one exchange step: kept rows of every shard on every rank (all_gather over RCCL,
+            # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors
             rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
             n_all = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
             dist.all_gather_into_tensor(rows_all, rows.contiguous())
             dist.all_gather_into_tensor(n_all, n.contiguous())
-            if rank == 0:
-                return [inf.format_results(ann, opt, rows_all[r], n_all[r]) for r in range(world)], dp
-            return None, dp
+            dp["rows_all"], dp["n_all"] = rows_all, n_all
+        # every rank builds the submission rows of ITS OWN shard (the host work shards with the queries)
         return [inf.format_results(ann, opt, rows, n)], dp
 
     def fence():

@@ -246,9 +246,19 @@ def window_table(store: FeatureStore, opt, win_idx):
     dev = store.device
     nq, K = win_idx.shape
     W, S = opt.max_v_l, int(opt.max_v_l / 2)
-    q_of, slot = (win_idx >= 0).nonzero(as_tuple=True)       # row-major; the one host sync of the table
-    wi = win_idx[q_of, slot].to(torch.int64)
     st = store.index_tensors()
+    if min(store.ctx_l) > (K - 2) * S:
+        # every video has at least K windows (ceil(ctx_l/S)+1 >= K): the table is dense, its row order is known
+        # without looking at win_idx -- no host sync, the launch queue runs ahead of the GPU
+        dense = st.get(("dense", K))
+        if dense is None:
+            ar = torch.arange(nq * K, device=dev)
+            dense = st[("dense", K)] = (ar // K, ar % K)
+        q_of, slot = dense
+        wi = win_idx.reshape(-1).to(torch.int64)
+    else:
+        q_of, slot = (win_idx >= 0).nonzero(as_tuple=True)   # row-major; the one host sync of the table
+        wi = win_idx[q_of, slot].to(torch.int64)
     ctx_l = st["q_ctx_l"][q_of]
     voff = st["q_vid_off"][q_of]
     start = torch.clamp((wi - 1) * S, min=0)
