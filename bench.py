@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--videos", type=int, default=50)
+    ap.add_argument("--pipeline_chunks", type=int, default=None,
+                    help="query chunks of the host/GPU software pipeline (default: automatic = 1 at this size)")
     ap.add_argument("--window_batch", type=int, default=32768)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_queries", type=int, default=400)
@@ -162,7 +164,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
-                   window_batch=args.window_batch)
+                   window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks)
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -171,17 +173,18 @@ def main():
     lib = _lib.load()
 
     def step():
-        dp = inf.device_pipeline(model, store, opt)
-        rows, n = dp["rows"], dp["n"]
+        # the product's own driver (cone_amd.inference.predict_split): stages A->C + the submission rows
+        out, dp = inf.predict_split(model, store, opt)
         if use_dist:    # the one exchange step: kept rows of every shard on every rank (all_gather over RCCL,
-            # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors
+            # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors; every rank has
+            # built the submission rows of ITS OWN shard (the host work shards with the queries)
+            rows, n = dp["rows"], dp["n"]
             rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
             n_all = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
             dist.all_gather_into_tensor(rows_all, rows.contiguous())
             dist.all_gather_into_tensor(n_all, n.contiguous())
             dp["rows_all"], dp["n_all"] = rows_all, n_all
-        # every rank builds the submission rows of ITS OWN shard (the host work shards with the queries)
-        return [inf.format_results(ann, opt, rows, n)], dp
+        return [out], dp
 
     def fence():
         torch.cuda.synchronize()

@@ -473,13 +473,53 @@ def _format_results(ann, opt, rows, n):
 
 
 @torch.no_grad()
+def query_chunks(nq: int, opt):
+    """Query ranges for the software pipeline of predict_split: a few chunks, cut at multiples of eval_bsz so
+    that every reference batch (and with it the padded length of hazard H3) stays inside one chunk."""
+    want = getattr(opt, "pipeline_chunks", None)
+    if want is None:
+        # measured on MI355X (config 2, 20 000 windows): 1 chunk 68.0 ms, 2 chunks 71.0, 4 chunks 77.8 -- the tall
+        # GEMMs lose more to shorter launches than the overlap of the host's list building wins back; pipeline only
+        # splits that are several window batches long anyway
+        want = (nq * opt.topk_window) // (2 * int(getattr(opt, "window_batch", 32768)))
+    nb = -(-nq // opt.eval_bsz)
+    want = max(1, min(int(want), nb))
+    cuts = sorted({min(nq, (-(-nb * i // want)) * opt.eval_bsz) for i in range(want + 1)})
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
 def predict_split(model, store: FeatureStore, opt):
-    """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info."""
+    """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info.
+
+    The queries run as a short software pipeline: all chunks are enqueued on the stream back to back (nothing in
+    device_pipeline synchronises when the window table is dense), their kept rows are copied to pinned host
+    memory behind an event each, and the host builds the submission rows of chunk i while the GPU is still
+    working on chunk i+1.  Results are identical to one big batch (rows of a GEMM are independent)."""
     t0 = time.time()
-    dp = device_pipeline(model, store, opt)
-    torch.cuda.synchronize()
-    dp["model_seconds"] = time.time() - t0
-    return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
+    chunks = query_chunks(len(store.ann), opt)
+    if len(chunks) == 1:
+        dp = device_pipeline(model, store, opt)
+        torch.cuda.synchronize()
+        dp["model_seconds"] = time.time() - t0
+        return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
+    pend = []
+    for lo, hi in chunks:
+        sub = FeatureStore.subset(store, lo, hi)
+        dp = device_pipeline(model, sub, opt)
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
+                for t in (dp["rows"], dp["n"])]
+        ev = torch.cuda.Event()
+        ev.record()
+        pend.append((sub, dp, host, ev))
+    outs = ([], [], [])
+    for sub, dp, host, ev in pend:
+        ev.synchronize()
+        for dst, part in zip(outs, format_results(sub.ann, opt, host[0], host[1])):
+            dst.extend(part)
+    model_seconds = time.time() - t0
+    info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
+                n_windows=sum(p[1]["n_windows"] for p in pend), model_seconds=model_seconds, chunks=chunks)
+    return outs, info
 
 
 EGO4D_VAL_GT = "data/ego4d_ori_data/nlq_val.json"      # hard-coded by the reference, cone/inference.py:420

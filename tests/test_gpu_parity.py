@@ -700,6 +700,27 @@ def test_val_split_ends_with_metric_tables(preset, tmp_path):
     assert "Rank@1" in strs[0] and f"{float(wref[0]) * 100:.02f}" in strs[0]
 
 
+def test_predict_split_pipeline_is_chunk_invariant():
+    """The host/GPU software pipeline of predict_split (query chunks cut at multiples of eval_bsz) returns the
+    same submission lists, bit for bit, as one big batch -- also with ragged tails and sparse window tables."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 0)
+    for ctx_range, nq in (((300, 500), 41), ((60, 200), 23)):      # dense table / some videos with < topk windows
+        outs = []
+        for chunks in (1, 2, 5):
+            opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=4,
+                           pipeline_chunks=chunks)
+            ann, vf, qf = synth.make_dataset(opt, nq, 4, seed=2, ctx_range=ctx_range)
+            store = inf.FeatureStore(opt, ann, vf, qf)
+            lists, info = inf.predict_split(model, store, opt)
+            assert info["n_windows"] > 0 and info["rows"].shape[1] == nq
+            outs.append(lists)
+        assert outs[0] == outs[1] == outs[2]
+        assert len(inf.query_chunks(nq, opt)) == 5
+    auto = make_opt("ego4d", topk_window=20, eval_bsz=32)
+    assert len(inf.query_chunks(1000, auto)) == 1 and len(inf.query_chunks(20000, auto)) == 6
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator
