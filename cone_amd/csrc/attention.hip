@@ -112,10 +112,14 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
         for (int kb = 0; kb < NKB; ++kb)
             if (kb < nkb) {
                 const float* vp = Vs + (kb * 32 + 4 * lh) * 32 + li;
+                // k-step t covers keys (t&3)+8(t>>2) (+4 on the upper half-wave): past the window's last key the
+                // probabilities are exactly 0, so the ragged last block stops early (uniform branch)
+                const int rem = L - kb * 32;
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kb][t] * inv, vp[((t & 3) + 8 * (t >> 2)) * 32], o,
-                                                             0, 0, 0);
+                    if ((t & 3) + 8 * (t >> 2) < rem)
+                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kb][t] * inv, vp[((t & 3) + 8 * (t >> 2)) * 32],
+                                                                 o, 0, 0, 0);
             }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
