@@ -10,9 +10,9 @@
 // window model's FLOPs) are replaced by 4 small per-window stages, all VALU + LDS (no padding waste: 40 pairs
 // and ~101 keys do not fill 32x32 MFMA tiles well):
 //   0. qk_p for the 40 pairs            (thread = column c, W_k read coalesced)
-//   A. scores: lane = key, wave = 10 pairs; mem+pos rows staged through LDS in 32-column chunks
+//   A. scores: lane = key, wave = 5 pairs; mem+pos rows staged through LDS in 32-column chunks
 //   B. softmax per pair (all keys of a pair live in one wave)
-//   C. ctx_p = sum_j P[p][j] mem_j      (lane = 4 columns, wave = 10 pairs, mem rows read coalesced)
+//   C. ctx_p = sum_j P[p][j] mem_j      (lane = 4 columns, wave = 5 pairs, mem rows read coalesced)
 //   D. out = W_v,h ctx_p + b_v          (thread = output column, W_v^T read coalesced)
 // Results equal the unfused path up to fp32 re-association (~1e-6 relative).
 #include "common.h"
@@ -49,9 +49,10 @@ __device__ __forceinline__ float wmax(float v) {
 template <int NQ, int NKL>
 struct DecCrossCfg {
     static constexpr int NP = 8 * NQ;                 // (slot, head) pairs of one window
-    static constexpr int PPW = 2 * NQ;                // pairs per wave
+    static constexpr int NT = 512, NWV = NT / 64;     // 8 waves: 16 per CU at two workgroups (latency hiding)
+    static constexpr int PPW = NP / NWV;              // pairs per wave
     static constexpr int PPWP = (PPW + 3) / 4 * 4;    //   padded to whole float4s in the P image
-    static constexpr int NPP = 4 * PPWP;
+    static constexpr int NPP = NWV * PPWP;
     static constexpr int KP = 64 * NKL;               // key capacity
     static constexpr int TILE_LD = 36;                // 32 columns + 4 pad: conflict-free ds_read_b128 per key
     static constexpr int UNION = KP * (NPP > TILE_LD ? NPP : TILE_LD);
@@ -59,7 +60,7 @@ struct DecCrossCfg {
 };
 
 template <int NQ, int NKL>
-__global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restrict__ DQ,
+__global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restrict__ DQ,
                                                            const float* __restrict__ XP,
                                                            const float* __restrict__ X,
                                                            const int* __restrict__ off,
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- q * sqrt(1/32) into LDS as [pair = s*8+h][32]
-    for (int i = tid; i < NQ * 256; i += 256) {
+    static_assert(C::NP % C::NWV == 0, "pairs must split evenly over the waves");
+    for (int i = tid; i < NQ * 256; i += C::NT) {
         const int s = i >> 8, o = i & 255;
         qs[(s * 8 + (o >> 5)) * 32 + (o & 31)] = DQ[(size_t)(b * NQ + s) * 256 + o] * 0.17677669529663687f;
     }
@@ -86,13 +88,14 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
 
     // ---- stage 0: qkf[p][c] = sum_d qs[p][d] * Wk[h*32+d][c], thread = column c.  Packed fp32 FMAs
     // (v_pk_fma_f32): even / odd d accumulate in the two halves, summed at the end.
-    for (int h = 0; h < 8; ++h) {
+    const int col = tid & 255, half = tid >> 8;          // two thread groups split the heads (stage 0) / slots (D)
+    for (int h = 4 * half; h < 4 * half + 4; ++h) {
         f2v a[NQ];
 #pragma unroll
         for (int s = 0; s < NQ; ++s) a[s] = f2v{0.f, 0.f};
-        const float* wcol = Wk + (size_t)h * 32 * 256 + tid;
-#pragma unroll
-        for (int d4 = 0; d4 < 8; ++d4) {      // 32 W_k loads in flight per thread: this stage is L2-latency bound
+        const float* wcol = Wk + (size_t)h * 32 * 256 + col;
+#pragma unroll 4
+        for (int d4 = 0; d4 < 8; ++d4) {      // 16 W_k loads in flight per thread: this stage is L2-latency bound
             const f2v w01 = {wcol[(d4 * 4 + 0) * 256], wcol[(d4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(d4 * 4 + 2) * 256], wcol[(d4 * 4 + 3) * 256]};
 #pragma unroll
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
             }
         }
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) qkf[(s * 8 + h) * 256 + tid] = a[s].x + a[s].y;
+        for (int s = 0; s < NQ; ++s) qkf[(s * 8 + h) * 256 + col] = a[s].x + a[s].y;
     }
 
     // ---- stage A: scores.  lane = key (NKL keys per lane), wave = PPW pairs.
@@ -112,18 +115,18 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
     for (int kk = 0; kk < NKL; ++kk)
 #pragma unroll
         for (int pp = 0; pp < C::PPW; ++pp) sc2[kk][pp] = f2v{0.f, 0.f};
-    constexpr int TPASS = C::KP / 32;                       // staging passes: 32 key rows per pass
+    constexpr int TPASS = C::KP / 64;                       // staging passes: 64 key rows per pass
     f4v pf[TPASS];
     const int srow = tid >> 3, spart = tid & 7;
 #define DC_FETCH(ch_)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < TPASS; ++i) {                                                     \
-        int r = srow + 32 * i;                                                                              \
+        int r = srow + 64 * i;                                                                              \
         r = r < L ? r : L - 1;                                                                              \
         pf[i] = *reinterpret_cast<const f4v*>(XP + (size_t)(t0 + r) * 256 + (ch_) * 32 + spart * 4);     \
     }
 #define DC_STASH()                                                                                          \
     _Pragma("unroll") for (int i = 0; i < TPASS; ++i)                                                       \
-        *reinterpret_cast<f4v*>(tile + (srow + 32 * i) * C::TILE_LD + spart * 4) = pf[i];
+        *reinterpret_cast<f4v*>(tile + (srow + 64 * i) * C::TILE_LD + spart * 4) = pf[i];
     DC_FETCH(0)
     DC_STASH()
     __syncthreads();                                        // tile(0) and qkf complete
@@ -218,27 +221,32 @@ __global__ __launch_bounds__(256, 2) void dec_cross_kernel(const float* __restri
         *reinterpret_cast<f4v*>(ctxs + (wave * C::PPW + pp) * 256 + lane * 4) = ctx[pp];
     __syncthreads();
 
-    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o
+    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o; the two
+    // thread groups take slots [0, NQ/2] and (NQ/2, NQ)
     {
-        f2v o[NQ];
+        constexpr int S0 = (NQ + 1) / 2;
+        f2v o[S0];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) o[s] = f2v{0.f, 0.f};
-        const int h = tid >> 5;
-        const float* wcol = WvT + tid;
+        for (int s = 0; s < S0; ++s) o[s] = f2v{0.f, 0.f};
+        const int h = col >> 5;
+        const int sbase = half * S0;
+        const float* wcol = WvT + col;
 #pragma unroll 8
         for (int c4 = 0; c4 < 64; ++c4) {
             const f2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
 #pragma unroll
-            for (int s = 0; s < NQ; ++s) {
-                const f4v cx = *reinterpret_cast<const f4v*>(ctxs + (s * 8 + h) * 256 + c4 * 4);
+            for (int s = 0; s < S0; ++s) {
+                const int sl = min(sbase + s, NQ - 1);
+                const f4v cx = *reinterpret_cast<const f4v*>(ctxs + (sl * 8 + h) * 256 + c4 * 4);
                 o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
                 o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
             }
         }
-        const float bias = bv[tid];
+        const float bias = bv[col];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) OUT[(size_t)(b * NQ + s) * 256 + tid] = (o[s].x + o[s].y) + bias;
+        for (int s = 0; s < S0; ++s)
+            if (sbase + s < NQ) OUT[(size_t)(b * NQ + sbase + s) * 256 + col] = (o[s].x + o[s].y) + bias;
     }
 }
 
@@ -252,7 +260,7 @@ static int launch_one(const float* DQ, const float* XP, const float* X, const in
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4));
         attr = true;
     }
-    hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL>), dim3(B), dim3(256), C::LDS_FLOATS * 4, s, DQ, XP, X, off, Wk, WvT,
+    hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL>), dim3(B), dim3(C::NT), C::LDS_FLOATS * 4, s, DQ, XP, X, off, Wk, WvT,
                        bv, OUT);
     CONE_LAUNCH_CHECK();
     return 0;
