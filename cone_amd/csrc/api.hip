@@ -244,6 +244,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 
 // ------------------------------------------------------------------------------ packed forward
 static int g_dec_fold = 1;   // test hook (cone_test_set_option "dec_fold"): 0 = separate K/V GEMMs + small_attn
+static int g_l0_gather = 1;  // test hook ("l0_gather"): 0 = pack_l0 writes q|k|v to HBM for the plain attention kernel
 
 struct FwdBuffers {
     int* off;
@@ -290,8 +291,10 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     if (l0) {
         CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
                      "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
+        // X and POS only: the first layer's attention gathers q|k|v from the caches itself (g_l0_gather, default)
         RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, l0->qkv_vid, l0->qkv_txt,
-                           l0->pos_qk, f.X, f.POS, f.QK, f.V, B, Lmax, s));
+                           l0->pos_qk, f.X, f.POS, g_l0_gather ? nullptr : f.QK, g_l0_gather ? nullptr : f.V, B, Lmax,
+                           s));
     } else {
         RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
     }
@@ -304,7 +307,10 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             RUN(launch_gemm(g, s));                                                         // q | k = (x+pos) W^T
             RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
         }
-        RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
+        if (l == 0 && l0 && g_l0_gather)
+            RUN(launch_enc_attn_l0(l0->qkv_vid, l0->qkv_txt, l0->pos_qk, vrow0, vlen, trow0, f.ATT, f.off, B, Lmax, s));
+        else
+            RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
         g = G(f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.X; g.ldr = 256; g.ln_g = e.n1.g; g.ln_b = e.n1.b;
         RUN(launch_gemm(g, s));                                                             // norm1(x + attn)
@@ -561,6 +567,7 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
 extern "C" int cone_test_set_option(const char* name, int value) {
     CONE_REQUIRE(name, "set_option: null name");
     if (!strcmp(name, "dec_fold")) { cone::g_dec_fold = value != 0; return 0; }
+    if (!strcmp(name, "l0_gather")) { cone::g_l0_gather = value != 0; return 0; }
     cone::set_error("set_option: unknown option '%s'", name);
     return CONE_E_INVALID;
 }

@@ -21,11 +21,24 @@ namespace cone {
 
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
 
-template <int NKB>
+// GATHER = true (first encoder layer with the layer-0 cache): q|k|v of a token are not read from packed (M, .)
+// matrices but straight from the per-clip / per-token projection caches, q and k of a clip plus the static
+// pos.W_qk^T row of its (window length, position) -- the gather that pack_l0_kernel would otherwise write out
+// to HBM (6 KB per token written and read back) happens in the staging loads.  Same adds, same results.
+struct L0Gather {
+    const float* qkv_vid;   // (n_clips, 768)  q | k | v
+    const float* qkv_txt;   // (n_tokens, 768)
+    const float* pos_qk;    // (W(W+1)/2, 512) row lv(lv-1)/2 + p
+    const int* vrow0;
+    const int* vlen;
+    const int* trow0;
+};
+
+template <int NKB, bool GATHER>
 __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
                                                        const float* __restrict__ V,   // (M,256)
                                                        float* __restrict__ OUT,       // (M,256)
-                                                       const int* __restrict__ off) {
+                                                       const int* __restrict__ off, L0Gather g) {
     __shared__ float Ks[NKB * 32 * 33];
     __shared__ __attribute__((aligned(16))) float Vs[NKB * 32 * 32];
     const int b = blockIdx.x, head = blockIdx.y;
@@ -34,14 +47,36 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
     const int nkb = (L + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
+    if (GATHER) { lv = g.vlen[b]; vr0 = g.vrow0[b]; tr0 = g.trow0[b]; pbase = lv * (lv - 1) / 2; }
+    // source row of token `tok` for column block `col` (0 = q, 256 = k, 512 = v) + its additive pos row (or null)
+    auto src_of = [&](int tok, int col, const float*& add) -> const float* {
+        if (tok < lv) {
+            add = col < 512 ? g.pos_qk + (size_t)(pbase + tok) * 512 + col : nullptr;
+            return g.qkv_vid + (size_t)(vr0 + tok) * 768 + col;
+        }
+        add = nullptr;
+        return g.qkv_txt + (size_t)(tr0 + tok - lv) * 768 + col;
+    };
 
     {   // stage K (transposing scalar writes, stride 33) and V (float4) for all keys of the window
         const int kr = tid >> 3, c = tid & 7;
         for (int key = kr; key < nkb * 32; key += 32) {
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (key < L) {
-                kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
-                vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
+                if (GATHER) {
+                    const float* add;
+                    const float* kp_ = src_of(key, 256, add);
+                    kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
+                    vv = *reinterpret_cast<const float4*>(kp_ + 256 + head * 32 + c * 4);
+                    if (add) {
+                        const float4 t = *reinterpret_cast<const float4*>(add + head * 32 + c * 4);
+                        kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
+                    }
+                } else {
+                    kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
+                    vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
+                }
             }
             float* kd = Ks + key * 33 + c * 4;
             kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
@@ -56,10 +91,16 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
         {
             int qrow = qb * 32 + li;
             qrow = qrow < L ? qrow : L - 1;
-            const float* qp = QK + (size_t)(t0 + qrow) * 512 + head * 32 + 16 * lh;
+            const float* qadd = nullptr;
+            const float* qp = GATHER ? src_of(qrow, 0, qadd) + head * 32 + 16 * lh
+                                     : QK + (size_t)(t0 + qrow) * 512 + head * 32 + 16 * lh;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 x = reinterpret_cast<const float4*>(qp)[u];
+                float4 x = reinterpret_cast<const float4*>(qp)[u];
+                if (GATHER && qadd) {
+                    const float4 t = reinterpret_cast<const float4*>(qadd + head * 32 + 16 * lh)[u];
+                    x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+                }
                 qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
                 qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
             }
@@ -129,18 +170,31 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
     }
 }
 
-int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
-                    hipStream_t s) {
+template <bool GATHER>
+static int launch_enc_attn_t(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
+                             const L0Gather& g, hipStream_t s) {
     CONE_REQUIRE(Lmax >= 1 && Lmax <= 192, "enc attention: window length %d not in [1,192]", Lmax);
     if (B <= 0) return 0;
     dim3 grid(B, 8), block(256);
     const int nkb = (Lmax + 31) / 32;
-    ProfScope ps(PK_ENC_ATTN, B, Lmax, 0, nullptr, s);
-    if (nkb <= 4) hipLaunchKernelGGL(enc_attn_kernel<4>, grid, block, 0, s, QK, V, OUT, off);
-    else if (nkb == 5) hipLaunchKernelGGL(enc_attn_kernel<5>, grid, block, 0, s, QK, V, OUT, off);
-    else hipLaunchKernelGGL(enc_attn_kernel<6>, grid, block, 0, s, QK, V, OUT, off);
+    ProfScope ps(PK_ENC_ATTN, B, Lmax, GATHER, nullptr, s);
+    if (nkb <= 4) hipLaunchKernelGGL((enc_attn_kernel<4, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
+    else if (nkb == 5) hipLaunchKernelGGL((enc_attn_kernel<5, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
+    else hipLaunchKernelGGL((enc_attn_kernel<6, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
     CONE_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
+                    hipStream_t s) {
+    return launch_enc_attn_t<false>(QK, V, OUT, off, B, Lmax, L0Gather{}, s);
+}
+
+int launch_enc_attn_l0(const float* qkv_vid, const float* qkv_txt, const float* pos_qk, const int* vrow0,
+                       const int* vlen, const int* trow0, float* OUT, const int* off, int B, int Lmax,
+                       hipStream_t s) {
+    return launch_enc_attn_t<true>(nullptr, nullptr, OUT, off, B, Lmax,
+                                   L0Gather{qkv_vid, qkv_txt, pos_qk, vrow0, vlen, trow0}, s);
 }
 
 // Decoder attentions: NQ (<= 8) query slots per window, one wavefront per (window, head).

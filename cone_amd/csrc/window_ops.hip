@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ 
     const int lv = vlen[b], lq = qlen[b];
     if (p >= lv + lq) return;
     const size_t row = (size_t)(off[b] + p);
-    float4 x, ps, q0, q1, vv;
+    float4 x, ps, q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, vv = q0;
     if (p < lv) {
         const size_t src = (size_t)(vrow0[b] + p);
         x = reinterpret_cast<const float4*>(vproj + src * 256)[lane];
@@ -132,24 +132,30 @@ __global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ 
         const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
         ps.x = sinf(__fdiv_rn(xe, dt.x)); ps.y = cosf(__fdiv_rn(xe, dt.y));
         ps.z = sinf(__fdiv_rn(xe, dt.z)); ps.w = cosf(__fdiv_rn(xe, dt.w));
-        const float4* qs = reinterpret_cast<const float4*>(qkv_vid + src * 768);
-        const float4* pq = reinterpret_cast<const float4*>(pos_qk + (size_t)(lv * (lv - 1) / 2 + p) * 512);
-        const float4 a0 = qs[lane], a1 = qs[64 + lane], t0 = pq[lane], t1 = pq[64 + lane];
-        q0 = make_float4(a0.x + t0.x, a0.y + t0.y, a0.z + t0.z, a0.w + t0.w);
-        q1 = make_float4(a1.x + t1.x, a1.y + t1.y, a1.z + t1.z, a1.w + t1.w);
-        vv = qs[128 + lane];
+        if (QK) {
+            const float4* qs = reinterpret_cast<const float4*>(qkv_vid + src * 768);
+            const float4* pq = reinterpret_cast<const float4*>(pos_qk + (size_t)(lv * (lv - 1) / 2 + p) * 512);
+            const float4 a0 = qs[lane], a1 = qs[64 + lane], t0 = pq[lane], t1 = pq[64 + lane];
+            q0 = make_float4(a0.x + t0.x, a0.y + t0.y, a0.z + t0.z, a0.w + t0.w);
+            q1 = make_float4(a1.x + t1.x, a1.y + t1.y, a1.z + t1.z, a1.w + t1.w);
+            vv = qs[128 + lane];
+        }
     } else {
         const size_t src = (size_t)(trow0[b] + p - lv);
         x = reinterpret_cast<const float4*>(tproj + src * 256)[lane];
         ps = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4* qs = reinterpret_cast<const float4*>(qkv_txt + src * 768);
-        q0 = qs[lane]; q1 = qs[64 + lane]; vv = qs[128 + lane];
+        if (QK) {
+            const float4* qs = reinterpret_cast<const float4*>(qkv_txt + src * 768);
+            q0 = qs[lane]; q1 = qs[64 + lane]; vv = qs[128 + lane];
+        }
     }
     reinterpret_cast<float4*>(X + row * 256)[lane] = x;
     reinterpret_cast<float4*>(POS + row * 256)[lane] = ps;
-    reinterpret_cast<float4*>(QK + row * 512)[lane] = q0;
-    reinterpret_cast<float4*>(QK + row * 512)[64 + lane] = q1;
-    reinterpret_cast<float4*>(V + row * 256)[lane] = vv;
+    if (QK) {       // null: the attention kernel gathers q|k|v itself (launch_enc_attn_l0)
+        reinterpret_cast<float4*>(QK + row * 512)[lane] = q0;
+        reinterpret_cast<float4*>(QK + row * 512)[64 + lane] = q1;
+        reinterpret_cast<float4*>(V + row * 256)[lane] = vv;
+    }
 }
 
 int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,

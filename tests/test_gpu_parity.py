@@ -508,6 +508,20 @@ def test_layer0_gather_cache_equals_gemm_path():
         outs.append(inf.run_windows(model, store, opt, wt))
     for k in ("pred_logits", "pred_spans"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < TOL, k     # measured ~3e-5 on logits of magnitude 10
+    # the in-kernel gather of the first layer's q|k|v is the same arithmetic as the packing kernel: bit-identical
+    from cone_amd import _lib
+    lib = _lib.load()
+    try:
+        _lib.check(lib.cone_test_set_option(b"l0_gather", 0))
+        opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8, layer0_cache=True)
+        ann, vf, qf = synth.make_dataset(opt, 17, 3, seed=5, ctx_range=(60, 300))
+        store = inf.FeatureStore(opt, ann, vf, qf)
+        wt = inf.window_table(store, opt, inf.prefilter(model, store, opt))
+        packed = inf.run_windows(model, store, opt, wt)
+    finally:
+        _lib.check(lib.cone_test_set_option(b"l0_gather", 1))
+    for k in ("pred_logits", "pred_spans", "matching"):
+        assert torch.equal(outs[0][k], packed[k]), k
 
 
 @pytest.mark.parametrize("preset", ["ego4d", "mad"])
