@@ -331,8 +331,13 @@ def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
 # ------------------------------------------------------------------------------------ stage C
 def _rows_to_lists(rows, n):
     """(3, nq, max_after, 5) fp64 + counts -> [fused, proposal, matching][query] -> list of rows."""
-    rows, n = rows.cpu().tolist(), n.cpu().tolist()
-    return [[rows[t][q][:n[t][q]] for q in range(len(n[t]))] for t in range(3)]
+    A = rows.shape[2]
+    n = n.cpu()
+    rows = rows.cpu().tolist()
+    if int(n.min()) == A:                   # every query kept max_after rows (the common case): nothing to trim
+        return rows
+    n = n.tolist()
+    return [[r[:k] for r, k in zip(rows[t], n[t])] for t in range(3)]
 
 
 def fuse_and_nms(cand, n_valid, opt):
@@ -456,23 +461,18 @@ def format_results(ann, opt, rows, n):
 
 def _format_results(ann, opt, rows, n):
     lists = _rows_to_lists(rows, n)
-    outs = []
-    for t in range(3):
-        lst = []
-        for qi, meta in enumerate(ann):
-            if opt.dset_name == "ego4d":
-                parts = meta["query_id"].split("_")
-                assert len(parts) == 2
-                o = {"query_idx": int(parts[1]), "annotation_uid": parts[0], "predicted_times": lists[t][qi],
-                     "clip_uid": meta["clip_id"]}
-            else:
-                o = {"query_id": meta["query_id"], "predicted_times": lists[t][qi], "video_id": meta["video_id"]}
-            lst.append(o)
-        outs.append(lst)
-    return tuple(outs)
+    if opt.dset_name == "ego4d":
+        keys = []
+        for meta in ann:                                            # cone/inference.py:133-140
+            parts = meta["query_id"].split("_")
+            assert len(parts) == 2
+            keys.append((int(parts[1]), parts[0], meta["clip_id"]))
+        return tuple([{"query_idx": k[0], "annotation_uid": k[1], "predicted_times": pt, "clip_uid": k[2]}
+                      for k, pt in zip(keys, lists[t])] for t in range(3))
+    return tuple([{"query_id": m["query_id"], "predicted_times": pt, "video_id": m["video_id"]}
+                  for m, pt in zip(ann, lists[t])] for t in range(3))
 
 
-@torch.no_grad()
 def query_chunks(nq: int, opt):
     """Query ranges for the software pipeline of predict_split: a few chunks, cut at multiples of eval_bsz so
     that every reference batch (and with it the padded length of hazard H3) stays inside one chunk."""
