@@ -404,15 +404,18 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
         be4 = *reinterpret_cast<const float4*>(p.ln_b + c4);
     }
     const int rows_here = min(32, M - mrow0);   // wave-uniform, may be <= 0 for a wave past M
+    __syncthreads();                            // every wave is done reading the last slab: LDS is reusable
 #pragma unroll
     for (int g = 0; g < 4; ++g) {               // rows 8g .. 8g+7 of this wave = accumulator registers 4g .. 4g+3
-        __syncthreads();
+        // the row image is private to the wave and a wave's LDS operations execute in order: no workgroup
+        // barrier between the groups (the four waves drift apart through the epilogue instead of marching)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int rr4 = 0; rr4 < 4; ++rr4)
                 ep[(rr4 + 4 * lh) * RT_EP_LD + t * 32 + li] = acc[t][4 * g + rr4];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         float4 v[8], rr[8], ad[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
