@@ -195,6 +195,41 @@ def test_stage_b_matches_oracle_random(preset, B, seed):
     assert np.abs(match.cpu().numpy() - ref_match.numpy())[ok].max() < TOL
 
 
+@pytest.mark.parametrize("Lv,Lq", [(160, 32), (129, 2), (96, 32), (1, 1)])
+def test_stage_b_window_length_boundaries(Lv, Lq):
+    """Maximum supported window (192 tokens: 6 key blocks in the encoder attention, the 192-key variant of the
+    fused decoder cross-attention), the 128/129 boundary of both, and the 1 + 1 token minimum, against the
+    oracle; one token more than 192 is rejected loudly."""
+    from cone_amd.model import build_model
+    from cone_amd import _lib
+    opt = make_opt("ego4d", max_v_l=Lv, max_q_l=Lq)
+    sdn = synth.make_state_dict(opt, 7)
+    model, _ = build_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    sd = O.as_torch_sd(sdn)
+    rng = np.random.default_rng(Lv)
+    B = 7
+    lens_v = [Lv] + [int(x) for x in rng.integers(1, Lv + 1, B - 1)]
+    lens_q = [Lq] + [int(x) for x in rng.integers(1, Lq + 1, B - 1)]
+    inp = gi.stage_b_inputs(opt, 31, lens_v, lens_q)
+    t = torch.from_numpy
+    with torch.no_grad():
+        ref = O.cone_forward(sd, opt, t(inp["src_txt"]), t(inp["txt_mask"]), t(inp["src_vid"]), t(inp["vid_mask"]))
+    dev = _gpu()
+    g = lambda a: torch.from_numpy(a).to(dev)
+    out = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]))
+    assert maxdiff(out["pred_logits"], ref["pred_logits"]) < TOL
+    assert maxdiff(out["pred_spans"], ref["pred_spans"]) < TOL
+    vm = _valid_token_mask(lens_v, lens_q, Lv, Lq)[:, :Lv]
+    assert np.abs(out["saliency_scores"].cpu().numpy() - ref["saliency_scores"].numpy())[vm].max() < TOL
+    if Lv + Lq == 192:
+        big = gi.stage_b_inputs(opt, 32, [Lv], [Lq])
+        txt = np.concatenate([big["src_txt"], big["src_txt"][:, :1]], axis=1)       # 193 tokens
+        msk = np.concatenate([big["txt_mask"], big["txt_mask"][:, :1]], axis=1)
+        with pytest.raises(_lib.ConeHipError):
+            model.forward(g(txt), g(msk), g(big["src_vid"]), g(big["vid_mask"]))
+
+
 def test_padding_independence_and_determinism():
     """Masked keys make the result independent of how far the batch is padded (H12) and the packed
     kernels are batch-composition independent: bit-identical outputs."""
