@@ -52,6 +52,25 @@ def collect_profile():
     return buf[:n]
 
 
+def reference_window_flops(lv, lq, dv, dt, d=256, ff=1024, nq=5, enc=2, dec=2):
+    """Algorithmic FLOPs of the reference's window model + matching for windows of lv clips and lq text tokens
+    (2*M*N*K per dense layer, 4*L^2*d per attention, padding not counted; 486.1 MFLOP at
+    lv=90, lq=20, dv=256, dt=768).  The reference computes all of it per window; this build de-duplicates the
+    input projections and the first in_proj across windows and folds the decoder's memory K/V projections, so it
+    executes fewer FLOPs than this for the same outputs."""
+    lv, lq = np.asarray(lv, dtype=np.float64), np.asarray(lq, dtype=np.float64)
+    L = lv + lq
+    proj = 2 * lv * (dv * d + d * d) + 2 * lq * (dt * d + d * d)
+    enc_f = enc * (2 * L * d * 3 * d + 2 * L * d * d + 4 * L * L * d + 2 * L * d * ff * 2)
+    dec_f = dec * (2 * L * d * 2 * d                                   # memory K/V projection
+                   + 2 * nq * d * 3 * d + 2 * nq * d * d + 4 * nq * nq * d          # self-attention over the slots
+                   + 2 * nq * d * d * 2 + 4 * nq * L * d                            # cross-attention q/out + scores
+                   + 2 * nq * d * ff * 2                                            # FFN
+                   + 2 * nq * (d * 2 + d * d * 2 + d * 2))                          # class + span heads (aux too)
+    rest = 2 * lv * d + 2 * nq * (dv * d * 2) + 2 * nq * dv                         # saliency, adapter on proposals, cosine
+    return proj + enc_f + dec_f + rest
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/
     r01_pmc_traffic.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
@@ -226,6 +245,16 @@ def main():
                        "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture"},
             "roofline": roof, "kernels": kern,
         }
+        wt = dp.get("windows")
+        if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
+            fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),
+                                        opt.v_appear_feat_dim, opt.t_feat_dim)
+            tf = world * float(fl.sum()) * args.steps / dt / 1e12
+            res["window_model"] = {"reference_mflop_per_window": round(float(fl.mean()) / 1e6, 1),
+                                   "reference_algorithmic_tflops": round(tf, 1),
+                                   "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
+                                   "note": "reference FLOPs (padding excluded) over the whole step time; the build "
+                                           "executes fewer (de-duplicated projections, folded decoder K/V)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_queries, max(1, args.cpu_queries * args.videos // args.queries))
         print(json.dumps(res))
