@@ -568,6 +568,7 @@ extern "C" int cone_test_set_option(const char* name, int value) {
     CONE_REQUIRE(name, "set_option: null name");
     if (!strcmp(name, "dec_fold")) { cone::g_dec_fold = value != 0; return 0; }
     if (!strcmp(name, "l0_gather")) { cone::g_l0_gather = value != 0; return 0; }
+    if (!strcmp(name, "attn16")) { cone::set_attn16(value); return 0; }
     cone::set_error("set_option: unknown option '%s'", name);
     return CONE_E_INVALID;
 }

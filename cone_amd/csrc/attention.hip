@@ -34,6 +34,9 @@ struct L0Gather {
     const int* trow0;
 };
 
+static int g_attn16 = 1;   // test hook (cone_test_set_option "attn16"): 0 = the 32x32x2 kernel below
+void set_attn16(int v) { g_attn16 = v != 0; }
+
 template <int NKB, bool GATHER>
 __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
                                                        const float* __restrict__ V,   // (M,256)
@@ -170,6 +173,153 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 16x16x4 variant (default): one wave per 16-query tile, workgroup = ceil(Lmax/16) waves.  A window of 101 tokens
+// pads to 112 x 112 scores instead of 128 x 128 (-23 % MFMA and exp work), a wave keeps only 4 registers per key
+// tile (7 waves x <= 96 VGPRs: twice the resident waves of the 32x32 kernel) and the per-wave critical path halves.
+//   S^T tile: A = K (keys on accumulator rows 4g + r, g = lane / 16), B = Q^T (query = lane % 16); the head dim
+//             is walked as d = 8 g + step so that a lane's 8 query values are two contiguous float4.
+//   P.V     : the probability registers are the A operand again (k slot g <-> key 4g + r of the tile); V rows are
+//             read at stride 36 floats, K is staged d-major [32][KP + 2]: both conflict-free for ds_read_b32.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int NKT, bool GATHER>
+__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __restrict__ QK, const float* __restrict__ V,
+                                                             float* __restrict__ OUT, const int* __restrict__ off,
+                                                             L0Gather g) {
+    constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
+    __shared__ float KsT[32 * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
+    const int b = blockIdx.x, head = blockIdx.y;
+    const int t0 = off[b];
+    const int L = off[b + 1] - t0;
+    const int nkt = (L + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
+    if (GATHER) { lv = g.vlen[b]; vr0 = g.vrow0[b]; tr0 = g.trow0[b]; pbase = lv * (lv - 1) / 2; }
+    auto src_of = [&](int tok, int col, const float*& add) -> const float* {
+        if (tok < lv) {
+            add = col < 512 ? g.pos_qk + (size_t)(pbase + tok) * 512 + col : nullptr;
+            return g.qkv_vid + (size_t)(vr0 + tok) * 768 + col;
+        }
+        add = nullptr;
+        return g.qkv_txt + (size_t)(tr0 + tok - lv) * 768 + col;
+    };
+
+    // this lane's query values d = 8 lg .. 8 lg + 7 (fetched before the K/V staging: independent round trips)
+    const int q0 = wave * 16;
+    float qv[8];
+    if (q0 < L) {
+        int qrow = q0 + li;
+        qrow = qrow < L ? qrow : L - 1;
+        const float* qadd = nullptr;
+        const float* qp = GATHER ? src_of(qrow, 0, qadd) + head * 32 + 8 * lg
+                                 : QK + (size_t)(t0 + qrow) * 512 + head * 32 + 8 * lg;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 x = reinterpret_cast<const float4*>(qp)[u];
+            if (GATHER && qadd) {
+                const float4 t = reinterpret_cast<const float4*>(qadd + head * 32 + 8 * lg)[u];
+                x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+            }
+            qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
+            qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+        }
+    }
+    {   // stage K (d-major) and V for all keys of the window; zero rows past L
+        const int kr = tid >> 3, c = tid & 7;
+        for (int key = kr; key < nkt * 16; key += NT / 8) {
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (key < L) {
+                if (GATHER) {
+                    const float* add;
+                    const float* kp_ = src_of(key, 256, add);
+                    kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
+                    vv = *reinterpret_cast<const float4*>(kp_ + 256 + head * 32 + c * 4);
+                    if (add) {
+                        const float4 t = *reinterpret_cast<const float4*>(add + head * 32 + c * 4);
+                        kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
+                    }
+                } else {
+                    kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
+                    vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
+                }
+            }
+            KsT[(4 * c + 0) * LDK + key] = kv.x; KsT[(4 * c + 1) * LDK + key] = kv.y;
+            KsT[(4 * c + 2) * LDK + key] = kv.z; KsT[(4 * c + 3) * LDK + key] = kv.w;
+            *reinterpret_cast<float4*>(Vs + key * LDV + c * 4) = vv;
+        }
+    }
+    __syncthreads();
+    if (q0 >= L) return;
+
+    f32x4m sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) sc[kt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const float* kp = KsT + (8 * lg + st) * LDK + li;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            if (kt < nkt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
+    }
+    // softmax over the keys of this lane's query: registers, then the four lane groups
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+            if (kt == nkt - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * lg + r >= L) sc[kt][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+        }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float m2 = m * 1.4426950408889634f;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
+                sc[kt][r] = e;
+                l += e;
+            }
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+            const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
+            const int rem = L - kt * 16;        // k-step r covers keys r, 4 + r, 8 + r, 12 + r of the tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rem) {
+                    const float pr = sc[kt][r] * inv;
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV + 16], o1, 0, 0, 0);
+                }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * lg + r;
+        if (qrow < L) {
+            float* dst = OUT + (size_t)(t0 + qrow) * 256 + head * 32 + li;
+            dst[0] = o0[r];
+            dst[16] = o1[r];
+        }
+    }
+}
+
 template <bool GATHER>
 static int launch_enc_attn_t(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
                              const L0Gather& g, hipStream_t s) {
@@ -178,6 +328,17 @@ static int launch_enc_attn_t(const float* QK, const float* V, float* OUT, const 
     dim3 grid(B, 8), block(256);
     const int nkb = (Lmax + 31) / 32;
     ProfScope ps(PK_ENC_ATTN, B, Lmax, GATHER, nullptr, s);
+    if (g_attn16) {
+        const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
+#define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, GATHER>), grid, dim3(64 * N), 0, s, QK, V, OUT, off, g); break;
+        switch (nkt) {
+            CONE_ATTN16(6)
+            CONE_ATTN16(7) CONE_ATTN16(8) CONE_ATTN16(9) CONE_ATTN16(10) CONE_ATTN16(11) CONE_ATTN16(12)
+        }
+#undef CONE_ATTN16
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
     if (nkb <= 4) hipLaunchKernelGGL((enc_attn_kernel<4, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
     else if (nkb == 5) hipLaunchKernelGGL((enc_attn_kernel<5, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
     else hipLaunchKernelGGL((enc_attn_kernel<6, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);

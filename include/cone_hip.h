@@ -253,7 +253,8 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
 /* Process-wide A/B switches for the parity tests.  "dec_fold" (default 1): decoder cross-attention with the
  * memory K/V projections folded into one kernel per layer; 0 = two stacked K/V GEMMs + per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
- * caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical. */
+ * caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
+ * "attn16" (default 1): encoder attention on 16x16x4 MFMA tiles, one wave per 16 queries; 0 = 32x32x2 tiles. */
 int cone_test_set_option(const char* name, int value);
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
  * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning

@@ -230,6 +230,36 @@ def test_stage_b_window_length_boundaries(Lv, Lq):
             model.forward(g(txt), g(msk), g(big["src_vid"]), g(big["vid_mask"]))
 
 
+@pytest.mark.parametrize("preset", ["ego4d", "mad"])
+def test_encoder_attention_tile_variants_agree(preset):
+    """The 16x16x4-tile encoder attention (one wave per 16 queries, default) and the 32x32x2-tile kernel compute the
+    same softmax(QK^T)V up to fp32 summation order."""
+    from cone_amd import _lib
+    model, opt, _ = get_model(preset, 0 if preset == "ego4d" else 1)
+    rng = np.random.default_rng(5)
+    B = 19
+    lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
+    lens_v[0], lens_v[1], lens_v[2] = opt.max_v_l, 1, 16
+    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
+    lens_q[0], lens_q[1], lens_q[2] = opt.max_q_l, 1, 16
+    inp = gi.stage_b_inputs(opt, 321, lens_v, lens_q)
+    dev = _gpu()
+    g = lambda a: torch.from_numpy(a).to(dev)
+    lib = _lib.load()
+    outs = []
+    try:
+        for v in (1, 0):
+            _lib.check(lib.cone_test_set_option(b"attn16", v))
+            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+            outs.append({k: o[k].cpu() for k in ("pred_logits", "pred_spans", "hs", "memory")})
+    finally:
+        _lib.check(lib.cone_test_set_option(b"attn16", 1))
+    vm = _valid_token_mask(lens_v, lens_q, inp["src_vid"].shape[1], inp["src_txt"].shape[1])
+    assert (outs[0]["memory"] - outs[1]["memory"]).abs().numpy()[vm].max() < 2e-5
+    for k in ("pred_logits", "pred_spans", "hs"):
+        assert maxdiff(outs[0][k], outs[1][k]) < 5e-5, k      # measured 2.2e-5 on logits of magnitude 6
+
+
 def test_padding_independence_and_determinism():
     """Masked keys make the result independent of how far the batch is padded (H12) and the packed
     kernels are batch-composition independent: bit-identical outputs."""
