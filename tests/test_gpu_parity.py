@@ -415,6 +415,48 @@ def test_fuse_nms_fp32_rounding_matches_python():
         assert out[t, 0, :int(cnt[t, 0])].cpu().tolist() == O.post_processing_mr_nms(opt, rd, idx)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuse_nms_random_batches_bit_exact(seed):
+    """Property test of stage C: many queries at once with ragged candidate counts, duplicate spans (dict collapse),
+    equal scores (stable order), constant score lists (min == max normalisation), every threshold regime
+    (-1 = no NMS, 0, 0.5, 1) and truncation limits -- kept rows equal the oracle's python doubles exactly."""
+    from cone_amd import ops
+    dev = _gpu()
+    rng = np.random.default_rng(seed)
+    nq, nmax = 64, 100
+    cand = np.zeros((nq, nmax, 4), np.float32)
+    nv = np.zeros(nq, np.int32)
+    for q in range(nq):
+        n = int(rng.integers(1, nmax + 1))
+        st = rng.uniform(0, 500, n)
+        ed = st + rng.uniform(0, 60, n)
+        pr = rng.uniform(0, 1, n)
+        ma = rng.uniform(-0.2, 0.6, n)
+        if q % 5 == 0 and n > 4:          # duplicates of earlier spans with other scores
+            k = n // 3
+            st[-k:], ed[-k:] = st[:k], ed[:k]
+        if q % 7 == 0:
+            pr[:] = 0.25                   # constant list: normalize_score returns it unchanged
+        if q % 11 == 0:
+            ma[:] = ma[0]
+        if q % 3 == 0 and n > 2:
+            pr[1] = pr[0]                  # ties in the sort key
+        cand[q, :n] = np.stack([st, ed, pr, ma], 1)
+        nv[q] = n
+    cd = torch.from_numpy(cand).to(dev)
+    nvd = torch.from_numpy(nv).to(dev)
+    for thd, mb, ma_ in ((0.5, 200, 5), (-1, 200, 5), (0.0, 50, 3), (1.0, 10, 10), (0.3, 7, 1), (0.7, 1000, 100)):
+        out, cnt, _ = ops.fuse_nms(cd, nvd, thd, mb, ma_)
+        opt = SimpleNamespace(nms_thd=thd, max_before_nms=mb, max_after_nms=ma_)
+        for q in range(nq):
+            rows = O.round4_rows(cand[q, :nv[q]].tolist())
+            rd = O.score_fusion(rows)
+            for t, idx in enumerate((2, 0, 1)):
+                ref = O.post_processing_mr_nms(opt, rd, idx)
+                got = out[t, q, :int(cnt[t, q])].cpu().tolist()
+                assert got == ref, (seed, thd, mb, ma_, q, t)
+
+
 def test_compose_rows_matches_torch_arithmetic():
     from cone_amd import ops
     dev = _gpu()
