@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--pipeline_chunks", type=int, default=None,
                     help="query chunks of the host/GPU software pipeline (default: automatic = 1 at this size)")
+    ap.add_argument("--set_option", action="append", default=[], metavar="NAME=0|1",
+                    help="diagnostics: flip an A/B switch of the library (cone_test_set_option), e.g. dec0_const=0")
     ap.add_argument("--window_batch", type=int, default=32768)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_queries", type=int, default=400)
@@ -190,6 +192,9 @@ def main():
     ann, vf, qf = synth.make_dataset(opt, args.queries, args.videos, seed=rank)
     store = inf.FeatureStore(opt, ann, vf, qf)          # features resident in HBM from here on
     lib = _lib.load()
+    for kv in args.set_option:
+        name, _, val = kv.partition("=")
+        _lib.check(lib.cone_test_set_option(name.encode(), int(val or 1)))
 
     def step():
         # the product's own driver (cone_amd.inference.predict_split): stages A->C + the submission rows

@@ -244,6 +244,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 
 // ------------------------------------------------------------------------------ packed forward
 static int g_dec_fold = 1;   // test hook (cone_test_set_option "dec_fold"): 0 = separate K/V GEMMs + small_attn
+static int g_dec0_const = 1; // test hook ("dec0_const"): 0 = first decoder layer's window-independent rows per window
 static int g_l0_gather = 1;  // test hook ("l0_gather"): 0 = pack_l0 writes q|k|v to HBM for the plain attention kernel
 
 struct FwdBuffers {
@@ -333,17 +334,26 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
     for (int l = 0; l < nd; ++l) {
         const DecLayer& dl = m->dec[l];
-        GemmArgs g = G(f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, T, nullptr, 512, 256);
+        // Layer 0 starts from tgt = 0 (cone/transformer.py:66): its self-attention block and its cross-attention
+        // queries do not depend on the window.  They are computed for ONE window's nq rows by the same kernels
+        // (rows of a GEMM are independent: identical bits) and replicated, instead of T = B*nq identical rows.
+        const int Tq = (l == 0 && g_dec0_const) ? m->nq : T;
+        const int Bq = (l == 0 && g_dec0_const) ? 1 : B;
+        GemmArgs g = G(f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, Tq, nullptr, 512, 256);
         g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
         RUN(launch_gemm(g, s));
-        RUN(launch_gemm(G(f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, T, nullptr, 256, 256), s));
-        RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
-        g = G(f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+        RUN(launch_gemm(G(f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, Tq, nullptr, 256, 256), s));
+        RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, Bq, m->nq, m->nq, s));
+        g = G(f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, Tq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
         RUN(launch_gemm(g, s));
-        g = G(f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, T, nullptr, 256, 256);
+        g = G(f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, Tq, nullptr, 256, 256);
         g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
         RUN(launch_gemm(g, s));
+        if (Tq != T) {
+            RUN(launch_tile_rows(f.TGT1, m->nq, T, s));
+            RUN(launch_tile_rows(f.DQ, m->nq, T, s));
+        }
         if (fold)
             RUN(launch_dec_cross(f.DQ, f.XP, MEM, f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B,
                                  m->nq, Lmax, s));
@@ -569,6 +579,7 @@ extern "C" int cone_test_set_option(const char* name, int value) {
     if (!strcmp(name, "dec_fold")) { cone::g_dec_fold = value != 0; return 0; }
     if (!strcmp(name, "l0_gather")) { cone::g_l0_gather = value != 0; return 0; }
     if (!strcmp(name, "attn16")) { cone::set_attn16(value); return 0; }
+    if (!strcmp(name, "dec0_const")) { cone::g_dec0_const = value != 0; return 0; }
     cone::set_error("set_option: unknown option '%s'", name);
     return CONE_E_INVALID;
 }

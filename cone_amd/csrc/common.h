@@ -99,6 +99,7 @@ int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float
 // ---------------------------------------------------------------- attention.hip
 int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
 void set_attn16(int v);
+int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s);
 // first encoder layer on the layer-0 cache: q|k|v gathered in the kernel's staging loads (attention.hip)
 int launch_enc_attn_l0(const float* qkv_vid, const float* qkv_txt, const float* pos_qk, const int* vrow0,
                        const int* vlen, const int* trow0, float* OUT, const int* off, int B, int Lmax,

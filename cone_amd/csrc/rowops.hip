@@ -105,6 +105,22 @@ int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out
     return 0;
 }
 
+// dst rows [period, n_rows) <- rows (r % period) of the same matrix (256 floats per row): replicates the decoder's
+// window-independent first-layer rows to every window.
+__global__ __launch_bounds__(256) void tile_rows_kernel(float* x, int period, int64_t n_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)period + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    reinterpret_cast<float4*>(x + row * 256)[lane] = reinterpret_cast<const float4*>(x + (row % period) * 256)[lane];
+}
+
+int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s) {
+    if (n_rows <= period) return 0;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((n_rows - period + 3) / 4)), dim3(256), 0, s, x, period, n_rows);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 // Heads with 1-2 outputs over d=256 inputs: class_embed, last span_embed layer (+sigmoid)
 // (cone/model.py:112-115).
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int ldx,

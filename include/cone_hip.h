@@ -254,6 +254,8 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  * memory K/V projections folded into one kernel per layer; 0 = two stacked K/V GEMMs + per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
  * caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
+ * "dec0_const" (default 1): the first decoder layer's self-attention block and cross-attention queries (tgt = 0:
+ * the same for every window) are computed for one window and replicated; 0 = for all windows.  Bit-identical.
  * "attn16" (default 1): encoder attention on 16x16x4 MFMA tiles, one wave per 16 queries; 0 = 32x32x2 tiles. */
 int cone_test_set_option(const char* name, int value);
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);

@@ -659,6 +659,14 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
     assert lib.cone_test_set_option(b"no_such_option", 1) != 0
     for k in ("pred_logits", "pred_spans", "hs"):
         assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
+    # the first decoder layer's window-independent rows (tgt = 0) computed once and replicated: identical bits
+    try:
+        _lib.check(lib.cone_test_set_option(b"dec0_const", 0))
+        o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+    finally:
+        _lib.check(lib.cone_test_set_option(b"dec0_const", 1))
+    for k in ("pred_logits", "pred_spans", "hs"):
+        assert torch.equal(o[k].cpu(), outs[0][k]), k
 
 
 @pytest.mark.parametrize("ctx_l,W,dv,nq,k,world", [(901, 90, 256, 3, 20, 8), (131, 90, 256, 2, 5, 8),
