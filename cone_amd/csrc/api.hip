@@ -326,6 +326,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     // decoder (cone/transformer.py:296-317, 117-146).  Default: the memory K / V projections are folded into
     // the cross-attention kernel (dec_cross.hip); otherwise memory K/V for all layers in two GEMMs.
     const bool fold = g_dec_fold && dec_cross_supported(m->nq, Lmax);
+    const bool want_aux = taps && (taps->hs || taps->aux_logits || taps->aux_spans);
     if (!fold) {
         GemmArgs g = G(f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
@@ -367,28 +368,34 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         g = G(f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT2; g.ldr = 256; g.ln_g = dl.n3.g; g.ln_b = dl.n3.b;
         RUN(launch_gemm(g, s));
-        RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
-                             256, s));
+        // decoder.norm + heads on an intermediate layer only feed aux_outputs / the hs tap (unused by inference,
+        // cone/inference.py:54-59): computed on request only
+        if (l == nd - 1 || want_aux)
+            RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
+                                 256, s));
     }
-    // heads on every decoder layer's output (cone/model.py:112-117); the last layer is the prediction
-    const int HT = nd * T;
-    RUN(launch_rowdot(f.HS, 256, m->class_embed.w, m->class_embed.b, f.LG, 2, HT, 2, 0, s));
-    RUN(launch_gemm(G(f.HS, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    // heads (cone/model.py:112-117); the last layer is the prediction
+    const int h0 = want_aux ? 0 : nd - 1;               // first decoder layer whose heads are needed
+    const int HT = (nd - h0) * T;
+    const size_t hoff = (size_t)h0 * T;
+    RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, f.LG + hoff * 2, 2, HT, 2, 0, s));
+    RUN(launch_gemm(G(f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
     RUN(launch_gemm(G(f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
-    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP, 2, HT, 2, 1, s));
+    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP + hoff * 2, 2, HT, 2, 1, s));
     const size_t last = (size_t)(nd - 1) * T * 2;
     CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (taps) {
         if (taps->hs)
-            CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)HT * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)nd * T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (taps->aux_logits && nd > 1)
             CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_logits, f.LG, last * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (taps->aux_spans && nd > 1)
             CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_spans, f.SP, last * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
-                        taps ? taps->memory : nullptr, Lq_max, B, s));
+    if (saliency || (taps && taps->memory))     // saliency == NULL: not wanted (cone/inference.py never reads it)
+        RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
+                            taps ? taps->memory : nullptr, Lq_max, B, s));
     return 0;
 }
 
@@ -464,7 +471,7 @@ extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, cons
                                    const int32_t* txt_len, int B, int Lv_max, int Lq_max, float* logits,
                                    float* spans, float* saliency, const cone_taps* taps, const cone_layer0* l0,
                                    void* ws, size_t ws_bytes, void* stream) {
-    CONE_REQUIRE(m && vproj && tproj && vid_row0 && vid_len && txt_row0 && txt_len && logits && spans && saliency,
+    CONE_REQUIRE(m && vproj && tproj && vid_row0 && vid_len && txt_row0 && txt_len && logits && spans,
                  "forward_packed: null argument");
     return forward_packed(m, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, B, Lv_max, Lq_max, logits, spans,
                           saliency, taps, ws, ws_bytes, (hipStream_t)stream, l0);
@@ -505,7 +512,7 @@ extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const
                                     const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,
                                     float* spans, float* saliency, const cone_taps* taps, void* ws,
                                     size_t ws_bytes, void* stream) {
-    CONE_REQUIRE(m && vid && txt && vid_len && txt_len && logits && spans && saliency, "forward_windows: null argument");
+    CONE_REQUIRE(m && vid && txt && vid_len && txt_len && logits && spans, "forward_windows: null argument");
     CONE_REQUIRE(B > 0 && Lv_pad > 0 && Lq_pad > 0, "forward_windows: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;

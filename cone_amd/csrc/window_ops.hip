@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void saliency_kernel(const float* __restrict__
             const float4 wv = reinterpret_cast<const float4*>(w)[lane];
             s = wave_sum((x.x * wv.x + x.y * wv.y) + (x.z * wv.z + x.w * wv.w)) + bias[0];
         }
-        if (lane == 0) sal[(size_t)b * Lv_out + p] = s;
+        if (lane == 0 && sal) sal[(size_t)b * Lv_out + p] = s;
         if (mem_tap) reinterpret_cast<float4*>(mem_tap + ((size_t)b * (Lv_out + Lq_out) + p) * 256)[lane] = x;
     } else if (mem_tap && p < Lv_out + Lq_out) {
         const int t = p - Lv_out;

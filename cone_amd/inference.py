@@ -301,7 +301,8 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
         sl = slice(c0, min(c0 + chunk, nw))
         g = lambda k: wt[k][sl].contiguous()
         out = model.forward_packed(feats["vproj"], g("vid_row0"), g("vid_len"), feats["tproj"], g("txt_row0"),
-                                   g("txt_len"), opt.max_v_l, Lq_max, l0=feats.get("l0"))
+                                   g("txt_len"), opt.max_v_l, Lq_max, l0=feats.get("l0"),
+                                   saliency=bool(getattr(opt, "need_saliency", False)))
         match = model.clip_matching_gathered(feats["cls_norm"], g("cls_row"), store.vid_raw, g("vid_row0"),
                                              g("vid_len"), g("pad_len"), out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, g("vid_len"), g("video_start"),

@@ -269,8 +269,10 @@ class CONE:
         _lib.check(lib.cone_layer0_project(h, _lib.ptr(tproj), tproj.shape[0], _lib.ptr(qt), _lib.stream()))
         return dict(qkv_vid=qv, qkv_txt=qt, pos_qk=self._pos_qk[1], max_v_l=max_v_l)
 
-    def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None):
-        """CONE.forward on windows given by index into projected token arenas."""
+    def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None,
+                       saliency: bool = True):
+        """CONE.forward on windows given by index into projected token arenas.  ``saliency=False`` skips the
+        saliency head (cone/inference.py computes and never reads it, :54-59)."""
         lib, h = _lib.load(), self._h()
         l0s = None
         if l0 is not None:
@@ -281,7 +283,7 @@ class CONE:
         nq = self.num_queries
         logits = torch.empty(B, nq, 2, device=dev)
         spans = torch.empty(B, nq, 2, device=dev)
-        sal = torch.empty(B, Lv_max, device=dev)
+        sal = torch.empty(B, Lv_max, device=dev) if saliency else None
         nbytes = lib.cone_forward_packed_workspace(h, B, Lv_max, Lq_max)
         ws = self._ws.get(nbytes, dev)
         i32 = torch.int32
@@ -290,7 +292,10 @@ class CONE:
                                            Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), None,
                                            C.byref(l0s) if l0s is not None else None,
                                            _lib.ptr(ws), ws.numel(), _lib.stream()))
-        return {"pred_logits": logits, "pred_spans": spans, "saliency_scores": sal}
+        out = {"pred_logits": logits, "pred_spans": spans}
+        if saliency:
+            out["saliency_scores"] = sal
+        return out
 
     def clip_matching_gathered(self, cls, cls_row, vid, vid_row0, vid_len, pad_len, spans):
         lib, h = _lib.load(), self._h()

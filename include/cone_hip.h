@@ -136,7 +136,9 @@ typedef struct {
 /* A6-A11, CONE.forward (cone/model.py:82-128) on zero-padded tensors exactly as
  * prepare_batch_inputs delivers them: vid (B,Lv_pad,v_dim), txt (B,Lq_pad,t_dim); masks are prefix
  * masks given as valid lengths vid_len[B], txt_len[B] (int32, device).
- * Outputs: logits (B,Nq,2), spans (B,Nq,2) = sigmoid(center,width), saliency (B,Lv_pad)
+ * Outputs: logits (B,Nq,2), spans (B,Nq,2) = sigmoid(center,width), saliency (B,Lv_pad; may be NULL: the
+ * saliency head is then skipped -- cone/inference.py computes and never reads it, :54-59; likewise the heads and
+ * decoder.norm of the intermediate decoder layers run only when taps ask for hs / aux_logits / aux_spans)
  * (entries at padded clips are written as 0; the reference leaves them unspecified/unused). */
 size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad);
 int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len,
