@@ -1,0 +1,16 @@
+import sys, time, torch
+sys.path.insert(0, '/root/repo')
+from cone_amd import synth, inference as inf
+from cone_amd.config import make_opt
+from cone_amd.model import build_model
+opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20)
+model, _ = build_model(opt)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
+for nq, nv in ((1, 1), (8, 1), (64, 4)):
+    ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=0, ctx_range=(900, 901))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    for _ in range(5): inf.predict_split(model, store, opt)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): out, dp = inf.predict_split(model, store, opt)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
+    print(f"{nq} queries x {nv} videos: {dp['n_windows']} windows, {dt*1e3:.2f} ms per split")
