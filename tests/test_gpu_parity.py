@@ -850,6 +850,74 @@ def test_predict_split_pipeline_is_chunk_invariant():
     assert len(inf.query_chunks(1000, auto)) == 1 and len(inf.query_chunks(20000, auto)) == 6
 
 
+def test_cli_start_inference_on_packed_store(tmp_path):
+    """The reference's command line end to end: checkpoint + opt.json beside it (saved options win except the CLI
+    whitelist, cone/config.py:184-196), annotations + features from the packed arena file, prediction files and
+    metric table on the val split -- same results as driving the Python API directly."""
+    from cone_amd import inference as inf
+    saved = make_opt("ego4d", nms_thd=0.5, topk_window=4, eval_bsz=8, max_after_nms=7)
+    sdn = synth.make_state_dict(saved, 3)
+    ckpt_dir = tmp_path / "run"
+    ckpt_dir.mkdir()
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in sdn.items()}, "epoch": 11}, ckpt_dir / "model_best.ckpt")
+    with open(ckpt_dir / "opt.json", "w") as f:
+        json.dump({k: v for k, v in vars(saved).items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
+    ann, vf, qf = synth.make_dataset(saved, 13, 2, seed=6, ctx_range=(150, 400))
+    rng = np.random.default_rng(1)
+    for r in ann:
+        a = float(rng.uniform(0, 0.7 * r["duration"]))
+        r["timestamps"] = [round(a, 3), round(a + 12.5, 3)]
+    gt = {"videos": [{"clips": []}]}
+    for r in ann:
+        uid, qidx = r["query_id"].split("_")
+        c = next((c for c in gt["videos"][0]["clips"] if c["clip_uid"] == r["clip_id"]), None)
+        if c is None:
+            c = {"clip_uid": r["clip_id"], "annotations": []}
+            gt["videos"][0]["clips"].append(c)
+        a = next((a for a in c["annotations"] if a["annotation_uid"] == uid), None)
+        if a is None:
+            a = {"annotation_uid": uid, "language_queries": {}}
+            c["annotations"].append(a)
+        a["language_queries"][int(qidx)] = {"clip_start_sec": r["timestamps"][0], "clip_end_sec": r["timestamps"][1]}
+    for c in gt["videos"][0]["clips"]:
+        for a in c["annotations"]:
+            m = max(a["language_queries"])
+            a["language_queries"] = [a["language_queries"].get(i, {"clip_start_sec": 0.0, "clip_end_sec": 1.0})
+                                     for i in range(m + 1)]
+    gt_path = tmp_path / "nlq_val.json"
+    gt_path.write_text(json.dumps(gt))
+    eval_path = tmp_path / "val.jsonl"
+    eval_path.write_text("\n".join(json.dumps(r) for r in ann))
+    cpu_store = inf.FeatureStore(saved, ann, vf, qf, device=torch.device("cpu"))
+    packed = cpu_store.save_packed(str(tmp_path / "val.conefs"))
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    # --topk_window is on the CLI whitelist (CLI wins: 5), --max_after_nms too; --hidden_dim is not (opt.json wins)
+    argv = ["--resume", str(ckpt_dir / "model_best.ckpt"), "--eval_split_name", "val", "--eval_path", str(eval_path),
+            "--eval_id", "t1", "--eval_results_dir", str(out_dir), "--packed_features", packed, "--nms_thd", "0.5",
+            "--topk_window", "5", "--max_after_nms", "7", "--hidden_dim", "64", "--save_all"]
+    import cone_amd.inference as mod
+    old = mod.EGO4D_VAL_GT
+    mod.EGO4D_VAL_GT = str(gt_path)
+    try:
+        res, miou, strs, paths = inf.start_inference(argv)
+    finally:
+        mod.EGO4D_VAL_GT = old
+    sub_path = out_dir / "inference_ego4d_val_t1_preds.json"
+    assert sub_path.exists() and (out_dir / "inference_ego4d_val_t1_proposal_preds.json").exists()
+    assert str(paths[0]).endswith("inference_ego4d_val_t1_preds.txt") and len(strs) == 4
+    sub = json.loads(sub_path.read_text())
+    assert sub["version"] == "1.0" and len(sub["results"]) == 13
+    # same answer as the Python API with the effective options
+    eff = make_opt("ego4d", nms_thd=0.5, topk_window=5, eval_bsz=8, max_after_nms=7, eval_split_name="val")
+    model, _ = __import__("cone_amd.model", fromlist=["build_model"]).build_model(eff)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()})
+    (fusion, _, _), _ = inf.predict_split(model, inf.FeatureStore(eff, ann, vf, qf), eff)
+    assert json.loads(json.dumps(fusion)) == sub["results"]
+    ref, ref_miou = O.evaluate_nlq_performance_ego4d(sub["results"], gt, [0.3, 0.5], [1, 5, 10, 50, 100])
+    assert np.array_equal(res, ref * 100) and float(miou) == float(ref_miou)
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator
