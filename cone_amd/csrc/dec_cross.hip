@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restri
         const int h = col >> 5;
         const int sbase = half * S0;
         const float* wcol = WvT + col;
-#pragma unroll 8
+#pragma unroll 4
         for (int c4 = 0; c4 < 64; ++c4) {
             const f2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
