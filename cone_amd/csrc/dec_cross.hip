@@ -186,67 +186,96 @@ __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restri
     }
     __syncthreads();
 
-    // ---- stage C: ctx[p][c] = sum_j P[j][p] * mem[j][c]; lane = 4 columns, wave = its PPW pairs
+    // ---- stage C: ctx[p][c] = sum_j P[j][p] * mem[j][c]; lane = 4 columns, wave = its PPW pairs.  Every wave needs
+    // every memory row, so the rows go through LDS once per workgroup (16-key chunks, double-buffered in the dead
+    // qkf region, register prefetch of the next chunk) instead of eight times through the vector L1.
     f4v ctx[C::PPW];
 #pragma unroll
     for (int pp = 0; pp < C::PPW; ++pp) ctx[pp] = f4v{0.f, 0.f, 0.f, 0.f};
-    const float* xrow = X + (size_t)t0 * 256 + lane * 4;
-    for (int j0 = 0; j0 < L; j0 += 4) {
-        f4v x4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = min(j0 + u, L - 1);
-            x4[u] = *reinterpret_cast<const f4v*>(xrow + (size_t)j * 256);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j0 + u < L) {
+    {
+        constexpr int CK = 16;
+        float* xs = qkf;                                     // [2][CK][256]
+        const int nch = (L + CK - 1) / CK;
+        const int xr = tid >> 5, xc = (tid & 31) * 4;        // 512 threads = 16 rows x 32 float4, two halves of a row
+        f4v xa, xb;
+#define DC_XFETCH(ch_)                                                                              \
+    {                                                                                               \
+        const int j = min((ch_) * CK + xr, L - 1);                                                  \
+        const float* src = X + (size_t)(t0 + j) * 256 + xc;                                         \
+        xa = *reinterpret_cast<const f4v*>(src);                                                    \
+        xb = *reinterpret_cast<const f4v*>(src + 128);                                              \
+    }
+#define DC_XSTASH(buf_)                                                                             \
+    {                                                                                               \
+        *reinterpret_cast<f4v*>(xs + (buf_) * (CK * 256) + xr * 256 + xc) = xa;                     \
+        *reinterpret_cast<f4v*>(xs + (buf_) * (CK * 256) + xr * 256 + xc + 128) = xb;               \
+    }
+        DC_XFETCH(0)
+        DC_XSTASH(0)
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < nch) DC_XFETCH(ch + 1)
+            const float* xrow = xs + buf * (CK * 256) + lane * 4;
+            const int jn = min(CK, L - ch * CK);
+            for (int u = 0; u < jn; ++u) {
+                const f4v x4 = *reinterpret_cast<const f4v*>(xrow + u * 256);
                 f4v pv[C::PPWP / 4];
 #pragma unroll
                 for (int i = 0; i < C::PPWP / 4; ++i)
-                    pv[i] = *reinterpret_cast<const f4v*>(P + (j0 + u) * C::NPP + wave * C::PPWP + 4 * i);
+                    pv[i] = *reinterpret_cast<const f4v*>(P + (ch * CK + u) * C::NPP + wave * C::PPWP + 4 * i);
 #pragma unroll
                 for (int pp = 0; pp < C::PPW; ++pp) {
                     const float p = pv[pp >> 2][pp & 3];
                     const f2v p2 = {p, p};
-                    ctx[pp].xy = __builtin_elementwise_fma(p2, x4[u].xy, ctx[pp].xy);
-                    ctx[pp].zw = __builtin_elementwise_fma(p2, x4[u].zw, ctx[pp].zw);
+                    ctx[pp].xy = __builtin_elementwise_fma(p2, x4.xy, ctx[pp].xy);
+                    ctx[pp].zw = __builtin_elementwise_fma(p2, x4.zw, ctx[pp].zw);
                 }
             }
+            if (ch + 1 < nch) DC_XSTASH(buf ^ 1)             // last read of that buffer was before the previous barrier
+            __syncthreads();
         }
+#undef DC_XFETCH
+#undef DC_XSTASH
     }
-    float* ctxs = qkf;                                       // qkf is dead since the last stage-A barrier
+    float* ctxs = qkf;                                       // the chunk buffers are dead after the loop's last barrier
 #pragma unroll
     for (int pp = 0; pp < C::PPW; ++pp)
         *reinterpret_cast<f4v*>(ctxs + (wave * C::PPW + pp) * 256 + lane * 4) = ctx[pp];
     __syncthreads();
 
-    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o; the two
-    // thread groups take slots [0, NQ/2] and (NQ/2, NQ)
+    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o; the two thread
+    // groups split the c range (each W_v^T element is loaded once per window), partial sums meet in LDS
     {
-        constexpr int S0 = (NQ + 1) / 2;
-        f2v o[S0];
+        f2v o[NQ];
 #pragma unroll
-        for (int s = 0; s < S0; ++s) o[s] = f2v{0.f, 0.f};
+        for (int s = 0; s < NQ; ++s) o[s] = f2v{0.f, 0.f};
         const int h = col >> 5;
-        const int sbase = half * S0;
-        const float* wcol = WvT + col;
+        const float* wcol = WvT + (size_t)half * 128 * 256 + col;
+        const float* crow = ctxs + h * 256 + half * 128;
 #pragma unroll 4
-        for (int c4 = 0; c4 < 64; ++c4) {
+        for (int c4 = 0; c4 < 32; ++c4) {
             const f2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
             const f2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
 #pragma unroll
-            for (int s = 0; s < S0; ++s) {
-                const int sl = min(sbase + s, NQ - 1);
-                const f4v cx = *reinterpret_cast<const f4v*>(ctxs + (sl * 8 + h) * 256 + c4 * 4);
+            for (int s = 0; s < NQ; ++s) {
+                const f4v cx = *reinterpret_cast<const f4v*>(crow + s * 8 * 256 + c4 * 4);
                 o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
                 o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
             }
         }
-        const float bias = bv[col];
+        float* red = tile;                                   // P image is dead since the end of stage C
+        if (half == 1) {
 #pragma unroll
-        for (int s = 0; s < S0; ++s)
-            if (sbase + s < NQ) OUT[(size_t)(b * NQ + sbase + s) * 256 + col] = (o[s].x + o[s].y) + bias;
+            for (int s = 0; s < NQ; ++s) red[s * 256 + col] = o[s].x + o[s].y;
+        }
+        __syncthreads();
+        if (half == 0) {
+            const float bias = bv[col];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s)
+                OUT[(size_t)(b * NQ + s) * 256 + col] = ((o[s].x + o[s].y) + red[s * 256 + col]) + bias;
+        }
     }
 }
 
