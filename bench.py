@@ -38,7 +38,7 @@ from cone_amd.model import build_model  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn_kernel", 4: "frame_score_kernel",
-                5: "gemm_rows_kernel<16>", 6: "gemm_rows_kernel<32>", 7: "dec_cross_kernel"}
+                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_kernel"}
 GEMM_KINDS = (0, 1, 2, 5, 6)
 
 

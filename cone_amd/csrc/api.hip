@@ -587,6 +587,7 @@ extern "C" int cone_test_set_option(const char* name, int value) {
     if (!strcmp(name, "l0_gather")) { cone::g_l0_gather = value != 0; return 0; }
     if (!strcmp(name, "attn16")) { cone::set_attn16(value); return 0; }
     if (!strcmp(name, "dec0_const")) { cone::g_dec0_const = value != 0; return 0; }
+    if (!strcmp(name, "gemm_waves")) { cone::set_gemm_rows_waves(value); return 0; }
     cone::set_error("set_option: unknown option '%s'", name);
     return CONE_E_INVALID;
 }

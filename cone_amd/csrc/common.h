@@ -61,7 +61,7 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 
 // ---------------------------------------------------------------- opt-in launch timing (prof.hip)
 enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4,
-                PK_GEMM_ROWS = 5, PK_GEMM_ROWS_A2 = 6, PK_DEC_CROSS = 7 };
+                PK_GEMM_ROWS = 5, PK_GEMM_ROWS16 = 6, PK_DEC_CROSS = 7 };
 bool prof_enabled();
 struct ProfScope {
     ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
@@ -87,6 +87,7 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 void set_gemm_variant(int v);
+void set_gemm_rows_waves(int w);
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,

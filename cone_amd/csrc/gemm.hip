@@ -452,13 +452,162 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
     }
 }
 
-static int g_gemm_variant = 0;  // 0 auto, 1 force register-staged tiles, 2/3 force the row tile (test hook A/B)
-static int g_rows_bk = 16;      // slab depth of the row tile: 16 (two workgroups per CU) or 32 (one)
-void set_gemm_variant(int v) {   // test hook: 1 register-staged square tiles, 2 row tile (default), 3 row tile BK=32
-    g_gemm_variant = v == 3 ? 2 : v;
-    if (v == 2) g_rows_bk = 16;
-    if (v == 3) g_rows_bk = 32;
+// ---------------------------------------------------------------------------------------------------------
+// 8-wave variant of the row-owning tile: same 128 x 256 x 16 slabs and LDS-DMA ring, but a wave owns 16 complete
+// rows on v_mfma_f32_16x16x4_f32 (64 accumulators instead of 128 -> <= 128 VGPRs -> 16 waves per CU at two
+// workgroups): while one wave walks its epilogue three others keep the matrix pipe busy.  Operand chunk swizzle
+// f[(row >> 2) & 3], f = {0, 3, 2, 1}: conflict-free for the (row = lane % 16, chunk = lane / 16) ds_read_b128.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
+
+__global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
+    constexpr int RBK = 16, SLAB = (RT_BM + RT_BN) * RBK, NBUF = 3, NPIECE = 3;   // 24 KiB slab / 8 waves
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int M = p.M;
+    if (p.M_dev) { int md = *p.M_dev; M = md < M ? md : M; }
+    const int nc = p.N / RT_BN;
+    const int L = blockIdx.x, grp = L / (8 * nc), r0 = L % (8 * nc);
+    const int m0 = (grp * 8 + (r0 & 7)) * RT_BM;
+    if (m0 >= M) return;
+    const int n0 = (r0 >> 3) * RT_BN;
+    const int K = p.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // LDS-DMA pieces: the slab image is 384 rows x 64 B; piece q (of 24) = rows 16q .. 16q+15; wave w issues pieces
+    // 3w .. 3w+2 (pieces 0-7 = A rows, 8-23 = W rows); lane -> (row = lane / 4, physical chunk = lane % 4)
+    const float* __restrict__ Ab = p.A + (size_t)m0 * p.lda;
+    const float* __restrict__ Wb = p.W + (size_t)n0 * p.ldw;
+    const float* src[NPIECE];
+    int dst[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int q = wave * NPIECE + i;
+        const int row = q * 16 + lane / 4;                        // row of the slab image
+        const int chunk = (lane % 4) ^ swz16(row);                // source chunk that lands in physical chunk lane % 4
+        if (q < 8) {
+            const int sr = (m0 + row < M) ? row : (M - 1 - m0);   // rows past M feed unstored outputs
+            src[i] = Ab + (size_t)sr * p.lda + (chunk << 2);
+        } else {
+            src[i] = Wb + (size_t)(row - RT_BM) * p.ldw + (chunk << 2);
+        }
+        dst[i] = q * 256;
+    }
+    auto stream_piece = [&](int kt, int buf, int i) { GLDS16(src[i] + kt * RBK, smem + buf * SLAB + dst[i]); };
+
+    f32x4a acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    const int csw = (lg ^ swz16(li)) << 2;                        // this lane's chunk (4 consecutive k) of row li
+    const int a_row = (wave * 16 + li) * RBK + csw;
+    const int b_row = RT_BM * RBK + li * RBK + csw;
+
+    const int nk = K / RBK;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) stream_piece(0, 0, i);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stream_piece(1, 1, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sb = smem + (kt % NBUF) * SLAB;
+        const int nxt = (kt + 2) % NBUF;
+        const bool more = kt + 2 < nk;
+        const f32x4a a = *reinterpret_cast<const f32x4a*>(sb + a_row);
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            const f32x4a b0 = *reinterpret_cast<const f32x4a*>(sb + b_row + t * 16 * RBK);
+            const f32x4a b1 = *reinterpret_cast<const f32x4a*>(sb + b_row + (t + 1) * 16 * RBK);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[t + 1], 0, 0, 0);
+            }
+            if (more && t / 2 < NPIECE) stream_piece(kt + 2, nxt, t / 2);
+            if (t & 2) asm volatile("" ::: "memory");       // bound the operand prefetch depth (register budget: 128)
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: accumulator (t, r) of lane (li, lg) = row 4 lg + r of the wave's 16, column 16 t + li.  Eight rows
+    // at a time (lane groups 0-1, then 2-3) are parked in LDS and walked with one float4 per lane per row.
+    const int flags = p.flags;
+    const int mrow0 = m0 + wave * 16;
+    float* ep = smem + wave * (8 * RT_EP_LD);
+    const int c4 = lane * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = bias4, be4 = bias4;
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
+    if (flags & EPI_LN) {
+        g4 = *reinterpret_cast<const float4*>(p.ln_g + c4);
+        be4 = *reinterpret_cast<const float4*>(p.ln_b + c4);
+    }
+    const int rows_here = min(16, M - mrow0);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        __builtin_amdgcn_wave_barrier();
+        if ((lg >> 1) == g) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(4 * (lg & 1) + r) * RT_EP_LD + t * 16 + li] = acc[t][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {          // four rows at a time: 64 accumulators + 48 row registers stay < 128
+            float4 v[4], rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int i = min(8 * g + 4 * hf + k, rows_here - 1);
+                i = i < 0 ? 0 : i;
+                const size_t m = (size_t)min(mrow0 + i, M - 1);
+                if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + m * p.ldr + n0 + c4);
+                v[k] = *reinterpret_cast<const float4*>(ep + (4 * hf + k) * RT_EP_LD + c4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 x = v[k];
+                x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+                if (flags & EPI_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                if (flags & EPI_RESIDUAL) { x.x += rr[k].x; x.y += rr[k].y; x.z += rr[k].z; x.w += rr[k].w; }
+                if (flags & EPI_LN) {
+                    const float mean = wave_sum_dpp((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+                    const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+                    const float var = wave_sum_dpp((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
+                    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                    x.x = d0 * rstd * g4.x + be4.x; x.y = d1 * rstd * g4.y + be4.y;
+                    x.z = d2 * rstd * g4.z + be4.z; x.w = d3 * rstd * g4.w + be4.w;
+                }
+                if (8 * g + 4 * hf + k < rows_here) {
+                    const size_t m = (size_t)(mrow0 + 8 * g + 4 * hf + k);
+                    *reinterpret_cast<float4*>(p.C + m * p.ldc + n0 + c4) = x;
+                    if (p.C2) {
+                        const float4 ad = *reinterpret_cast<const float4*>(p.ADD + m * p.ldc + n0 + c4);
+                        x.x += ad.x; x.y += ad.y; x.z += ad.z; x.w += ad.w;
+                        *reinterpret_cast<float4*>(p.C2 + m * p.ldc + n0 + c4) = x;
+                    }
+                }
+            }
+        }
+    }
 }
+
+static int g_gemm_variant = 0;  // 0 auto, 1 force register-staged tiles, 2/3 force a row tile (test hook A/B)
+static int g_rows_waves = 8;    // row tile flavour: 8 waves x 16 rows on 16x16x4 (default) or 4 waves x 32 rows on 32x32x2
+void set_gemm_variant(int v) {   // test hook: 1 register-staged square tiles, 2 four-wave row tile, 3 eight-wave row tile
+    g_gemm_variant = v == 3 ? 2 : v;
+    if (v == 2) g_rows_waves = 4;
+    if (v == 3 || v == 0) g_rows_waves = 8;
+}
+void set_gemm_rows_waves(int w) { g_rows_waves = w == 4 ? 4 : 8; }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
@@ -475,17 +624,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (use_rows || need_rows) {
         static bool attr_set = false;
         if (!attr_set) {
-            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               RowTile<32>::LDS_BYTES));
+            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               RowTile<16>::LDS_BYTES));
             CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                RowTile<16>::LDS_BYTES));
             attr_set = true;
         }
         const int row_tiles = (a.M + RT_BM - 1) / RT_BM;
         dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (a.N / RT_BN)));      // 1-D, see the tile order in the kernel
-        ProfScope ps(PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);
-        if (g_rows_bk == 32)
-            hipLaunchKernelGGL(gemm_rows_kernel<32>, grid, dim3(256), RowTile<32>::LDS_BYTES, s, a);
+        ProfScope ps(g_rows_waves == 8 ? PK_GEMM_ROWS16 : PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);
+        if (g_rows_waves == 8)
+            hipLaunchKernelGGL(gemm_rows16_kernel, grid, dim3(512), RowTile<16>::LDS_BYTES, s, a);
         else
             hipLaunchKernelGGL(gemm_rows_kernel<16>, grid, dim3(256), RowTile<16>::LDS_BYTES, s, a);
         CONE_LAUNCH_CHECK();

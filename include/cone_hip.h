@@ -245,8 +245,7 @@ int cone_eval_window_recall(const int32_t* win_idx, int nq, int k, const double*
  * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
  * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
  * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, 0); kind 4 = frame-score
- * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile without / with fused
- * addend (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq).  Returns the record count.  Not thread-safe. */
+ * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq).  Returns the record count.  Not thread-safe. */
 int cone_prof_enable(int on);
 int64_t cone_prof_collect(double* out, int64_t max_rec);
 
@@ -258,11 +257,13 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  * caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
  * "dec0_const" (default 1): the first decoder layer's self-attention block and cross-attention queries (tgt = 0:
  * the same for every window) are computed for one window and replicated; 0 = for all windows.  Bit-identical.
+ * "gemm_waves" (default 8): row-owning GEMM tile as 8 waves x 16 rows on 16x16x4 MFMA; 4 = 4 waves x 32 rows on
+ * 32x32x2 (same slabs; both are exact-fp32 fma chains per output element that walk k in different orders).
  * "attn16" (default 1): encoder attention on 16x16x4 MFMA tiles, one wave per 16 queries; 0 = 32x32x2 tiles. */
 int cone_test_set_option(const char* name, int value);
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
- * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning
- * LDS-DMA tile, 0 = automatic).  Optional second output C2 = C + ADD (row tile only). */
+ * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning LDS-DMA tile
+ * with 4 waves x 32 rows, 3 = the same tile with 8 waves x 16 rows, 0 = automatic = 3 where the shape allows).  Optional second output C2 = C + ADD (row tile only). */
 int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
                    const float* R, const float* ln_g, const float* ln_b, float* C, float* C2,
                    const float* ADD, int M, int N, int K, int flags, void* stream);

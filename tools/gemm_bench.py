@@ -35,7 +35,7 @@ def main():
         lg, lb = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
         C = torch.empty(M, N, device=dev)
         bufs[name] = (A, A2, W, b, R, lg, lb, C)
-    variants = {"tiles-v1": 0x100, "rows-bk16": 0x200, "rows-bk32": 0x300}
+    variants = {"tiles-v1": 0x100, "rows-4waves": 0x200, "rows-8waves": 0x300}
     times = {(s[0], v): [] for s in SHAPES for v in variants}
     for r in range(rounds + 1):
         for name, N, K, flags, a2 in SHAPES:
