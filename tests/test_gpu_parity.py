@@ -918,6 +918,27 @@ def test_cli_start_inference_on_packed_store(tmp_path):
     assert np.array_equal(res, ref * 100) and float(miou) == float(ref_miou)
 
 
+def test_pipeline_ignores_stale_memory():
+    """No kernel of the pipeline may read memory it (or an earlier kernel of the same run) did not write: filling
+    the caller-owned workspace and the allocator's free blocks with NaN / huge values changes nothing."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20)
+    ann, vf, qf = synth.make_dataset(opt, 9, 2, seed=4, ctx_range=(880, 940))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    ref = inf.device_pipeline(model, store, opt)
+    ref = {k: ref[k].clone() for k in ("rows", "n", "cand", "win_idx")}
+    for val in (float("nan"), 1e30, -7.5):
+        buf = model._ws.buf
+        n4 = (buf.numel() // 4) * 4
+        buf[:n4].view(torch.float32).fill_(val)
+        junk = [torch.full((n,), val, device=buf.device) for n in (1 << 24, 1 << 22, 1 << 20, 1 << 18, 65536, 4096)]
+        del junk
+        got = inf.device_pipeline(model, store, opt)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (val, k)
+
+
 def test_localizer_matches_reference_golden(golden_dir):
     """cone_amd.localizator.CONELocalizator.predict_moment vs the reference's run_on_video output."""
     from cone_amd.localizator import CONELocalizator
