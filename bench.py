@@ -8,14 +8,19 @@
 One "step" = stages A->C (pre-filter, top-k windows, Moment-DETR window model, proposal matching,
 fusion, 3x NMS, JSON rows) over BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic split
 (1 000 queries over 50 videos, ctx_l~U[850,950), window_len 90, d 256, top-k 20 => 20 000 windows,
-NMS 0.5) with every feature already resident in HBM.  With N>1 every rank runs its own split of that
-size (weak scaling; queries are independent) and the kept rows are all-gathered to rank 0 over RCCL,
-which formats the JSON rows of all shards.
+NMS 0.5) with every feature already resident in HBM.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the fp32-MFMA GEMM tile
-that accumulates the most time -- from hipEvent timings taken around each of its launches inside the
-timed region (cone_prof_*), FLOPs = 2*M*N*K with the M actually processed.  `cpu_baseline` times the
-CPU oracle (a torch-CPU port of the reference path) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `value` (weak scaling): every rank runs its own split of that size, the kept
+rows of all shards are all-gathered over RCCL.  Extra objects on the same line:
+  * `roofline`      -- the dominant kernel (the fp32-MFMA GEMM tile that accumulates the most time) priced from
+                       hipEvent timings taken around each of its launches inside the timed region (cone_prof_*),
+                       FLOPs = 2*M*N*K with the M actually processed;
+  * `strong_scaling` (N > 1) -- BASELINE configs[3]: ONE such split sharded by window over the N ranks
+                       (cone_amd.parallel.predict_split_distributed, one all_gather of proposal rows);
+  * `prefilter_mad`, `latency_config1`, `config5` (N = 1) -- BASELINE configs[2], [0] and [4] on one GPU: the
+                       MAD-scale pre-filter against the HBM roofline (1 and 64 queries), the single-query latency,
+                       64 queries x one MAD-length video end to end;
+  * `cpu_baseline`  -- the CPU oracle (a torch-CPU port of the reference path) on a bounded sample.
 """
 import argparse
 import json
@@ -30,16 +35,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from cone_amd import _lib, synth  # noqa: E402
+from cone_amd import _lib, ops, synth  # noqa: E402
 from cone_amd import inference as inf  # noqa: E402
 from cone_amd.config import make_opt  # noqa: E402
 from cone_amd.model import build_model  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0           # same guide: HBM3E peak BW (spec); 6.29 TB/s measured float4 copy
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
-                2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn_kernel", 4: "frame_score_kernel",
+                2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn16_kernel", 4: "frame_score_kernel",
                 5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_kernel"}
 GEMM_KINDS = (0, 1, 2, 5, 6)
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def collect_profile():
@@ -73,17 +80,19 @@ def reference_window_flops(lv, lq, dv, dt, d=256, ff=1024, nq=5, enc=2, dec=2):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/
-    r01_pmc_traffic.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
+    rNN_pmc_traffic.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
     runs; counters cannot be read from inside the process).  Same averaging as `achieved`: over all launches of
     the kernel in a step."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)["cone::" + kernel]
-    except (OSError, KeyError, ValueError):
-        return {"traffic": None}
-    return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
-            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                t = json.load(f)["cone::" + kernel]
+        except (OSError, KeyError, ValueError):
+            continue
+        return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
+                "traffic_source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+    return {"traffic": None}
 
 
 def roofline_from_profile(rec):
@@ -154,6 +163,91 @@ def cpu_baseline(opt, sd, n_queries, n_videos):
                       f"Ego4D-NLQ config, oracle eval_epoch end to end in {dt:.1f} s with {best_t} torch threads"}
 
 
+# ------------------------------------------------------------------------------------------ other BASELINE configs
+def _timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
+    """BASELINE configs[2]: MAD-scale long video (ctx_l x 512 fp32 = 12.7 GB resident in HBM, ~100 k windows of 125
+    clips), frame scores + window max + stable top-30 for 1 query (streaming kernel) and for 64 queries at once
+    (fp32-MFMA GEMM over the clip arena).  Roofline: SURVEY 8d's algorithmic bytes 4*ctx_l*dv + Q*4*(dv + num_window)
+    over the hipEvent time of the frame-score kernel(s) of one query batch (the dominant kernel, > 75 % of the
+    path) and, as `path_frac`, over the wall time of the whole pre-filter call sequence."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(0)
+    vid = torch.randn(ctx_l, dv, device=dev, generator=g)
+    vid = ops.l2_normalize(vid, 0.0)
+    nw = ops.num_windows(ctx_l, W)
+    out = {"workload": f"BASELINE.json configs[2]: one video of ctx_l={ctx_l} clips x d={dv} fp32 "
+                       f"({ctx_l * dv * 4 / 1e9:.1f} GB resident), window_len={W}, {nw} windows, stable top-{topk}"}
+    for nq in (1, 64):
+        txt = ops.l2_normalize(torch.randn(nq, dv, device=dev, generator=g), 0.0)
+
+        def call():
+            fs, ws = ops.prefilter_scores(vid, txt, W)
+            return ops.topk_windows(ws, topk)
+        _timed(call, 1, 2)
+        lib.cone_prof_enable(1)
+        dt, _ = _timed(call, steps, 0)
+        rec = collect_profile()
+        lib.cone_prof_enable(0)
+        k_ms = float(rec[np.isin(rec[:, 0], (0, 4))][:, 4].sum()) / steps        # frame-score launches of one call
+        alg = 4.0 * ctx_l * dv + nq * 4.0 * (dv + nw)
+        ach = alg / (k_ms * 1e-3) / 1e9
+        out[f"q{nq}"] = {"queries": nq, "ms_per_call": round(dt * 1e3, 3), "windows_per_s": round(nw * nq / dt, 1),
+                         "frame_score_kernel_ms": round(k_ms, 3),
+                         "kernel": KERNEL_NAMES[4] if nq == 1 else KERNEL_NAMES[0],
+                         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "algorithmic_bytes": int(alg)},
+                         "path_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        del txt
+    del vid
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_latency_config1(sd_seed=0, steps=20):
+    """BASELINE configs[0]: one query over one video of ctx_l = 900 clips => 22 windows, top-20
+    => B = 20 windows, stages A->C + the JSON rows, as a latency figure."""
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20)
+    model, _ = build_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, sd_seed).items()})
+    ann, vf, qf = synth.make_dataset(opt, 1, 1, seed=0, ctx_range=(900, 901), lq_range=(12, 13))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    dt, (_, dp) = _timed(lambda: inf.predict_split(model, store, opt), steps, 5)
+    return {"workload": "BASELINE.json configs[0]: 1 query x 1 video (ctx_l 900, 22 windows), top-20 => 20 windows, "
+                        "stages A-C + JSON rows", "ms_per_query": round(dt * 1e3, 3),
+            "windows_per_s": round(dp["n_windows"] / dt, 1), "queries_per_s": round(1.0 / dt, 1)}
+
+
+def bench_config5(ctx_l=33_000, queries=64, steps=10):
+    """BASELINE configs[4] on one GPU: 64 concurrent queries over one MAD-length video (ctx_l ~ 33 k clips = 110 min
+    at 5 fps, d 512, window_len 125, top-30 => 1 920 windows), stages A->C + JSON rows."""
+    opt = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=30)
+    model, _ = build_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 1).items()})
+    ann, vf, qf = synth.make_dataset(opt, queries, 1, seed=0, ctx_range=(ctx_l, ctx_l + 1))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    dt, (_, dp) = _timed(lambda: inf.predict_split(model, store, opt), steps, 3)
+    wt = dp["windows"]
+    fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(), 512, 512)
+    return {"workload": f"BASELINE.json configs[4] on 1 GPU: {queries} queries x one MAD-length video (ctx_l {ctx_l}, "
+                        f"d 512, window_len 125), top-30 => {dp['n_windows']} windows, stages A-C + JSON rows",
+            "ms_per_step": round(dt * 1e3, 3), "windows_per_s": round(dp["n_windows"] / dt, 1),
+            "queries_per_s": round(queries / dt, 1),
+            "reference_algorithmic_tflops": round(float(fl.sum()) / dt / 1e12, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,10 +257,13 @@ def main():
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--pipeline_chunks", type=int, default=None,
                     help="query chunks of the host/GPU software pipeline (default: automatic = 1 at this size)")
-    ap.add_argument("--set_option", action="append", default=[], metavar="NAME=0|1",
-                    help="diagnostics: flip an A/B switch of the library (cone_test_set_option), e.g. dec0_const=0")
+    ap.add_argument("--set_option", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostics: flip an A/B switch of the model handle (cone_model_set_option), e.g. pos_tables=0")
     ap.add_argument("--window_batch", type=int, default=32768)
+    ap.add_argument("--need_saliency", action="store_true",
+                    help="A/B: also run the saliency head (the reference computes it and never reads it)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_extras", action="store_true", help="skip the configs[0]/[2]/[4] figures (N = 1)")
     ap.add_argument("--cpu_queries", type=int, default=400)
     args = ap.parse_args()
 
@@ -185,7 +282,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
-                   window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks)
+                   window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks,
+                   need_saliency=args.need_saliency)
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -194,7 +292,7 @@ def main():
     lib = _lib.load()
     for kv in args.set_option:
         name, _, val = kv.partition("=")
-        _lib.check(lib.cone_test_set_option(name.encode(), int(val or 1)))
+        model.set_option(name, int(val or 1))
 
     def step():
         # the product's own driver (cone_amd.inference.predict_split): stages A->C + the submission rows
@@ -216,22 +314,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    lib.cone_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, dp = step()
-    fence()
-    dt = time.perf_counter() - t0
-    rec = collect_profile()
-    lib.cone_prof_enable(0)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_region(fn):
+        """W untimed + exactly K timed steps between barrier + synchronize fences; MAX over ranks."""
+        for _ in range(args.warmup):
+            fn()
+        fence()
+        lib.cone_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        rec = collect_profile()
+        lib.cone_prof_enable(0)
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, rec, res
+
+    dt, rec, (out, dp) = timed_region(step)
     n_windows = dp["n_windows"]
+
+    strong = None
+    if use_dist and world > 1:
+        # BASELINE configs[3]: ONE config-2 split (the same on every rank: features replicated), sharded by window
+        from cone_amd import parallel as par
+        ann0, vf0, qf0 = (ann, vf, qf) if rank == 0 else synth.make_dataset(opt, args.queries, args.videos, seed=0)
+        store0 = store if rank == 0 else inf.FeatureStore(opt, ann0, vf0, qf0)
+
+        def strong_step():
+            return par.predict_split_distributed(model, store0, opt, mode="window", format_shard=True)
+        sdt, _, (_, sinfo) = timed_region(strong_step)
+        strong = {"config": "BASELINE.json configs[3]: ONE Ego4D-NLQ val-scale split sharded by window over the ranks, "
+                            "one RCCL all_gather of the per-window proposal rows, fusion + NMS of all queries on every "
+                            "rank, JSON rows of its own query shard on every rank",
+                  "scaling": "strong", "value": round(sinfo["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
+                  "queries_per_s": round(args.queries * args.steps / sdt, 1),
+                  "ms_per_step": round(sdt / args.steps * 1e3, 2), "n_windows": sinfo["n_windows"],
+                  "ranks_seen": dist.get_world_size(), "collectives_per_step": 1}
 
     if rank == 0:
         roof, kern = roofline_from_profile(rec)
@@ -247,9 +368,17 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic, "
                                    f"{args.queries} queries x {args.videos} videos per GPU, window_len=90, d=256, "
                                    f"topk_window=20, NMS 0.5, {n_windows} windows per GPU per step",
-                       "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture"},
+                       "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture",
+                       "outputs": "per window pred_logits, pred_spans, matching scores -> rows [st, ed, proposal, "
+                                  "matching]; per query fused / proposal / matching top-5 after NMS as JSON rows"
+                                  + ("; saliency head computed too" if args.need_saliency else
+                                     "; saliency and aux (intermediate-layer) heads not computed -- the reference "
+                                     "computes them and never reads them (cone/inference.py:54-59)"),
+                       "ranks_seen": dist.get_world_size() if use_dist else 1},
             "roofline": roof, "kernels": kern,
         }
+        if strong is not None:
+            res["strong_scaling"] = strong
         wt = dp.get("windows")
         if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
             fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),
@@ -260,6 +389,13 @@ def main():
                                    "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
                                    "note": "reference FLOPs (padding excluded) over the whole step time; the build "
                                            "executes fewer (de-duplicated projections, folded decoder K/V)"}
+        if world == 1 and not args.no_extras:
+            del store, dp, out
+            model._ws.buf = None
+            torch.cuda.empty_cache()
+            res["latency_config1"] = bench_latency_config1()
+            res["config5"] = bench_config5()
+            res["prefilter_mad"] = bench_prefilter_mad()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_queries, max(1, args.cpu_queries * args.videos // args.queries))
         print(json.dumps(res))

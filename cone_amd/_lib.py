@@ -54,7 +54,8 @@ class Weights(C.Structure):
 
 
 class Layer0(C.Structure):
-    _fields_ = [("qkv_vid", C.c_void_p), ("qkv_txt", C.c_void_p), ("pos_qk", C.c_void_p), ("max_v_l", C.c_int32)]
+    _fields_ = [("qkv_vid", C.c_void_p), ("qkv_txt", C.c_void_p), ("pos_qk", C.c_void_p), ("pos_rows", C.c_void_p),
+                ("max_v_l", C.c_int32)]
 
 
 class Taps(C.Structure):
@@ -86,12 +87,12 @@ _SIGNATURES = {
     "cone_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Taps),
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cone_forward_packed_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cone_forward_packed_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Layer0)]),
     "cone_forward_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(Taps), C.POINTER(Layer0), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cone_layer0_pos_rows": (C.c_int64, [C.c_int]),
-    "cone_layer0_pos_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_pos_table_rows": (C.c_int64, [C.c_int]),
+    "cone_pos_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_layer0_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cone_clip_matching_workspace": (C.c_size_t, [C.c_void_p, C.c_int]),
     "cone_clip_matching_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -115,7 +116,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_eval_window_recall": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_void_p]),
-    "cone_test_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "cone_model_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     # cone_test_gemm(A, A2, a2_mod, W, bias, R, ln_g, ln_b, C, C2, ADD, M, N, K, flags, stream)
     "cone_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -149,7 +150,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 1:
+    if lib.cone_abi_version() != 2:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

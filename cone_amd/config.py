@@ -114,9 +114,14 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def parse_test_options(argv=None) -> SimpleNamespace:
-    """``TestOptions().parse()``: options saved beside the checkpoint win, except
-    the CLI_WINS whitelist (cone/config.py:184-196)."""
+    """``TestOptions().parse()`` (cone/config.py:175-222): ``--debug`` redirects results_root and zeroes
+    num_workers (:179-181); options saved beside the checkpoint win, except the CLI_WINS whitelist (:184-193);
+    ``results_dir`` stays the SAVED one unless ``--eval_results_dir`` is given (:194-195) -- a checkpoint directory
+    whose opt.json carries no results_dir falls back to the checkpoint's own directory."""
     opt = build_parser().parse_args(argv)
+    if opt.debug:
+        opt.results_root = os.path.sep.join(opt.results_root.split(os.path.sep)[:-1] + ["debug_results"])
+        opt.num_workers = 0
     if opt.resume is None:
         raise ValueError("--resume <ckpt> is required at inference")
     opt.model_dir = os.path.dirname(opt.resume)
@@ -125,6 +130,9 @@ def parse_test_options(argv=None) -> SimpleNamespace:
     for k, v in saved.items():
         if k not in CLI_WINS:
             setattr(opt, k, v)
-    opt.results_dir = opt.eval_results_dir if opt.eval_results_dir is not None else opt.model_dir
+    if opt.eval_results_dir is not None:
+        opt.results_dir = opt.eval_results_dir
+    elif not getattr(opt, "results_dir", None):
+        opt.results_dir = opt.model_dir
     opt.pin_memory = not opt.no_pin_memory
     return opt

@@ -43,6 +43,12 @@ struct cone_model {
     cone::Linear dec_k, dec_v;
     // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
     const float* dec_vT[CONE_MAX_LAYERS] = {};
+    // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
+    int opt_dec_fold = 1;     // decoder memory K/V projections folded into the cross-attention kernel
+    int opt_dec0_const = 1;   // first decoder layer's window-independent rows computed once and replicated
+    int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
+    int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
+    int opt_gemm = 0;         // GEMM tile family forced for every dense layer (GEMM_AUTO = by shape)
 };
 
 namespace cone {
@@ -201,11 +207,12 @@ struct Carver {
     }
 };
 
-static GemmArgs G(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
-                  const int* M_dev, int N, int K, int flags = 0) {
+static GemmArgs G(const cone_model* m, const float* A, int lda, const float* W, int ldw, const float* bias, float* C,
+                  int ldc, int M, const int* M_dev, int N, int K, int flags = 0) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.M_dev = M_dev; g.N = N; g.K = K; g.flags = flags;
+    g.variant = m ? m->opt_gemm : GEMM_AUTO;
     return g;
 }
 
@@ -233,7 +240,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
     for (int i = 0; i < m->n_proj; ++i) {
         const bool last = i == m->n_proj - 1;
         float* dst = last ? out : (cur == ta ? tb : ta);
-        GemmArgs g = G(cur, K, lin[i].w, K, lin[i].b, dst, 256, (int)n, nullptr, 256, K, last ? 0 : EPI_RELU);
+        GemmArgs g = G(m, cur, K, lin[i].w, K, lin[i].b, dst, 256, (int)n, nullptr, 256, K, last ? 0 : EPI_RELU);
         if (!last) { g.flags |= EPI_LN; g.ln_g = lns[i + 1].g; g.ln_b = lns[i + 1].b; }
         RUN(launch_gemm(g, s));
         cur = dst;
@@ -243,33 +250,49 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 }
 
 // ------------------------------------------------------------------------------ packed forward
-static int g_dec_fold = 1;   // test hook (cone_test_set_option "dec_fold"): 0 = separate K/V GEMMs + small_attn
-static int g_dec0_const = 1; // test hook ("dec0_const"): 0 = first decoder layer's window-independent rows per window
-static int g_l0_gather = 1;  // test hook ("l0_gather"): 0 = pack_l0 writes q|k|v to HBM for the plain attention kernel
-
+// Workspace of one batch of B windows (M = B * Lmax token rows at most).  Two layouts:
+//   table path (layer-0 cache + position tables; the eval driver): X, X1 and ONE (M, ff) region that holds, in
+//     turn, the layer's q|k|v (M, 768) + attention output (M, 256) and then the FFN hidden rows -- q|k|v are dead
+//     once the attention has run, its output once out_proj has, and FFN1 writes only after that: 4 * (2 * 256 +
+//     max(ff, 1024)) = 6 KiB per token row at ff = 1024;
+//   legacy path (no cache: cone_forward_windows, and the A/B switches of the parity tests): additionally POS and
+//     XP = X + POS, and the stacked decoder K / V rows when the cross-attention fold is off.
 struct FwdBuffers {
     int* off;
-    float *X, *POS, *XP, *QK, *V, *ATT, *X1, *H, *KD, *VD;
+    float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
     float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP;
 };
-static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, FwdBuffers& f) {
+struct FwdPlan { bool tables, fold; };
+static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
+    FwdPlan p;
+    p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && m->opt_l0_gather;
+    p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax);
+    if (!p.fold) p.tables = false;      // the unfolded decoder projects keys from memory + pos rows
+    return p;
+}
+static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const FwdPlan& p, FwdBuffers& f) {
     const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
+    const size_t wide = m->ff > 1024 ? m->ff : 1024;
     f.off = c.take<int>(B + 1);
-    f.X = c.take<float>(M * 256); f.POS = c.take<float>(M * 256); f.XP = c.take<float>(M * 256);
-    f.QK = c.take<float>(M * 512);
-    f.V = c.take<float>(M * 256); f.ATT = c.take<float>(M * 256); f.X1 = c.take<float>(M * 256);
-    f.H = c.take<float>(M * m->ff);
-    f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd);
+    f.X = c.take<float>(M * 256); f.X1 = c.take<float>(M * 256);
+    f.H = c.take<float>(M * wide);
+    f.QKV = f.H; f.ATT = f.H + M * 768;            // aliases of the FFN hidden region (see above)
+    f.POS = f.XP = f.KD = f.VD = nullptr;
+    if (!p.tables) {
+        f.POS = c.take<float>(M * 256); f.XP = c.take<float>(M * 256);
+        f.QKV = c.take<float>(M * 768); f.ATT = c.take<float>(M * 256);
+    }
+    if (!p.fold) { f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd); }
     f.TGT = c.take<float>(T * 256); f.TGT1 = c.take<float>(T * 256); f.TGT2 = c.take<float>(T * 256);
     f.DQK = c.take<float>(T * 512); f.DV = c.take<float>(T * 256); f.DATT = c.take<float>(T * 256);
     f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
     f.HS = c.take<float>(nd * T * 256); f.S1 = c.take<float>(nd * T * 256); f.S2 = c.take<float>(nd * T * 256);
     f.LG = c.take<float>(nd * T * 2); f.SP = c.take<float>(nd * T * 2);
 }
-static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax) {
+static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax, const FwdPlan& p) {
     Carver c(nullptr, ~(size_t)0);
     FwdBuffers f;
-    carve_fwd(m, c, B, Lmax, f);
+    carve_fwd(m, c, B, Lmax, p, f);
     return c.cur;
 }
 
@@ -281,21 +304,26 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int Lmax = Lv_max + Lq_max;
     CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
     CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
+    if (l0)
+        CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
+                     "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
+    const FwdPlan plan = plan_of(m, l0, Lmax);
     Carver c(ws, ws_bytes);
     FwdBuffers f;
-    carve_fwd(m, c, B, Lmax, f);
+    carve_fwd(m, c, B, Lmax, plan, f);
     if (!c.ok) { set_error("forward: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     const int Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
     const int* Mdev = f.off + B;
+    const size_t pos_rows_n = l0 ? (size_t)l0->max_v_l * (l0->max_v_l + 1) / 2 : 0;
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
+    const bool gather0 = l0 && m->opt_l0_gather;
     if (l0) {
-        CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
-                     "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
-        // X and POS only: the first layer's attention gathers q|k|v from the caches itself (g_l0_gather, default)
+        // X (and, off the table path, POS): the first layer's attention gathers q|k|v from the caches itself; with
+        // the gather switched off a packing pass writes them out first
         RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, l0->qkv_vid, l0->qkv_txt,
-                           l0->pos_qk, f.X, f.POS, g_l0_gather ? nullptr : f.QK, g_l0_gather ? nullptr : f.V, B, Lmax,
-                           s));
+                           l0->pos_qk, f.X, f.POS, gather0 ? nullptr : f.QKV, gather0 ? nullptr : f.QKV + (size_t)Mmax * 512,
+                           B, Lmax, s));
     } else {
         RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
     }
@@ -303,34 +331,48 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     for (int l = 0; l < m->n_enc; ++l) {  // cone/transformer.py:233-246
         const EncLayer& e = m->enc[l];
         GemmArgs g;
-        if (l > 0 || !l0) {
-            g = G(f.XP, 256, e.sa.in_w, 256, e.sa.in_b, f.QK, 512, Mmax, Mdev, 512, 256);
-            RUN(launch_gemm(g, s));                                                         // q | k = (x+pos) W^T
-            RUN(launch_gemm(G(f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, f.V, 256, Mmax, Mdev, 256, 256), s));
+        AttnSrc src{};
+        int mode = ATTN_PACKED;
+        if (l == 0 && gather0) {
+            mode = ATTN_GATHER;
+            src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.pos_qk = l0->pos_qk;
+            src.vrow0 = vrow0; src.vlen = vlen; src.trow0 = trow0;
+        } else if (l == 0 && l0) {                         // packed by pack_l0: (M, 512) q|k then (M, 256) v
+            src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + (size_t)Mmax * 512;
+            src.ldq = src.ldk = 512; src.ldv = 256;
+        } else if (plan.tables) {
+            // q | k | v = x W^T + b in ONE N = 768 GEMM on x; the attention adds pos W_qk^T of this layer from the
+            // static table ((x + pos) W^T = x W^T + pos W^T): no x + pos matrix, no second A operand
+            RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
+            mode = ATTN_POSADD;
+            src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + 512; src.ldq = src.ldk = src.ldv = 768;
+            src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512; src.vlen = vlen;
+        } else {
+            float* QK = f.QKV; float* V = f.QKV + (size_t)Mmax * 512;
+            RUN(launch_gemm(G(m, f.XP, 256, e.sa.in_w, 256, e.sa.in_b, QK, 512, Mmax, Mdev, 512, 256), s));  // q | k = (x+pos) W^T
+            RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, V, 256, Mmax, Mdev, 256, 256), s));
+            src.Q = QK; src.K = QK + 256; src.V = V; src.ldq = src.ldk = 512; src.ldv = 256;
         }
-        if (l == 0 && l0 && g_l0_gather)
-            RUN(launch_enc_attn_l0(l0->qkv_vid, l0->qkv_txt, l0->pos_qk, vrow0, vlen, trow0, f.ATT, f.off, B, Lmax, s));
-        else
-            RUN(launch_enc_attn(f.QK, f.V, f.ATT, f.off, B, Lmax, s));
-        g = G(f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
+        RUN(launch_enc_attn(mode, src, f.ATT, f.off, B, Lmax, s));
+        g = G(m, f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.X; g.ldr = 256; g.ln_g = e.n1.g; g.ln_b = e.n1.b;
         RUN(launch_gemm(g, s));                                                             // norm1(x + attn)
-        RUN(launch_gemm(G(f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
-        g = G(f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
+        RUN(launch_gemm(G(m, f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
+        g = G(m, f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
         g.R = f.X1; g.ldr = 256; g.ln_g = e.n2.g; g.ln_b = e.n2.b;
-        g.C2 = f.XP; g.ADD = f.POS;     // and x + pos for the next layer's q/k (or the decoder's keys)
+        if (!plan.tables) { g.C2 = f.XP; g.ADD = f.POS; }   // x + pos for the next layer's q/k / the decoder's keys
         RUN(launch_gemm(g, s));                                                             // norm2(x + ffn)
     }
     const float* MEM = f.X;
 
     // decoder (cone/transformer.py:296-317, 117-146).  Default: the memory K / V projections are folded into
     // the cross-attention kernel (dec_cross.hip); otherwise memory K/V for all layers in two GEMMs.
-    const bool fold = g_dec_fold && dec_cross_supported(m->nq, Lmax);
+    const bool fold = plan.fold;
     const bool want_aux = taps && (taps->hs || taps->aux_logits || taps->aux_spans);
     if (!fold) {
-        GemmArgs g = G(f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
+        GemmArgs g = G(m, f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
-        RUN(launch_gemm(G(MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
+        RUN(launch_gemm(G(m, MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
     }
     CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
     for (int l = 0; l < nd; ++l) {
@@ -338,17 +380,17 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         // Layer 0 starts from tgt = 0 (cone/transformer.py:66): its self-attention block and its cross-attention
         // queries do not depend on the window.  They are computed for ONE window's nq rows by the same kernels
         // (rows of a GEMM are independent: identical bits) and replicated, instead of T = B*nq identical rows.
-        const int Tq = (l == 0 && g_dec0_const) ? m->nq : T;
-        const int Bq = (l == 0 && g_dec0_const) ? 1 : B;
-        GemmArgs g = G(f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, Tq, nullptr, 512, 256);
+        const int Tq = (l == 0 && m->opt_dec0_const) ? m->nq : T;
+        const int Bq = (l == 0 && m->opt_dec0_const) ? 1 : B;
+        GemmArgs g = G(m, f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, Tq, nullptr, 512, 256);
         g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
         RUN(launch_gemm(g, s));
-        RUN(launch_gemm(G(f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, Tq, nullptr, 256, 256), s));
+        RUN(launch_gemm(G(m, f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, Tq, nullptr, 256, 256), s));
         RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, Bq, m->nq, m->nq, s));
-        g = G(f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, Tq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+        g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, Tq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
         RUN(launch_gemm(g, s));
-        g = G(f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, Tq, nullptr, 256, 256);
+        g = G(m, f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, Tq, nullptr, 256, 256);
         g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
         RUN(launch_gemm(g, s));
         if (Tq != T) {
@@ -356,16 +398,16 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             RUN(launch_tile_rows(f.DQ, m->nq, T, s));
         }
         if (fold)
-            RUN(launch_dec_cross(f.DQ, f.XP, MEM, f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B,
-                                 m->nq, Lmax, s));
+            RUN(launch_dec_cross(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
+                                 f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, s));
         else
             RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
                                   m->nq, Lmax, s));
-        g = G(f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+        g = G(m, f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT1; g.ldr = 256; g.ln_g = dl.n2.g; g.ln_b = dl.n2.b;
         RUN(launch_gemm(g, s));
-        RUN(launch_gemm(G(f.TGT2, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
-        g = G(f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
+        RUN(launch_gemm(G(m, f.TGT2, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
+        g = G(m, f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
         g.R = f.TGT2; g.ldr = 256; g.ln_g = dl.n3.g; g.ln_b = dl.n3.b;
         RUN(launch_gemm(g, s));
         // decoder.norm + heads on an intermediate layer only feed aux_outputs / the hs tap (unused by inference,
@@ -379,8 +421,8 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int HT = (nd - h0) * T;
     const size_t hoff = (size_t)h0 * T;
     RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, f.LG + hoff * 2, 2, HT, 2, 0, s));
-    RUN(launch_gemm(G(f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
-    RUN(launch_gemm(G(f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_gemm(G(m, f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
     RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP + hoff * 2, 2, HT, 2, 1, s));
     const size_t last = (size_t)(nd - 1) * T * 2;
     CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -439,8 +481,8 @@ extern "C" int cone_adapter_norm(const cone_model* m, const float* x, int64_t n_
     float* h = c.take<float>((size_t)n_rows * 256);
     float* y = c.take<float>((size_t)n_rows * m->dv);
     if (!c.ok) { set_error("adapter_norm: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
-    RUN(launch_gemm(G(x, m->dv, m->adapter[0].w, m->dv, m->adapter[0].b, h, 256, (int)n_rows, nullptr, 256, m->dv, EPI_RELU), s));
-    GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, renorm ? y : out, m->dv, (int)n_rows, nullptr, m->dv,
+    RUN(launch_gemm(G(m, x, m->dv, m->adapter[0].w, m->dv, m->adapter[0].b, h, 256, (int)n_rows, nullptr, 256, m->dv, EPI_RELU), s));
+    GemmArgs g = G(m, h, 256, m->adapter[1].w, 256, m->adapter[1].b, renorm ? y : out, m->dv, (int)n_rows, nullptr, m->dv,
                    256, EPI_RESIDUAL);
     g.R = x; g.ldr = m->dv;
     RUN(launch_gemm(g, s));
@@ -463,8 +505,9 @@ extern "C" int cone_project_tokens(const cone_model* m, int which, const float* 
     return project_tokens(m, which, x, n_rows, out, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max) {
-    return fwd_ws_bytes(m, B, Lv_max + Lq_max);
+extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
+                                                const cone_layer0* l0) {
+    return fwd_ws_bytes(m, B, Lv_max + Lq_max, plan_of(m, l0, Lv_max + Lq_max));
 }
 extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                                    const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
@@ -477,26 +520,25 @@ extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, cons
                           saliency, taps, ws, ws_bytes, (hipStream_t)stream, l0);
 }
 
-extern "C" int64_t cone_layer0_pos_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2; }
+extern "C" int64_t cone_pos_table_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2; }
 
-extern "C" int cone_layer0_pos_table(const cone_model* m, int max_v_l, float* pos_qk, void* ws, size_t ws_bytes,
-                                     void* stream) {
-    CONE_REQUIRE(m && pos_qk && max_v_l >= 1 && max_v_l <= 192, "layer0_pos_table: bad argument");
-    const int64_t rows = cone_layer0_pos_rows(max_v_l);
-    Carver c(ws, ws_bytes);
-    float* pr = c.take<float>((size_t)rows * 256);
-    if (!c.ok) { set_error("layer0_pos_table: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+extern "C" int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream) {
+    CONE_REQUIRE(m && pos_rows && pos_qk && max_v_l >= 1 && max_v_l <= 192, "pos_tables: bad argument");
+    const int64_t rows = cone_pos_table_rows(max_v_l);
     hipStream_t s = (hipStream_t)stream;
-    RUN(launch_pos_rows(m->dim_t, max_v_l, pr, s));
-    // pos W_q^T | pos W_k^T, no bias (the bias travels with the clip / token rows)
-    return launch_gemm(G(pr, 256, m->enc[0].sa.in_w, 256, nullptr, pos_qk, 512, (int)rows, nullptr, 512, 256), s);
+    RUN(launch_pos_rows(m->dim_t, max_v_l, pos_rows, s));
+    // pos W_q^T | pos W_k^T of every encoder layer, no bias (the bias travels with the clip / token rows)
+    for (int l = 0; l < m->n_enc; ++l)
+        RUN(launch_gemm(G(m, pos_rows, 256, m->enc[l].sa.in_w, 256, nullptr, pos_qk + (size_t)l * rows * 512, 512,
+                          (int)rows, nullptr, 512, 256), s));
+    return 0;
 }
 
 extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv,
                                    void* stream) {
     CONE_REQUIRE(m && proj_rows && qkv && n_rows < (1ll << 31), "layer0_project: bad argument");
     if (n_rows <= 0) return 0;
-    return launch_gemm(G(proj_rows, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, qkv, 768, (int)n_rows, nullptr,
+    return launch_gemm(G(m, proj_rows, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, qkv, 768, (int)n_rows, nullptr,
                          768, 256), (hipStream_t)stream);
 }
 
@@ -505,8 +547,8 @@ extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad,
     size_t pw = project_ws_bytes(m, 0, nv);
     const size_t pt = project_ws_bytes(m, 1, nt);
     if (pt > pw) pw = pt;
-    return fwd_ws_bytes(m, B, Lv_pad + Lq_pad) + pw + align_up(nv * 256 * 4, 256) + align_up(nt * 256 * 4, 256) +
-           2 * align_up((size_t)B * 4, 256);
+    return fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_of(m, nullptr, Lv_pad + Lq_pad)) + pw + align_up(nv * 256 * 4, 256) +
+           align_up(nt * 256 * 4, 256) + 2 * align_up((size_t)B * 4, 256);
 }
 extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len, const float* txt,
                                     const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,
@@ -556,8 +598,8 @@ extern "C" int cone_clip_matching_gathered(const cone_model* m, const float* cls
     RUN(launch_proposal_mean(vid, vid_row0, vid_len, pad_len, spans, B, m->nq, dv, pf, s));
     const float* feat = pf;
     if (m->has_adapter) {
-        RUN(launch_gemm(G(pf, dv, m->adapter[0].w, dv, m->adapter[0].b, h, 256, T, nullptr, 256, dv, EPI_RELU), s));
-        GemmArgs g = G(h, 256, m->adapter[1].w, 256, m->adapter[1].b, pa, dv, T, nullptr, dv, 256, EPI_RESIDUAL);
+        RUN(launch_gemm(G(m, pf, dv, m->adapter[0].w, dv, m->adapter[0].b, h, 256, T, nullptr, 256, dv, EPI_RELU), s));
+        GemmArgs g = G(m, h, 256, m->adapter[1].w, 256, m->adapter[1].b, pa, dv, T, nullptr, dv, 256, EPI_RESIDUAL);
         g.R = pf; g.ldr = dv;
         RUN(launch_gemm(g, s));
         feat = pa;
@@ -581,13 +623,17 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
                                        (char*)ws + c.cur, ws_bytes - c.cur, stream);
 }
 
-extern "C" int cone_test_set_option(const char* name, int value) {
-    CONE_REQUIRE(name, "set_option: null name");
-    if (!strcmp(name, "dec_fold")) { cone::g_dec_fold = value != 0; return 0; }
-    if (!strcmp(name, "l0_gather")) { cone::g_l0_gather = value != 0; return 0; }
-    if (!strcmp(name, "attn16")) { cone::set_attn16(value); return 0; }
-    if (!strcmp(name, "dec0_const")) { cone::g_dec0_const = value != 0; return 0; }
-    if (!strcmp(name, "gemm_waves")) { cone::set_gemm_rows_waves(value); return 0; }
+extern "C" int cone_model_set_option(cone_model* m, const char* name, int value) {
+    CONE_REQUIRE(m && name, "set_option: null argument");
+    if (!strcmp(name, "dec_fold")) { m->opt_dec_fold = value != 0; return 0; }
+    if (!strcmp(name, "l0_gather")) { m->opt_l0_gather = value != 0; return 0; }
+    if (!strcmp(name, "dec0_const")) { m->opt_dec0_const = value != 0; return 0; }
+    if (!strcmp(name, "pos_tables")) { m->opt_pos_tables = value != 0; return 0; }
+    if (!strcmp(name, "gemm")) {
+        CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
+        m->opt_gemm = value;
+        return 0;
+    }
     cone::set_error("set_option: unknown option '%s'", name);
     return CONE_E_INVALID;
 }
@@ -595,14 +641,11 @@ extern "C" int cone_test_set_option(const char* name, int value) {
 extern "C" int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
                               const float* R, const float* ln_g, const float* ln_b, float* C, float* C2,
                               const float* ADD, int M, int N, int K, int flags, void* stream) {
-    set_gemm_variant((flags >> 8) & 3);   // test hook: bits 8-9 pick the tile family (0 auto)
-    flags &= 0xff;
-    GemmArgs g = G(A, K, W, K, bias, C, N, M, nullptr, N, K, flags);
+    GemmArgs g = G(nullptr, A, K, W, K, bias, C, N, M, nullptr, N, K, flags & 0xff);
+    g.variant = (flags >> 8) & 3;          // test hook: bits 8-9 pick the tile family (0 automatic)
     g.A2 = A2; g.lda2 = K; g.a2_mod = a2_mod; g.R = R; g.ldr = N; g.ln_g = ln_g; g.ln_b = ln_b;
     g.C2 = C2; g.ADD = ADD;
-    const int rc = launch_gemm(g, (hipStream_t)stream);
-    set_gemm_variant(0);
-    return rc;
+    return launch_gemm(g, (hipStream_t)stream);
 }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                                    int dim, void* stream) {

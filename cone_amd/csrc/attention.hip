@@ -1,6 +1,6 @@
 // Multi-head attention cores of the Moment-DETR window model (head_dim = 32).
 //
-//   enc_attn_kernel   : encoder self-attention (cone/transformer.py:233-240 -> nn.MultiheadAttention),
+//   enc_attn16_kernel : encoder self-attention (cone/transformer.py:233-240 -> nn.MultiheadAttention),
 //                       one workgroup per (window, head) over the window's PACKED tokens
 //                       (video clips then text tokens; padded keys simply do not exist, which is what
 //                       the reference's -inf key_padding_mask amounts to).
@@ -8,185 +8,29 @@
 //                       (cone/transformer.py:296-311): self-attention over the slots and
 //                       cross-attention to the window's memory tokens.
 //
-// enc_attn_kernel layout (exact-fp32 MFMA 32x32x2):
-//   S^T = K . Q^T is computed with the KEY on the accumulator rows and the QUERY on the lanes, so a
-//   lane owns one query column: the row softmax is an in-register reduction plus ONE cross-half
-//   shuffle (lane ^ 32), and the probability registers are directly the A operand of O = P . V
-//   (the MFMA k index may be permuted freely as long as A and B agree, and the accumulator row
-//   pattern (r&3)+8(r>>2)+4(lane>>5) is used as that permutation).  K is staged in LDS as
-//   [key][33] (odd stride: conflict-free lane==key reads), V as [key][32] (lane==d reads).
+// enc_attn16_kernel layout (exact-fp32 MFMA 16x16x4), one wave per 16-query tile, workgroup = ceil(Lmax/16) waves:
+//   a window of 101 tokens pads to 112 x 112 scores, a wave keeps 4 registers per key tile.
+//   S^T tile: A = K (keys on accumulator rows 4g + r, g = lane / 16), B = Q^T (query = lane % 16): a lane owns one
+//             query column, so the row softmax is an in-register reduction plus two cross-group shuffles, and the
+//             probability registers are directly the A operand of O = P . V (k slot g <-> key 4g + r of the tile;
+//             the MFMA k index may be permuted freely as long as A and B agree).  The head dim is walked as
+//             d = 8 g + step so that a lane's 8 query values are two contiguous float4.
+//   P.V     : V rows are read at stride 36 floats, K is staged d-major [32][KP + 2]: both conflict-free for
+//             ds_read_b32.
 #include "common.h"
 
 namespace cone {
 
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
 
-// GATHER = true (first encoder layer with the layer-0 cache): q|k|v of a token are not read from packed (M, .)
-// matrices but straight from the per-clip / per-token projection caches, q and k of a clip plus the static
-// pos.W_qk^T row of its (window length, position) -- the gather that pack_l0_kernel would otherwise write out
-// to HBM (6 KB per token written and read back) happens in the staging loads.  Same adds, same results.
-struct L0Gather {
-    const float* qkv_vid;   // (n_clips, 768)  q | k | v
-    const float* qkv_txt;   // (n_tokens, 768)
-    const float* pos_qk;    // (W(W+1)/2, 512) row lv(lv-1)/2 + p
-    const int* vrow0;
-    const int* vlen;
-    const int* trow0;
-};
-
-static int g_attn16 = 1;   // test hook (cone_test_set_option "attn16"): 0 = the 32x32x2 kernel below
-void set_attn16(int v) { g_attn16 = v != 0; }
-
-template <int NKB, bool GATHER>
-__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const float* __restrict__ QK,  // (M,512): q | k
-                                                       const float* __restrict__ V,   // (M,256)
-                                                       float* __restrict__ OUT,       // (M,256)
-                                                       const int* __restrict__ off, L0Gather g) {
-    __shared__ float Ks[NKB * 32 * 33];
-    __shared__ __attribute__((aligned(16))) float Vs[NKB * 32 * 32];
-    const int b = blockIdx.x, head = blockIdx.y;
-    const int t0 = off[b];
-    const int L = off[b + 1] - t0;
-    const int nkb = (L + 31) >> 5;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
-    if (GATHER) { lv = g.vlen[b]; vr0 = g.vrow0[b]; tr0 = g.trow0[b]; pbase = lv * (lv - 1) / 2; }
-    // source row of token `tok` for column block `col` (0 = q, 256 = k, 512 = v) + its additive pos row (or null)
-    auto src_of = [&](int tok, int col, const float*& add) -> const float* {
-        if (tok < lv) {
-            add = col < 512 ? g.pos_qk + (size_t)(pbase + tok) * 512 + col : nullptr;
-            return g.qkv_vid + (size_t)(vr0 + tok) * 768 + col;
-        }
-        add = nullptr;
-        return g.qkv_txt + (size_t)(tr0 + tok - lv) * 768 + col;
-    };
-
-    {   // stage K (transposing scalar writes, stride 33) and V (float4) for all keys of the window
-        const int kr = tid >> 3, c = tid & 7;
-        for (int key = kr; key < nkb * 32; key += 32) {
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < L) {
-                if (GATHER) {
-                    const float* add;
-                    const float* kp_ = src_of(key, 256, add);
-                    kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
-                    vv = *reinterpret_cast<const float4*>(kp_ + 256 + head * 32 + c * 4);
-                    if (add) {
-                        const float4 t = *reinterpret_cast<const float4*>(add + head * 32 + c * 4);
-                        kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
-                    }
-                } else {
-                    kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
-                    vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
-                }
-            }
-            float* kd = Ks + key * 33 + c * 4;
-            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-            *reinterpret_cast<float4*>(Vs + key * 32 + c * 4) = vv;
-        }
-    }
-    __syncthreads();
-
-    for (int qb = wave; qb < nkb; qb += 4) {
-        // this lane's query row, dims 16*lh .. 16*lh+15, pre-scaled
-        float qv[16];
-        {
-            int qrow = qb * 32 + li;
-            qrow = qrow < L ? qrow : L - 1;
-            const float* qadd = nullptr;
-            const float* qp = GATHER ? src_of(qrow, 0, qadd) + head * 32 + 16 * lh
-                                     : QK + (size_t)(t0 + qrow) * 512 + head * 32 + 16 * lh;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float4 x = reinterpret_cast<const float4*>(qp)[u];
-                if (GATHER && qadd) {
-                    const float4 t = reinterpret_cast<const float4*>(qadd + head * 32 + 16 * lh)[u];
-                    x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
-                }
-                qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
-                qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
-            }
-        }
-        f32x16 sc[NKB];
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
-            if (kb < nkb) {
-                const float* kp = Ks + (kb * 32 + li) * 33 + 16 * lh;
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], qv[t], sc[kb], 0, 0, 0);
-            }
-        }
-        // softmax over keys: registers (half of each key block) + the other half-wave.  Only the last key
-        // block can hold padding; exp(s - m) is one fma + one v_exp_f32 (exp2((s - m) * log2 e)).
-        float m = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-            if (kb < nkb) {
-                if (kb == nkb - 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kb * 32 + acc_row(r, lane) >= L) sc[kb][r] = -INFINITY;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[kb][r]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float m2 = m * 1.4426950408889634f;
-        float l = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-            if (kb < nkb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], 1.4426950408889634f, -m2));
-                    sc[kb][r] = e;
-                    l += e;
-                }
-            }
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-            if (kb < nkb) {
-                const float* vp = Vs + (kb * 32 + 4 * lh) * 32 + li;
-                // k-step t covers keys (t&3)+8(t>>2) (+4 on the upper half-wave): past the window's last key the
-                // probabilities are exactly 0, so the ragged last block stops early (uniform branch)
-                const int rem = L - kb * 32;
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if ((t & 3) + 8 * (t >> 2) < rem)
-                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kb][t] * inv, vp[((t & 3) + 8 * (t >> 2)) * 32],
-                                                                 o, 0, 0, 0);
-            }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qrow = qb * 32 + acc_row(r, lane);
-            if (qrow < L) OUT[(size_t)(t0 + qrow) * 256 + head * 32 + li] = o[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 16x16x4 variant (default): one wave per 16-query tile, workgroup = ceil(Lmax/16) waves.  A window of 101 tokens
-// pads to 112 x 112 scores instead of 128 x 128 (-23 % MFMA and exp work), a wave keeps only 4 registers per key
-// tile (7 waves x <= 96 VGPRs: twice the resident waves of the 32x32 kernel) and the per-wave critical path halves.
-//   S^T tile: A = K (keys on accumulator rows 4g + r, g = lane / 16), B = Q^T (query = lane % 16); the head dim
-//             is walked as d = 8 g + step so that a lane's 8 query values are two contiguous float4.
-//   P.V     : the probability registers are the A operand again (k slot g <-> key 4g + r of the tile); V rows are
-//             read at stride 36 floats, K is staged d-major [32][KP + 2]: both conflict-free for ds_read_b32.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-template <int NKT, bool GATHER>
-__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __restrict__ QK, const float* __restrict__ V,
-                                                             float* __restrict__ OUT, const int* __restrict__ off,
-                                                             L0Gather g) {
+// MODE: ATTN_PACKED / ATTN_GATHER / ATTN_POSADD (common.h).  In the two table modes the q | k rows of a clip token
+// get the static row pos_qk[(lv, p)] added in the staging loads -- the adds the reference performs as
+// ``q = k = src + pos`` ahead of in_proj (cone/transformer.py:237), moved behind the (linear) projection.
+template <int NKT, int MODE>
+__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
+                                                                 const int* __restrict__ off) {
     constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
     __shared__ float KsT[32 * LDK];
     __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
@@ -198,14 +42,17 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
-    if (GATHER) { lv = g.vlen[b]; vr0 = g.vrow0[b]; tr0 = g.trow0[b]; pbase = lv * (lv - 1) / 2; }
-    auto src_of = [&](int tok, int col, const float*& add) -> const float* {
-        if (tok < lv) {
-            add = col < 512 ? g.pos_qk + (size_t)(pbase + tok) * 512 + col : nullptr;
-            return g.qkv_vid + (size_t)(vr0 + tok) * 768 + col;
+    if (MODE != ATTN_PACKED) { lv = a.vlen[b]; pbase = lv * (lv - 1) / 2; }
+    if (MODE == ATTN_GATHER) { vr0 = a.vrow0[b]; tr0 = a.trow0[b]; }
+    // row pointers of token `tok`: q, k, v (each at column 0 of its 256-wide block) and the additive pos row (or null)
+    auto rows_of = [&](int tok, const float*& q, const float*& k, const float*& v, const float*& add) {
+        add = (MODE != ATTN_PACKED && tok < lv) ? a.pos_qk + (size_t)(pbase + tok) * 512 : nullptr;
+        if (MODE == ATTN_GATHER) {
+            const float* r = tok < lv ? a.qkv_vid + (size_t)(vr0 + tok) * 768 : a.qkv_txt + (size_t)(tr0 + tok - lv) * 768;
+            q = r; k = r + 256; v = r + 512;
+        } else {
+            q = a.Q + (size_t)(t0 + tok) * a.ldq; k = a.K + (size_t)(t0 + tok) * a.ldk; v = a.V + (size_t)(t0 + tok) * a.ldv;
         }
-        add = nullptr;
-        return g.qkv_txt + (size_t)(tr0 + tok - lv) * 768 + col;
     };
 
     // this lane's query values d = 8 lg .. 8 lg + 7 (fetched before the K/V staging: independent round trips)
@@ -214,13 +61,13 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
     if (q0 < L) {
         int qrow = q0 + li;
         qrow = qrow < L ? qrow : L - 1;
-        const float* qadd = nullptr;
-        const float* qp = GATHER ? src_of(qrow, 0, qadd) + head * 32 + 8 * lg
-                                 : QK + (size_t)(t0 + qrow) * 512 + head * 32 + 8 * lg;
+        const float *qp, *kp_, *vp_, *qadd;
+        rows_of(qrow, qp, kp_, vp_, qadd);
+        qp += head * 32 + 8 * lg;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             float4 x = reinterpret_cast<const float4*>(qp)[u];
-            if (GATHER && qadd) {
+            if (MODE != ATTN_PACKED && qadd) {
                 const float4 t = reinterpret_cast<const float4*>(qadd + head * 32 + 8 * lg)[u];
                 x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
             }
@@ -233,18 +80,13 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
         for (int key = kr; key < nkt * 16; key += NT / 8) {
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (key < L) {
-                if (GATHER) {
-                    const float* add;
-                    const float* kp_ = src_of(key, 256, add);
-                    kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
-                    vv = *reinterpret_cast<const float4*>(kp_ + 256 + head * 32 + c * 4);
-                    if (add) {
-                        const float4 t = *reinterpret_cast<const float4*>(add + head * 32 + c * 4);
-                        kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
-                    }
-                } else {
-                    kv = *reinterpret_cast<const float4*>(QK + (size_t)(t0 + key) * 512 + 256 + head * 32 + c * 4);
-                    vv = *reinterpret_cast<const float4*>(V + (size_t)(t0 + key) * 256 + head * 32 + c * 4);
+                const float *qp, *kp_, *vp_, *add;
+                rows_of(key, qp, kp_, vp_, add);
+                kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
+                vv = *reinterpret_cast<const float4*>(vp_ + head * 32 + c * 4);
+                if (MODE != ATTN_PACKED && add) {
+                    const float4 t = *reinterpret_cast<const float4*>(add + 256 + head * 32 + c * 4);
+                    kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
                 }
             }
             KsT[(4 * c + 0) * LDK + key] = kv.x; KsT[(4 * c + 1) * LDK + key] = kv.y;
@@ -265,7 +107,8 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
         for (int kt = 0; kt < NKT; ++kt)
             if (kt < nkt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
     }
-    // softmax over the keys of this lane's query: registers, then the four lane groups
+    // softmax over the keys of this lane's query: registers, then the four lane groups.  Only the last key tile can
+    // hold padding; exp(s - m) is one fma + one v_exp_f32 (exp2((s - m) * log2 e)).
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -300,7 +143,9 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
     for (int kt = 0; kt < NKT; ++kt)
         if (kt < nkt) {
             const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
-            const int rem = L - kt * 16;        // k-step r covers keys r, 4 + r, 8 + r, 12 + r of the tile
+            // k-step r covers keys r, 4 + r, 8 + r, 12 + r of the tile: past the window's last key the probabilities
+            // are exactly 0, so the ragged last tile stops early (uniform branch)
+            const int rem = L - kt * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (r < rem) {
@@ -320,42 +165,38 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(const float* __
     }
 }
 
-template <bool GATHER>
-static int launch_enc_attn_t(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
-                             const L0Gather& g, hipStream_t s) {
-    CONE_REQUIRE(Lmax >= 1 && Lmax <= 192, "enc attention: window length %d not in [1,192]", Lmax);
-    if (B <= 0) return 0;
-    dim3 grid(B, 8), block(256);
-    const int nkb = (Lmax + 31) / 32;
-    ProfScope ps(PK_ENC_ATTN, B, Lmax, GATHER, nullptr, s);
-    if (g_attn16) {
-        const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
-#define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, GATHER>), grid, dim3(64 * N), 0, s, QK, V, OUT, off, g); break;
-        switch (nkt) {
-            CONE_ATTN16(6)
-            CONE_ATTN16(7) CONE_ATTN16(8) CONE_ATTN16(9) CONE_ATTN16(10) CONE_ATTN16(11) CONE_ATTN16(12)
-        }
-#undef CONE_ATTN16
-        CONE_LAUNCH_CHECK();
-        return 0;
+template <int MODE>
+static int launch_enc_attn_t(const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
+    dim3 grid(B, 8);
+    const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
+#define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, MODE>), grid, dim3(64 * N), 0, s, a, OUT, off); break;
+    switch (nkt) {
+        CONE_ATTN16(6)
+        CONE_ATTN16(7) CONE_ATTN16(8) CONE_ATTN16(9) CONE_ATTN16(10) CONE_ATTN16(11) CONE_ATTN16(12)
     }
-    if (nkb <= 4) hipLaunchKernelGGL((enc_attn_kernel<4, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
-    else if (nkb == 5) hipLaunchKernelGGL((enc_attn_kernel<5, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
-    else hipLaunchKernelGGL((enc_attn_kernel<6, GATHER>), grid, block, 0, s, QK, V, OUT, off, g);
+#undef CONE_ATTN16
     CONE_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax,
-                    hipStream_t s) {
-    return launch_enc_attn_t<false>(QK, V, OUT, off, B, Lmax, L0Gather{}, s);
-}
-
-int launch_enc_attn_l0(const float* qkv_vid, const float* qkv_txt, const float* pos_qk, const int* vrow0,
-                       const int* vlen, const int* trow0, float* OUT, const int* off, int B, int Lmax,
-                       hipStream_t s) {
-    return launch_enc_attn_t<true>(nullptr, nullptr, OUT, off, B, Lmax,
-                                   L0Gather{qkv_vid, qkv_txt, pos_qk, vrow0, vlen, trow0}, s);
+int launch_enc_attn(int mode, const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
+    CONE_REQUIRE(Lmax >= 1 && Lmax <= 192, "enc attention: window length %d not in [1,192]", Lmax);
+    if (B <= 0) return 0;
+    ProfScope ps(PK_ENC_ATTN, B, Lmax, mode, nullptr, s);
+    switch (mode) {
+        case ATTN_PACKED:
+            CONE_REQUIRE(a.Q && a.K && a.V, "enc attention: packed mode needs Q, K, V");
+            return launch_enc_attn_t<ATTN_PACKED>(a, OUT, off, B, Lmax, s);
+        case ATTN_GATHER:
+            CONE_REQUIRE(a.qkv_vid && a.qkv_txt && a.pos_qk && a.vrow0 && a.vlen && a.trow0,
+                         "enc attention: gather mode needs the layer-0 caches");
+            return launch_enc_attn_t<ATTN_GATHER>(a, OUT, off, B, Lmax, s);
+        case ATTN_POSADD:
+            CONE_REQUIRE(a.Q && a.K && a.V && a.pos_qk && a.vlen, "enc attention: pos-add mode needs Q, K, V, pos_qk, vlen");
+            return launch_enc_attn_t<ATTN_POSADD>(a, OUT, off, B, Lmax, s);
+    }
+    set_error("enc attention: unknown mode %d", mode);
+    return CONE_E_INVALID;
 }
 
 // Decoder attentions: NQ (<= 8) query slots per window, one wavefront per (window, head).

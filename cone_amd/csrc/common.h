@@ -84,10 +84,14 @@ struct GemmArgs {
     int M; const int* M_dev;              // rows; *M_dev wins when non-null (grid sized by M)
     int N, K;
     int flags;
+    int variant;                          // tile family: 0 automatic (GEMM_ROWS8 where the shape allows), else forced
 };
+// GEMM_SQUARE: register-staged 128x128 / 64x256 tiles; GEMM_ROWS4 / GEMM_ROWS8: the 128x256 row-owning LDS-DMA tile
+// with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4).  The family is a function of the shape and of
+// this field only (never of M or of process state): a row of C is computed by the same instruction sequence
+// whatever batch it sits in.
+enum { GEMM_AUTO = 0, GEMM_SQUARE = 1, GEMM_ROWS4 = 2, GEMM_ROWS8 = 3 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
-void set_gemm_variant(int v);
-void set_gemm_rows_waves(int w);
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
@@ -98,17 +102,28 @@ int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float
                   int64_t n_rows, int nout, int act, hipStream_t s);
 
 // ---------------------------------------------------------------- attention.hip
-int launch_enc_attn(const float* QK, const float* V, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
-void set_attn16(int v);
+// Where the encoder self-attention reads the q | k | v rows of a window's tokens from:
+//   ATTN_PACKED : packed (M, ld) matrices Q / K / V (row off[b] + token), q and k already carry the position term;
+//   ATTN_GATHER : the layer-0 caches -- clip rows qkv_vid[vrow0[b] + p] (+ pos_qk row of (vlen[b], p) on q | k), text
+//                 rows qkv_txt[trow0[b] + j]: the first layer's in_proj is never written per window;
+//   ATTN_POSADD : packed Q / K / V = x W^T + b of the layer's input WITHOUT the position term; the kernel adds the
+//                 static row pos_qk[(vlen[b], p)] = pos W_qk^T to q | k of clip tokens in its staging loads
+//                 ((x + pos) W^T = x W^T + pos W^T): one N = 768 GEMM on x per layer, no x + pos matrix.
+enum { ATTN_PACKED = 0, ATTN_GATHER = 1, ATTN_POSADD = 2 };
+struct AttnSrc {
+    const float* Q; const float* K; const float* V; int ldq, ldk, ldv;
+    const float* qkv_vid; const float* qkv_txt; const float* pos_qk;    // pos_qk (R, 512), row lv (lv - 1) / 2 + p
+    const int* vrow0; const int* vlen; const int* trow0;
+};
+int launch_enc_attn(int mode, const AttnSrc& src, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
 int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s);
-// first encoder layer on the layer-0 cache: q|k|v gathered in the kernel's staging loads (attention.hip)
-int launch_enc_attn_l0(const float* qkv_vid, const float* qkv_txt, const float* pos_qk, const int* vrow0,
-                       const int* vlen, const int* trow0, float* OUT, const int* off, int B, int Lmax,
-                       hipStream_t s);
-// fused decoder cross-attention with the memory K/V projections folded in (dec_cross.hip)
+// fused decoder cross-attention with the memory K/V projections folded in (dec_cross.hip).  Keys = memory + pos:
+// either XP (M, 256) = memory + pos precomputed, or (XP == nullptr) memory rows X plus the static sine rows
+// pos_rows[(vlen[b], p)] of clip tokens added in the staging loads.
 bool dec_cross_supported(int nq, int Lmax);
-int launch_dec_cross(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
-                     const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax, hipStream_t s);
+int launch_dec_cross(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
+                     const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
+                     int Lmax, hipStream_t s);
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 
@@ -118,6 +133,7 @@ int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const
                     const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
                     int Lmax, hipStream_t s);
 int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
+// X always; POS (sine rows) and QK / V (layer-0 q|k|v gathered from the caches) only when non-null
 int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                    const int* qlen, const int* off, const float* dim_t, const float* qkv_vid, const float* qkv_txt,
                    const float* pos_qk, float* X, float* POS, float* QK, float* V, int B, int Lmax, hipStream_t s);

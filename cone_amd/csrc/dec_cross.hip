@@ -15,6 +15,8 @@
 //   C. ctx_p = sum_j P[p][j] mem_j      (lane = 4 columns, wave = 5 pairs, mem rows read coalesced)
 //   D. out = W_v,h ctx_p + b_v          (thread = output column, W_v^T read coalesced)
 // Results equal the unfused path up to fp32 re-association (~1e-6 relative).
+#include <mutex>
+
 #include "common.h"
 
 namespace cone {
@@ -59,10 +61,15 @@ struct DecCrossCfg {
     static constexpr int LDS_FLOATS = NP * 32 + NP * 256 + UNION;
 };
 
-template <int NQ, int NKL>
+// POSTAB: the keys memory + pos are formed in the staging loads from the memory rows X and the static sine table
+// (row (lv, p) of pos_rows for clip token p of a window with lv clips; text tokens carry no position, cone/model.py:106)
+// instead of being read from a precomputed (M, 256) matrix XP.
+template <int NQ, int NKL, bool POSTAB>
 __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restrict__ DQ,
                                                            const float* __restrict__ XP,
                                                            const float* __restrict__ X,
+                                                           const float* __restrict__ pos_rows,
+                                                           const int* __restrict__ vlen,
                                                            const int* __restrict__ off,
                                                            const float* __restrict__ Wk,
                                                            const float* __restrict__ WvT,
@@ -75,6 +82,9 @@ __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restri
     const int b = blockIdx.x;
     const int t0 = off[b];
     const int L = min(off[b + 1] - t0, C::KP);
+    const int lv = POSTAB ? vlen[b] : 0;
+    const float* __restrict__ KEYS = POSTAB ? X : XP;
+    const float* __restrict__ prow = POSTAB ? pos_rows + (size_t)(lv * (lv - 1) / 2) * 256 : nullptr;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -122,7 +132,8 @@ __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restri
     _Pragma("unroll") for (int i = 0; i < TPASS; ++i) {                                                     \
         int r = srow + 64 * i;                                                                              \
         r = r < L ? r : L - 1;                                                                              \
-        pf[i] = *reinterpret_cast<const f4v*>(XP + (size_t)(t0 + r) * 256 + (ch_) * 32 + spart * 4);     \
+        pf[i] = *reinterpret_cast<const f4v*>(KEYS + (size_t)(t0 + r) * 256 + (ch_) * 32 + spart * 4);   \
+        if (POSTAB && r < lv) pf[i] += *reinterpret_cast<const f4v*>(prow + (size_t)r * 256 + (ch_) * 32 + spart * 4); \
     }
 #define DC_STASH()                                                                                          \
     _Pragma("unroll") for (int i = 0; i < TPASS; ++i)                                                       \
@@ -279,31 +290,39 @@ __global__ __launch_bounds__(512, 4) void dec_cross_kernel(const float* __restri
     }
 }
 
-template <int NQ, int NKL>
-static int launch_one(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
-                      const float* WvT, const float* bv, float* OUT, int B, hipStream_t s) {
+template <int NQ, int NKL, bool POSTAB>
+static int launch_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
+                      const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
+                      hipStream_t s) {
     using C = DecCrossCfg<NQ, NKL>;
-    static bool attr = false;
-    if (!attr) {
-        CONE_CHECK_HIP(hipFuncSetAttribute((const void*)dec_cross_kernel<NQ, NKL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4));
-        attr = true;
-    }
-    hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL>), dim3(B), dim3(C::NT), C::LDS_FLOATS * 4, s, DQ, XP, X, off, Wk, WvT,
-                       bv, OUT);
+    static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)dec_cross_kernel<NQ, NKL, POSTAB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
+    });
+    CONE_CHECK_HIP(attr_rc);
+    hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL, POSTAB>), dim3(B), dim3(C::NT), C::LDS_FLOATS * 4, s, DQ, XP, X,
+                       pos_rows, vlen, off, Wk, WvT, bv, OUT);
     CONE_LAUNCH_CHECK();
     return 0;
 }
 
 bool dec_cross_supported(int nq, int Lmax) { return nq == 5 && Lmax <= 192; }
 
-int launch_dec_cross(const float* DQ, const float* XP, const float* X, const int* off, const float* Wk,
-                     const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax, hipStream_t s) {
+int launch_dec_cross(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
+                     const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
+                     int Lmax, hipStream_t s) {
     CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
+    CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
-    if (Lmax <= 128) return launch_one<5, 2>(DQ, XP, X, off, Wk, WvT, bv, OUT, B, s);
-    return launch_one<5, 3>(DQ, XP, X, off, Wk, WvT, bv, OUT, B, s);
+    if (XP) {
+        if (Lmax <= 128) return launch_one<5, 2, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, s);
+        return launch_one<5, 3, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, s);
+    }
+    if (Lmax <= 128) return launch_one<5, 2, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, s);
+    return launch_one<5, 3, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, s);
 }
 
 }  // namespace cone

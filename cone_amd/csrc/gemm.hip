@@ -15,6 +15,8 @@
 // ds_read_b32 operand fetches are both bank-conflict free.  Global loads of slab t+1 are
 // issued before the MFMAs of slab t (register prefetch); one LDS buffer, two barriers per slab,
 // 2-4 workgroups per CU cover each other's barriers.
+#include <mutex>
+
 #include "common.h"
 
 namespace cone {
@@ -600,15 +602,6 @@ __global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
     }
 }
 
-static int g_gemm_variant = 0;  // 0 auto, 1 force register-staged tiles, 2/3 force a row tile (test hook A/B)
-static int g_rows_waves = 8;    // row tile flavour: 8 waves x 16 rows on 16x16x4 (default) or 4 waves x 32 rows on 32x32x2
-void set_gemm_variant(int v) {   // test hook: 1 register-staged square tiles, 2 four-wave row tile, 3 eight-wave row tile
-    g_gemm_variant = v == 3 ? 2 : v;
-    if (v == 2) g_rows_waves = 4;
-    if (v == 3 || v == 0) g_rows_waves = 8;
-}
-void set_gemm_rows_waves(int w) { g_rows_waves = w == 4 ? 4 : 8; }
-
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     CONE_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4");
@@ -616,24 +609,28 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0) return 0;
     if (a.flags & EPI_LN) CONE_REQUIRE(a.N == 256 && a.ln_g && a.ln_b, "gemm: LayerNorm epilogue needs N == 256");
     const bool rows_ok = a.N % 256 == 0 && !a.A2;
-    // The tile family is a function of the SHAPE only (never of M), so a row of C is computed by the same
-    // instruction sequence whatever batch it sits in: results are bit-identical across batch compositions.
-    const bool use_rows = rows_ok && g_gemm_variant != 1;
+    // The tile family is a function of the SHAPE and of a.variant only (never of M or of process state), so a row
+    // of C is computed by the same instruction sequence whatever batch it sits in: results are bit-identical
+    // across batch compositions.
+    const bool use_rows = rows_ok && a.variant != GEMM_SQUARE;
     const bool need_rows = a.C2 != nullptr;
     CONE_REQUIRE(!need_rows || (rows_ok && a.ADD), "gemm: second output needs the row tile (N %% 256 == 0, no A2)");
     if (use_rows || need_rows) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               RowTile<16>::LDS_BYTES));
-            CONE_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               RowTile<16>::LDS_BYTES));
-            attr_set = true;
-        }
+        static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
+        static hipError_t attr_rc = hipSuccess;
+        std::call_once(once, [] {
+            attr_rc = hipFuncSetAttribute((const void*)gemm_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          RowTile<16>::LDS_BYTES);
+            if (attr_rc == hipSuccess)
+                attr_rc = hipFuncSetAttribute((const void*)gemm_rows_kernel<16>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, RowTile<16>::LDS_BYTES);
+        });
+        CONE_CHECK_HIP(attr_rc);
+        const bool waves8 = a.variant != GEMM_ROWS4;
         const int row_tiles = (a.M + RT_BM - 1) / RT_BM;
         dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (a.N / RT_BN)));      // 1-D, see the tile order in the kernel
-        ProfScope ps(g_rows_waves == 8 ? PK_GEMM_ROWS16 : PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);
-        if (g_rows_waves == 8)
+        ProfScope ps(waves8 ? PK_GEMM_ROWS16 : PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);
+        if (waves8)
             hipLaunchKernelGGL(gemm_rows16_kernel, grid, dim3(512), RowTile<16>::LDS_BYTES, s, a);
         else
             hipLaunchKernelGGL(gemm_rows_kernel<16>, grid, dim3(256), RowTile<16>::LDS_BYTES, s, a);

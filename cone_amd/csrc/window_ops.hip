@@ -124,14 +124,16 @@ __global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ 
     const int lv = vlen[b], lq = qlen[b];
     if (p >= lv + lq) return;
     const size_t row = (size_t)(off[b] + p);
-    float4 x, ps, q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, vv = q0;
+    float4 x, ps = make_float4(0.f, 0.f, 0.f, 0.f), q0 = ps, q1 = q0, vv = q0;
     if (p < lv) {
         const size_t src = (size_t)(vrow0[b] + p);
         x = reinterpret_cast<const float4*>(vproj + src * 256)[lane];
-        const float xe = __fmul_rn(__fdiv_rn((float)(p + 1), __fadd_rn((float)lv, 1e-6f)), 6.283185307179586f);
-        const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
-        ps.x = sinf(__fdiv_rn(xe, dt.x)); ps.y = cosf(__fdiv_rn(xe, dt.y));
-        ps.z = sinf(__fdiv_rn(xe, dt.z)); ps.w = cosf(__fdiv_rn(xe, dt.w));
+        if (POS) {      // null: every consumer of the position term reads the static tables instead
+            const float xe = __fmul_rn(__fdiv_rn((float)(p + 1), __fadd_rn((float)lv, 1e-6f)), 6.283185307179586f);
+            const float4 dt = reinterpret_cast<const float4*>(dim_t)[lane];
+            ps.x = sinf(__fdiv_rn(xe, dt.x)); ps.y = cosf(__fdiv_rn(xe, dt.y));
+            ps.z = sinf(__fdiv_rn(xe, dt.z)); ps.w = cosf(__fdiv_rn(xe, dt.w));
+        }
         if (QK) {
             const float4* qs = reinterpret_cast<const float4*>(qkv_vid + src * 768);
             const float4* pq = reinterpret_cast<const float4*>(pos_qk + (size_t)(lv * (lv - 1) / 2 + p) * 512);
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ 
         }
     }
     reinterpret_cast<float4*>(X + row * 256)[lane] = x;
-    reinterpret_cast<float4*>(POS + row * 256)[lane] = ps;
-    if (QK) {       // null: the attention kernel gathers q|k|v itself (launch_enc_attn_l0)
+    if (POS) reinterpret_cast<float4*>(POS + row * 256)[lane] = ps;
+    if (QK) {       // null: the attention kernel gathers q|k|v itself (ATTN_GATHER)
         reinterpret_cast<float4*>(QK + row * 512)[lane] = q0;
         reinterpret_cast<float4*>(QK + row * 512)[64 + lane] = q1;
         reinterpret_cast<float4*>(V + row * 256)[lane] = vv;

@@ -29,6 +29,7 @@ import os
 import time
 import warnings
 from collections import OrderedDict
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -45,8 +46,15 @@ class FeatureStore:
     """Device-resident features of one evaluation split (replaces PreFilteringDataset +
     StartEndDataset of cone/ego4d_mad_dataloader.py for the eval path)."""
 
-    def __init__(self, opt, annotations, video_feats, query_feats, device=None):
+    def __init__(self, opt, annotations, video_feats, query_feats, device=None, tok_normalized=False,
+                 cls_normalized=False):
+        """``video_feats``: clip_id -> RAW (ctx_l, dv) features (hazard H2: the window model sees them un-normalised);
+        ``query_feats``: query_id -> {token_features, cls_features | eot_features}.  ``tok_normalized`` /
+        ``cls_normalized``: the text side already went through the reference's ``l2_normalize_np_array`` on the
+        host (features taken from the reference's dataset objects, ``from_datasets``) and must not be normalised
+        a second time."""
         self.opt = opt
+        self.tok_normalized, self.cls_normalized = bool(tok_normalized), bool(cls_normalized)
         self.ann = list(annotations)
         if opt.data_ratio != 1:
             self.ann = self.ann[:int(len(self.ann) * opt.data_ratio)]   # dataloader :116-121
@@ -72,15 +80,21 @@ class FeatureStore:
         self.tok_raw = torch.from_numpy(np.concatenate(toks, 0)).to(dev)
         self.cls_raw = torch.from_numpy(np.stack(clss, 0)).to(dev)
         self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
+        self.q_base = 0         # annotation index of this store's first query in the split it was cut from
+        self.nq_split = len(self.ann)
         self._plan = None
         self._index = None
 
     @classmethod
     def subset(cls, store, lo: int, hi: int):
-        """View of queries [lo, hi) of `store` (annotation order) sharing its device arenas -- the
-        per-rank shard of a query-sharded multi-GPU run."""
+        """View of queries [lo, hi) of `store` (annotation order) sharing its device arenas -- a chunk of the
+        software pipeline or the per-rank shard of a query-sharded multi-GPU run.  The view remembers where it
+        sits in the split (``q_base``): the reference pads every batch of ``eval_bsz`` consecutive queries of
+        the SPLIT to its longest window (hazard H3), so batch ids must stay global."""
         sub = cls.__new__(cls)
         sub.opt, sub.device = store.opt, store.device
+        sub.tok_normalized, sub.cls_normalized = store.tok_normalized, store.cls_normalized
+        sub.q_base, sub.nq_split = store.q_base + lo, store.nq_split
         sub.ann = store.ann[lo:hi]
         sub.clip_ids, sub.clip2idx, sub.ctx_l, sub.vid_off = store.clip_ids, store.clip2idx, store.ctx_l, store.vid_off
         sub.vid_raw = store.vid_raw
@@ -135,24 +149,31 @@ class FeatureStore:
     @classmethod
     def from_lmdb(cls, opt, device=None):
         """Read the reference's LMDBs of np.savez blobs (keys ``features`` / ``token_features`` +
-        ``cls_features``|``eot_features``; cone/ego4d_mad_dataloader.py:263-302)."""
+        ``cls_features``|``eot_features``, keyed by clip_id / query_id utf-8; cone/ego4d_mad_dataloader.py:73-103,
+        258-302, 453-473) -- the default data source of the CLI, as in the reference."""
         try:
             import lmdb
-        except ImportError as e:  # pragma: no cover - lmdb is not in this image
-            raise ImportError("reading the reference LMDB feature stores needs the `lmdb` package") from e
+        except ImportError as e:
+            raise ImportError("reading the reference LMDB feature stores needs the `lmdb` package "
+                              "(or convert once with `python -m cone_amd.pack_features` where it is installed)") from e
         if opt.motion_feat_dir != opt.appearance_feat_dir:
             raise NotImplementedError("separate motion/appearance feature dirs are not used by any shipped script")
         with open(opt.eval_path) as f:
-            ann = [json.loads(l.strip("\n")) for l in f.readlines()]
+            ann = [json.loads(l.strip("\n")) for l in f.readlines()]      # utils/basic_utils.py:51-53
+        if opt.data_ratio != 1:
+            ann = ann[:int(len(ann) * opt.data_ratio)]                     # dataloader :116-121 (before any read)
 
         def read_all(path, keys, fields):
             env = lmdb.open(path, readonly=True, create=False, max_readers=4096 * 8, readahead=False)
+            txn = env.begin(buffers=True)
             out = {}
-            with env.begin(buffers=True) as txn:
-                for k in keys:
-                    with io.BytesIO(txn.get(k.encode())) as reader:
-                        dump = np.load(reader, allow_pickle=True)
-                        out[k] = {f: dump[f] for f in fields if f in dump}
+            for k in keys:
+                dump = txn.get(k.encode())
+                if dump is None:
+                    raise KeyError(f"{path}: no entry for {k!r}")
+                with io.BytesIO(dump) as reader:
+                    blob = np.load(reader, allow_pickle=True)
+                    out[k] = {f: np.asarray(blob[f]) for f in fields if f in blob}
             return out
 
         vf = {k: v["features"] for k, v in read_all(opt.appearance_feat_dir,
@@ -160,7 +181,36 @@ class FeatureStore:
                                                     ["features"]).items()}
         qf = read_all(opt.t_feat_dir, [r["query_id"] for r in ann],
                       ["token_features", "cls_features", "eot_features"])
-        return cls(opt, ann, vf, qf, device=device)
+        st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device)
+        st.opt = opt
+        return st
+
+    @classmethod
+    def from_datasets(cls, opt, eval_inter_window_dataset, eval_intra_window_dataset, device=None):
+        """Build the store from the reference's two dataset objects, as ``eval_epoch(model, inter_ds, intra_ds, opt,
+        ...)`` receives them (cone/inference.py:227-228; cone/train.py:164-168): annotation rows and the RAM-resident
+        RAW clip features from the StartEndDataset (``.data``, ``.videofeat``: dataloader :93-103, hazard H2), text
+        features through its own accessor ``_get_query_feat_by_qid`` (:258-282) -- which hands back tokens that are
+        already truncated and (unless ``normalize_t`` is off) L2-normalised, and a normalised cls vector, so the
+        store is told not to normalise them again.  The PreFilteringDataset reads the same LMDBs (:409-431) and only
+        contributes a consistency check here."""
+        intra, inter = eval_intra_window_dataset, eval_inter_window_dataset
+        if not getattr(intra, "same_visual_path", True):
+            raise NotImplementedError("separate motion/appearance feature sources are not used by any shipped script")
+        ann = list(intra.data)
+        if inter is not None and hasattr(inter, "query_data"):
+            if [r["query_id"] for r in inter.query_data] != [r["query_id"] for r in ann]:
+                raise ValueError("the two datasets list different queries")
+        to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+        vf = {c: to_np(intra.videofeat[c]) for c in OrderedDict.fromkeys(r["clip_id"] for r in ann)}
+        qf = {}
+        for r in ann:
+            tok, cq = intra._get_query_feat_by_qid(r["query_id"])
+            qf[r["query_id"]] = dict(token_features=to_np(tok), cls_features=to_np(cq))
+        st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device,
+                 tok_normalized=bool(getattr(intra, "normalize_t", True)), cls_normalized=True)
+        st.opt = opt
+        return st
 
     # -- packed arena file (SURVEY 8f row 1): one mmap-able .bin per split instead of an LMDB of compressed npz
     PACK_MAGIC = b"CONEFS01"
@@ -201,6 +251,7 @@ class FeatureStore:
               for k, v in head["arrays"].items()}
         st = cls.__new__(cls)
         st.opt = opt
+        st.tok_normalized = st.cls_normalized = False
         dev = device or torch.device("cuda", torch.cuda.current_device())
         st.device = dev
         st.ann = list(head["ann"])
@@ -222,6 +273,7 @@ class FeatureStore:
         st.tok_raw = up(mm["tok_raw"][:int(st.tok_off[-1])])
         st.cls_raw = up(mm["cls_raw"][:nq])
         st.q_vid = np.array([st.clip2idx[r["clip_id"]] for r in st.ann], dtype=np.int64)
+        st.q_base, st.nq_split = 0, len(st.ann)
         st._plan = None
         st._index = None
         return st
@@ -232,18 +284,16 @@ class FeatureStore:
 def prefilter(model, store: FeatureStore, opt, k=None):
     """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window);
     ``k`` overrides opt.topk_window (the window-recall table ranks deeper than the model consumes)."""
-    dev = store.device
     vid_norm = ops.l2_normalize(store.vid_raw, 1e-5)          # PreFilteringDataset :459
     ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
-    cls_norm = ops.l2_normalize(store.cls_raw, 1e-5)          # :473
+    cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :473
     win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, store.prefilter_plan(), opt.max_v_l, k or opt.topk_window)
     return win_idx
 
 
-def window_table(store: FeatureStore, opt, win_idx):
-    """Eval branch of StartEndDataset.__getitem__ + collate (dataloader :144-159, 229-234, 305-344)
-    as index arithmetic on the device: one row per (query, selected window), in annotation order."""
-    dev = store.device
+def _window_geometry(store: FeatureStore, opt, win_idx):
+    """(q_of, slot, start, vlen) of every selected window, row-major over (query, rank slot)."""
+    dev = win_idx.device
     nq, K = win_idx.shape
     W, S = opt.max_v_l, int(opt.max_v_l / 2)
     st = store.index_tensors()
@@ -260,30 +310,78 @@ def window_table(store: FeatureStore, opt, win_idx):
         q_of, slot = (win_idx >= 0).nonzero(as_tuple=True)   # row-major; the one host sync of the table
         wi = win_idx[q_of, slot].to(torch.int64)
     ctx_l = st["q_ctx_l"][q_of]
-    voff = st["q_vid_off"][q_of]
     start = torch.clamp((wi - 1) * S, min=0)
     end = torch.minimum((wi - 1) * S + W, ctx_l)
-    vlen = end - start
-    # zero-padded length of the reference batch this window would sit in (hazard H3)
-    bid = q_of // opt.eval_bsz
-    nb = (nq + opt.eval_bsz - 1) // opt.eval_bsz
-    pad = torch.zeros(nb, dtype=torch.int64, device=dev).scatter_reduce_(0, bid, vlen, reduce="amax")
+    return q_of, slot, start, end - start
+
+
+def reference_batch_pad(store: FeatureStore, opt, win_idx):
+    """Zero-padded clip length of every reference batch of the SPLIT ``store`` is (or was cut from): the
+    reference collates ``eval_bsz`` consecutive queries x their top-k windows into one tensor padded to the
+    longest window of that batch (cone/inference.py:306-313, utils/tensor_utils.py:36-39), and the proposal
+    mean of forward_clip_matching divides by a length clipped to that padding (cone/model.py:186-199, hazard
+    H3).  Returns (ceil(nq_split / eval_bsz),) int64; entries of batches this store holds no query of are 0."""
+    q_of, _, _, vlen = _window_geometry(store, opt, win_idx)
+    nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
+    bid = (q_of + store.q_base) // opt.eval_bsz
+    return torch.zeros(nb, dtype=torch.int64, device=win_idx.device).scatter_reduce_(0, bid, vlen, reduce="amax")
+
+
+def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
+    """Eval branch of StartEndDataset.__getitem__ + collate (dataloader :144-159, 229-234, 305-344)
+    as index arithmetic on the device: one row per (query, selected window), in annotation order.
+
+    ``batch_pad`` = reference_batch_pad() of the whole split.  Without it the padding is derived from the
+    windows of ``store`` alone, which is only the reference's when ``store`` holds whole reference batches --
+    a view cut inside a batch must be given the split's table (checked)."""
+    nq = win_idx.shape[0]
+    q_of, slot, start, vlen = _window_geometry(store, opt, win_idx)
+    st = store.index_tensors()
+    voff = st["q_vid_off"][q_of]
+    if batch_pad is None:
+        hi = store.q_base + nq
+        if store.q_base % opt.eval_bsz or (hi % opt.eval_bsz and hi != store.nq_split):
+            raise ValueError(f"queries [{store.q_base}, {hi}) of a {store.nq_split}-query split cut a reference "
+                             f"batch (eval_bsz {opt.eval_bsz}): pass batch_pad=reference_batch_pad(split, ...)")
+        batch_pad = reference_batch_pad(store, opt, win_idx)
+    bid = (q_of + store.q_base) // opt.eval_bsz
     i32 = lambda t: t.to(torch.int32).contiguous()
     tok_off, tok_len = st["tok_off"], st["tok_len"]
     return dict(q_of=q_of, slot=slot, vid_row0=i32(voff + start), vid_len=i32(vlen), video_start=i32(start),
-                pad_len=i32(pad[bid]), txt_row0=i32(tok_off[q_of]), txt_len=i32(tok_len[q_of]), cls_row=i32(q_of))
+                pad_len=i32(batch_pad[bid]), txt_row0=i32(tok_off[q_of]), txt_len=i32(tok_len[q_of]), cls_row=i32(q_of))
 
 
 # ------------------------------------------------------------------------------------ stage B
 @torch.no_grad()
-def project_features(model, store: FeatureStore):
-    """Row-wise work shared by every window that contains a clip and by all windows of a query
-    (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors."""
-    vproj = model.project(0, store.vid_raw)                                 # raw features: H2
-    tproj = model.project(1, ops.l2_normalize(store.tok_raw, 1e-5))         # dataloader :274-275
-    feats = dict(vproj=vproj, tproj=tproj, cls_norm=ops.l2_normalize(store.cls_raw, 1e-5))  # :277
+def project_video(model, store: FeatureStore, row_range=None):
+    """Clip-side row work shared by every window that contains a clip: the input projection of each clip once
+    (raw features: hazard H2) and, with the layer-0 cache, its first-layer q|k|v rows + the static position
+    tables.  ``row_range`` = (r0, r1) restricts it to arena rows [r0, r1) (a rank that only runs the windows of
+    some videos); ``vid_base`` is what window rows must be rebased by."""
+    r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
+    vproj = model.project(0, store.vid_raw[r0:r1])
+    out = dict(vproj=vproj, vid_base=r0)
     if getattr(store.opt, "layer0_cache", True):
-        feats["l0"] = model.layer0_cache(vproj, tproj, store.opt.max_v_l)
+        out["l0_vid"] = model.layer0_rows(vproj)
+        out["tables"] = model.pos_tables(store.opt.max_v_l)
+    return out
+
+
+@torch.no_grad()
+def project_features(model, store: FeatureStore, video=None):
+    """Row-wise work shared by every window that contains a clip and by all windows of a query
+    (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors.  ``video`` =
+    project_video() of the arena ``store`` shares (computed once per split, reused by its views)."""
+    video = video or project_video(model, store)
+    tok = store.tok_raw
+    if not (store.tok_normalized or getattr(store.opt, "no_norm_tfeat", False)):
+        tok = ops.l2_normalize(tok, 1e-5)                                   # dataloader :277-278 (normalize_t)
+    tproj = model.project(1, tok)
+    cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :280
+    feats = dict(vproj=video["vproj"], vid_base=video["vid_base"], tproj=tproj, cls_norm=cls_norm)
+    if "l0_vid" in video:
+        feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=model.layer0_rows(tproj), max_v_l=store.opt.max_v_l,
+                           **video["tables"])
     return feats
 
 
@@ -296,11 +394,13 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
     nw = wt["vid_row0"].shape[0]
     chunk = chunk or int(getattr(opt, "window_batch", 32768))
     Lq_max = max(store.tok_len)
+    base = int(feats.get("vid_base", 0))
     outs = {k: [] for k in ("pred_logits", "pred_spans", "matching", "rows")}
     for c0 in range(0, nw, chunk):
         sl = slice(c0, min(c0 + chunk, nw))
         g = lambda k: wt[k][sl].contiguous()
-        out = model.forward_packed(feats["vproj"], g("vid_row0"), g("vid_len"), feats["tproj"], g("txt_row0"),
+        prow0 = g("vid_row0") - base if base else g("vid_row0")
+        out = model.forward_packed(feats["vproj"], prow0, g("vid_len"), feats["tproj"], g("txt_row0"),
                                    g("txt_len"), opt.max_v_l, Lq_max, l0=feats.get("l0"),
                                    saliency=bool(getattr(opt, "need_saliency", False)))
         match = model.clip_matching_gathered(feats["cls_norm"], g("cls_row"), store.vid_raw, g("vid_row0"),
@@ -309,6 +409,8 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
                                 opt.clip_length, not opt.no_sort_results)
         outs["pred_logits"].append(out["pred_logits"]); outs["pred_spans"].append(out["pred_spans"])
         outs["matching"].append(match); outs["rows"].append(rows)
+        if "saliency_scores" in out:
+            outs.setdefault("saliency_scores", []).append(out["saliency_scores"])
     return {k: torch.cat(v, 0) for k, v in outs.items()}
 
 
@@ -316,6 +418,8 @@ def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
     """cone/inference.py:30-100: the window-level submission list (python floats rounded to 4 dp)."""
     if win_idx is None:
         win_idx = prefilter(model, store, opt)
+    if getattr(opt, "debug", False) and len(store.ann) > opt.eval_bsz:     # :93-94: stop after the first batch
+        store, win_idx = FeatureStore.subset(store, 0, opt.eval_bsz), win_idx[:opt.eval_bsz].contiguous()
     wt = window_table(store, opt, win_idx)
     res = run_windows(model, store, opt, wt)
     rows = res["rows"].cpu().tolist()
@@ -333,6 +437,8 @@ def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
 def _rows_to_lists(rows, n):
     """(3, nq, max_after, 5) fp64 + counts -> [fused, proposal, matching][query] -> list of rows."""
     A = rows.shape[2]
+    if rows.shape[1] == 0:
+        return [[], [], []]
     n = n.cpu()
     rows = rows.cpu().tolist()
     if int(n.min()) == A:                   # every query kept max_after rows (the common case): nothing to trim
@@ -423,22 +529,31 @@ def write_submissions(opt, fusion, proposal, matching, save_submission_filename)
     return paths
 
 
-@torch.no_grad()
-def device_pipeline(model, store: FeatureStore, opt):
-    """Stages A->C on the device only: returns the kept rows per query as tensors
-    (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables."""
-    win_idx = prefilter(model, store, opt)
-    wt = window_table(store, opt, win_idx)
-    res = run_windows(model, store, opt, wt)
+def candidate_lists(rows, wt, win_idx, Nq):
+    """Per-window rows (Nw, Nq, 4) -> per-query candidate lists (nq, K*Nq, 4) in (window rank, slot) order --
+    the order cone/inference.py:141-149 extends ``predicted_times`` in -- and their valid counts."""
     nq, K = win_idx.shape
-    Nq = model.num_queries
-    rows = res["rows"]
-    cand = torch.zeros(nq, K * Nq, 4, device=rows.device)
+    cand = torch.zeros(nq, K * Nq, 4, dtype=rows.dtype, device=rows.device)
     cand.view(nq, K, Nq, 4)[wt["q_of"], wt["slot"]] = rows
     n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
+    return cand, n_valid
+
+
+@torch.no_grad()
+def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=None, video=None):
+    """Stages A->C on the device only: returns the kept rows per query as tensors
+    (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables.  ``win_idx`` /
+    ``batch_pad`` / ``video``: results of prefilter / reference_batch_pad / project_video on the split ``store``
+    was cut from (a view shares them instead of recomputing them over the whole arena)."""
+    if win_idx is None:
+        win_idx = prefilter(model, store, opt)
+    wt = window_table(store, opt, win_idx, batch_pad)
+    res = run_windows(model, store, opt, wt, project_features(model, store, video))
+    rows = res["rows"]
+    cand, n_valid = candidate_lists(rows, wt, win_idx, model.num_queries)
     out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
     return dict(rows=out_rows, n=out_n, idx=out_idx, win_idx=win_idx, windows=wt, cand=cand,
-                n_windows=int(rows.shape[0]))
+                n_windows=int(rows.shape[0]), outputs=res)
 
 
 @contextlib.contextmanager
@@ -495,18 +610,32 @@ def predict_split(model, store: FeatureStore, opt):
     The queries run as a short software pipeline: all chunks are enqueued on the stream back to back (nothing in
     device_pipeline synchronises when the window table is dense), their kept rows are copied to pinned host
     memory behind an event each, and the host builds the submission rows of chunk i while the GPU is still
-    working on chunk i+1.  Results are identical to one big batch (rows of a GEMM are independent)."""
+    working on chunk i+1.  Results are identical to one big batch (rows of a GEMM are independent).
+
+    ``--debug`` keeps the reference's meaning (cone/inference.py:93-94): the pre-filter runs over the whole split,
+    the window model stops after the first batch of ``eval_bsz`` queries, and only those queries are written."""
     t0 = time.time()
+    if getattr(opt, "debug", False) and len(store.ann) > opt.eval_bsz:
+        win_idx = prefilter(model, store, opt)
+        store = FeatureStore.subset(store, 0, opt.eval_bsz)
+        dp = device_pipeline(model, store, opt, win_idx=win_idx[:opt.eval_bsz].contiguous())
+        torch.cuda.synchronize()
+        dp["model_seconds"] = time.time() - t0
+        dp["ann"] = store.ann
+        return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
     chunks = query_chunks(len(store.ann), opt)
     if len(chunks) == 1:
         dp = device_pipeline(model, store, opt)
         torch.cuda.synchronize()
         dp["model_seconds"] = time.time() - t0
         return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
+    # clip-side work once for the split, shared by the chunks (they are views of one arena)
+    win_idx = prefilter(model, store, opt)
+    video = project_video(model, store)
     pend = []
     for lo, hi in chunks:
         sub = FeatureStore.subset(store, lo, hi)
-        dp = device_pipeline(model, sub, opt)
+        dp = device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi], video=video)
         host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
                 for t in (dp["rows"], dp["n"])]
         ev = torch.cuda.Event()
@@ -519,7 +648,8 @@ def predict_split(model, store: FeatureStore, opt):
             dst.extend(part)
     model_seconds = time.time() - t0
     info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
-                n_windows=sum(p[1]["n_windows"] for p in pend), model_seconds=model_seconds, chunks=chunks)
+                n_windows=sum(p[1]["n_windows"] for p in pend), model_seconds=model_seconds, chunks=chunks,
+                win_idx=win_idx)
     return outs, info
 
 
@@ -561,12 +691,36 @@ def evaluate_split(model, store: FeatureStore, opt, dp, ground_truth=None, epoch
     return (*out, strs)
 
 
-def eval_epoch(model, store: FeatureStore, opt, save_submission_filename, epoch_i=None, criterion=None,
-               tb_writer=None, ground_truth=None):
+def eval_epoch(model, *args, epoch_i=None, criterion=None, tb_writer=None, ground_truth=None):
     """cone/inference.py:227-499: writes the prediction files; on the splits the reference scores (Ego4D val,
     MAD val / test) also the metric tables + ``.txt`` file.  Returns the reference's tuple
     ``(results, mIoU, [window, fusion, proposal, matching score strings], latest_file_paths)`` -- ``(None, None,
-    [], paths)`` when there is nothing to score (the reference ``exit(0)``s there, :476-477)."""
+    [], paths)`` when there is nothing to score (the reference ``exit(0)``s there, :476-477).
+
+    Two call shapes:
+      ``eval_epoch(model, store, opt, save_submission_filename, ...)``                      -- a FeatureStore;
+      ``eval_epoch(model, eval_inter_window_dataset, eval_intra_window_dataset, opt, save_submission_filename,
+      epoch_i, criterion, tb_writer)``  -- the reference's own signature (:227-228), so that its second caller,
+      the training loop (cone/train.py:164-168), can switch imports: the two dataset objects are read once into a
+      device-resident store (``FeatureStore.from_datasets``, cached on the intra-window dataset object).
+    ``criterion`` / ``tb_writer`` are accepted and ignored: the reference only feeds them eval-loss meters, which
+    need the training criterion (out of scope here)."""
+    if isinstance(args[0], FeatureStore):
+        store, opt, save_submission_filename = args[0], args[1], args[2]
+        rest = args[3:]
+    else:
+        inter_ds, intra_ds, opt, save_submission_filename = args[0], args[1], args[2], args[3]
+        rest = args[4:]
+        store = getattr(intra_ds, "_cone_amd_store", None)
+        if store is None:
+            store = FeatureStore.from_datasets(opt, inter_ds, intra_ds)
+            try:
+                intra_ds._cone_amd_store = store
+            except AttributeError:
+                pass
+        store.opt = opt
+    if len(rest) > 0 and epoch_i is None:
+        epoch_i = rest[0]
     logger.info("Generate submissions")
     (fusion, proposal, matching), info = predict_split(model, store, opt)
     print("total model running time: ", info["model_seconds"])
@@ -575,6 +729,8 @@ def eval_epoch(model, store: FeatureStore, opt, save_submission_filename, epoch_
     if not scored:
         print("end of inference on test split")
         return None, None, [], paths
+    if "ann" in info:           # --debug: only the first batch of queries went through the model
+        store = FeatureStore.subset(store, 0, len(info["ann"]))
     res, miou, res_p, miou_p, res_m, miou_m, strs = evaluate_split(model, store, opt, info, ground_truth, epoch_i)
     for s_ in strs:
         print(s_, flush=True)

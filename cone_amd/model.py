@@ -103,7 +103,7 @@ class CONE:
             if extra:
                 raise KeyError(f"unexpected keys in state_dict: {extra[:5]}")
         self._sd = sd
-        self._pos_qk = None
+        self._pos_tabs = None
         self._dim_t = _dim_t_table(self.hidden_dim).to(dev)
         a = self.args
         w = _lib.Weights()
@@ -252,46 +252,60 @@ class CONE:
                                            ws.numel(), _lib.stream()))
         return out
 
-    def layer0_cache(self, vproj, tproj, max_v_l: int):
-        """First encoder layer's in_proj hoisted out of the window loop: q|k|v rows once per clip and per
-        text token (cone_layer0_project) + the static pos W_qk^T table (built once per model)."""
+    def set_option(self, name: str, value: int):
+        """A/B switch of this model's handle (cone_model_set_option): parity tests and diagnostics only."""
+        _lib.check(_lib.load().cone_model_set_option(self._h(), name.encode(), int(value)))
+        return self
+
+    def layer0_rows(self, proj_rows):
+        """First encoder layer's in_proj hoisted out of the window loop: q|k|v rows once per projected clip /
+        text token (cone_layer0_project)."""
         lib, h = _lib.load(), self._h()
-        dev = vproj.device
-        if getattr(self, "_pos_qk", None) is None or self._pos_qk[0] != max_v_l:
-            rows = lib.cone_layer0_pos_rows(max_v_l)
-            tab = torch.empty(rows, 2 * self.hidden_dim, device=dev)
-            ws = self._ws.get(rows * self.hidden_dim * 4 + 4096, dev)
-            _lib.check(lib.cone_layer0_pos_table(h, max_v_l, _lib.ptr(tab), _lib.ptr(ws), ws.numel(), _lib.stream()))
-            self._pos_qk = (max_v_l, tab)
-        qv = torch.empty(vproj.shape[0], 3 * self.hidden_dim, device=dev)
-        qt = torch.empty(tproj.shape[0], 3 * self.hidden_dim, device=dev)
-        _lib.check(lib.cone_layer0_project(h, _lib.ptr(vproj), vproj.shape[0], _lib.ptr(qv), _lib.stream()))
-        _lib.check(lib.cone_layer0_project(h, _lib.ptr(tproj), tproj.shape[0], _lib.ptr(qt), _lib.stream()))
-        return dict(qkv_vid=qv, qkv_txt=qt, pos_qk=self._pos_qk[1], max_v_l=max_v_l)
+        qkv = torch.empty(proj_rows.shape[0], 3 * self.hidden_dim, device=proj_rows.device)
+        _lib.check(lib.cone_layer0_project(h, _lib.ptr(proj_rows), proj_rows.shape[0], _lib.ptr(qkv), _lib.stream()))
+        return qkv
+
+    def pos_tables(self, max_v_l: int):
+        """Static position tables of this checkpoint (built once per model and window length): the sine rows of
+        every (window length, position) and their W_qk^T images per encoder layer (cone_pos_tables)."""
+        lib, h = _lib.load(), self._h()
+        if getattr(self, "_pos_tabs", None) is None or self._pos_tabs[0] != max_v_l:
+            rows = lib.cone_pos_table_rows(max_v_l)
+            dev = self.device
+            pos_rows = torch.empty(rows, self.hidden_dim, device=dev)
+            pos_qk = torch.empty(self.args.enc_layers, rows, 2 * self.hidden_dim, device=dev)
+            _lib.check(lib.cone_pos_tables(h, max_v_l, _lib.ptr(pos_rows), _lib.ptr(pos_qk), _lib.stream()))
+            self._pos_tabs = (max_v_l, dict(pos_rows=pos_rows, pos_qk=pos_qk))
+        return self._pos_tabs[1]
+
+    def layer0_cache(self, vproj, tproj, max_v_l: int):
+        """cone_layer0 for forward_packed: per-row q|k|v caches + the static position tables."""
+        return dict(qkv_vid=self.layer0_rows(vproj), qkv_txt=self.layer0_rows(tproj), max_v_l=max_v_l,
+                    **self.pos_tables(max_v_l))
 
     def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None,
                        saliency: bool = True):
         """CONE.forward on windows given by index into projected token arenas.  ``saliency=False`` skips the
         saliency head (cone/inference.py computes and never reads it, :54-59)."""
         lib, h = _lib.load(), self._h()
-        l0s = None
+        l0s = l0p = None
         if l0 is not None:
             l0s = _lib.Layer0(l0["qkv_vid"].data_ptr(), l0["qkv_txt"].data_ptr(), l0["pos_qk"].data_ptr(),
-                              l0["max_v_l"])
+                              l0["pos_rows"].data_ptr() if l0.get("pos_rows") is not None else None, l0["max_v_l"])
+            l0p = C.byref(l0s)
         B = vid_row0.shape[0]
         dev = vproj.device
         nq = self.num_queries
         logits = torch.empty(B, nq, 2, device=dev)
         spans = torch.empty(B, nq, 2, device=dev)
         sal = torch.empty(B, Lv_max, device=dev) if saliency else None
-        nbytes = lib.cone_forward_packed_workspace(h, B, Lv_max, Lq_max)
+        nbytes = lib.cone_forward_packed_workspace(h, B, Lv_max, Lq_max, l0p)
         ws = self._ws.get(nbytes, dev)
         i32 = torch.int32
         _lib.check(lib.cone_forward_packed(h, _lib.ptr(vproj), _lib.ptr(vid_row0, i32), _lib.ptr(vid_len, i32),
                                            _lib.ptr(tproj), _lib.ptr(txt_row0, i32), _lib.ptr(txt_len, i32), B,
                                            Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), None,
-                                           C.byref(l0s) if l0s is not None else None,
-                                           _lib.ptr(ws), ws.numel(), _lib.stream()))
+                                           l0p, _lib.ptr(ws), ws.numel(), _lib.stream()))
         out = {"pred_logits": logits, "pred_spans": spans}
         if saliency:
             out["saliency_scores"] = sal

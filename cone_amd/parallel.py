@@ -3,14 +3,18 @@
 The reference is single-device; this is the MI355X-native extension the hot path
 allows: after the pre-filter every (query, window) pair is independent until the per-query fusion + NMS.
 
-Two shard modes
-  * ``"window"`` -- the flat (query, window) list is cut into contiguous slices, one per rank; each rank
-    runs the window model on its slice and the per-window proposal rows (Nq x 4 fp32 = 80 B / window)
-    are ``all_gather``-ed so that the owner of a query holds all its candidates; fusion + NMS run on
-    the owner; the kept rows are gathered for rank 0 to write.  This is BASELINE config 4: one long
-    video / few queries still fill 8 GPUs.
-  * ``"query"``  -- whole queries per rank (NMS is rank-local); only the kept rows are gathered.  The
-    cheapest exchange; preferred when there are at least a few hundred queries per GPU.
+Two shard modes of ``predict_split_distributed``
+  * ``"window"`` -- BASELINE config 4.  The flat (query, window) list is cut into contiguous slices, one per
+    rank; each rank projects only the clips / text tokens its slice reads, runs the window model on the slice
+    and the per-window proposal rows (Nq x 4 fp32 = 80 B / window) are exchanged with ONE fixed-size
+    ``all_gather_into_tensor`` (the slice sizes follow from the replicated window table: no size exchange, no
+    host sync).  Fusion + NMS over all queries then run on every rank (one workgroup per query, ~0.2 ms for
+    1 000 queries -- cheaper than a second collective), so every rank ends the step holding the kept rows of the
+    whole split; each rank formats the submission rows of its own query shard and rank 0 those of all.
+    One long video / few queries still fill 8 GPUs.
+  * ``"query"``  -- whole queries per rank (fusion + NMS are rank-local); only the kept rows are exchanged, again
+    in one fixed-size all_gather.  The pre-filter is replicated (it is HBM-bound and cheap) so that the
+    reference-batch padding of hazard H3 is that of the whole split whatever the cut points are.
 
 One huge video (BASELINE configs 3 / 5: MAD-scale ctx_l, features 12.7 GB) shards the PRE-FILTER instead:
 ``ctx_shard`` cuts the window list into contiguous ranges, each rank holds only the clip rows its windows
@@ -21,13 +25,15 @@ stable descending rank list bit for bit.
 Messages are tiny (<= 1.6 KB / query) and latency-bound: ONE all_gather per batch of queries, never per
 query.  xGMI is point-to-point (7 links per GPU), which a single small all_gather does not stress.
 
-The communication helpers take the process group and plain tensors, so they run unchanged on the
-``gloo`` backend (CPU tensors) -- that is how tests/test_parallel_cpu.py exercises them with 2 ranks.
+The drivers take their per-rank compute through a small ``hooks`` object (default: the HIP pipeline of
+``cone_amd.inference``), so the very same sharding / exchange / assembly code runs on the ``gloo`` backend with
+CPU tensors and a CPU checker injected as hooks -- that is how tests/test_parallel_cpu.py covers world sizes 2 and 3.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+from typing import Callable, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -39,22 +45,50 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def all_gather_fixed(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenate, in rank order, per-rank tensors whose dim-0 sizes are ``shard_range(n_total, r, world)``
+    -- known on every rank, so there is no size exchange and no host sync: ONE ``all_gather_into_tensor`` on
+    a buffer padded to the largest shard (ceil(n_total / world) rows)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_range(n_total, rank, world)
+    assert local.shape[0] == hi - lo, (local.shape, lo, hi)
+    if world == 1:
+        return local
+    cap = -(-n_total // world)
+    tail = tuple(local.shape[1:])
+    send = local
+    if local.shape[0] != cap:
+        send = torch.zeros((cap,) + tail, dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if n_total == world * cap:
+        return recv
+    # ranks < n_total % world hold `cap` rows, the others cap - 1: drop each short rank's one padding row
+    extra = n_total % world
+    keep = torch.ones(world, cap, dtype=torch.bool)
+    keep[extra:, cap - 1] = False
+    return recv[keep.reshape(-1).to(recv.device)]
+
+
 def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
-    """Concatenate per-rank tensors that differ only in dim 0 (rank order).  One size all_gather
-    (8 B / rank) + one padded payload all_gather."""
+    """Concatenate per-rank tensors that differ in dim 0 by amounts NOT known to the other ranks (rank order):
+    one size all_gather (8 B / rank, one host sync) + one padded payload all_gather.  The drivers below never
+    need it -- their shard sizes are static -- it serves ad-hoc gathers (tools, tests)."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sizes = sizes.tolist()
     nmax = max(sizes)
     pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous(), group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    recv = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, pad, group=group)
+    return torch.cat([recv[r * nmax:r * nmax + s] for r, s in enumerate(sizes)], dim=0)
 
 
 def run_window_sharded(n_windows: int, compute_rows: Callable[[int, int], torch.Tensor], group=None):
@@ -64,19 +98,35 @@ def run_window_sharded(n_windows: int, compute_rows: Callable[[int, int], torch.
     lo, hi = shard_range(n_windows, rank, world)
     local = compute_rows(lo, hi)
     assert local.shape[0] == hi - lo
-    return all_gather_rows(local, group)
+    return all_gather_fixed(local, n_windows, group)
+
+
+def pack_kept(rows: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
+    """(3, nq, A, 5) fp64 kept rows + (3, nq) counts -> ONE (nq, 3, A*5 + 1) fp64 message (count in the last
+    slot; exact in fp64), so that a query shard's results travel in a single collective."""
+    t, nq, A, _ = rows.shape
+    msg = torch.empty(nq, t, A * 5 + 1, dtype=torch.float64, device=rows.device)
+    msg[:, :, :A * 5] = rows.permute(1, 0, 2, 3).reshape(nq, t, A * 5)
+    msg[:, :, A * 5] = n.t().to(torch.float64)
+    return msg
+
+
+def unpack_kept(msg: torch.Tensor):
+    nq, t, w = msg.shape
+    A = (w - 1) // 5
+    rows = msg[:, :, :A * 5].reshape(nq, t, A, 5).permute(1, 0, 2, 3).contiguous()
+    n = msg[:, :, A * 5].t().to(torch.int32).contiguous()
+    return rows, n
 
 
 def run_query_sharded(n_queries: int, compute_kept: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]],
                       group=None):
-    """Each rank runs stages A-C for its contiguous query shard; returns (rows, n) of all queries
-    in annotation order on every rank.  rows (3, nq, max_after, 5), n (3, nq): gathered along dim 1."""
+    """Each rank runs its contiguous query shard; returns (rows, n) of all queries in annotation order on
+    every rank.  rows (3, nq, max_after, 5), n (3, nq): ONE fixed-size all_gather."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_queries, rank, world)
     rows, n = compute_kept(lo, hi)
-    rows_all = all_gather_rows(rows.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()
-    n_all = all_gather_rows(n.transpose(0, 1).contiguous(), group).transpose(0, 1).contiguous()
-    return rows_all, n_all
+    return unpack_kept(all_gather_fixed(pack_kept(rows, n), n_queries, group))
 
 
 def assemble_candidates(rows_all: torch.Tensor, q_of: torch.Tensor, slot: torch.Tensor, nq: int, K: int):
@@ -144,7 +194,8 @@ def prefilter_ctx_sharded(ctx_local: torch.Tensor, ctx_l: int, cls_norm: torch.T
                           group=None, window_scores_fn: Callable = None, topk_fn: Callable = None):
     """Pre-filter (cone/inference.py:284-299) of ONE video whose clip rows are sharded over the ranks of
     `group` as ``ctx_shard`` prescribes.  Every rank returns the same (idx (nq,k) int32 global window
-    ids, -1 padded; val (nq,k)).  One all_gather of k x (4 + 4) B per query -- no feature row ever moves."""
+    ids, -1 padded; val (nq,k)).  One all_gather of k x (4 + 4) B per query (the window ids travel as exact
+    fp32 bit patterns next to the scores) -- no feature row ever moves."""
     if window_scores_fn is None or topk_fn is None:
         from . import ops
         window_scores_fn = window_scores_fn or (lambda v, c, w: ops.prefilter_scores(v, c, w)[1])
@@ -153,54 +204,130 @@ def prefilter_ctx_sharded(ctx_local: torch.Tensor, ctx_l: int, cls_norm: torch.T
     shard = ctx_shard(ctx_l, max_v_l, rank, world)
     val, idx = local_window_topk(ctx_local, shard, cls_norm, max_v_l, k, window_scores_fn, topk_fn)
     if world > 1:
-        vb = [torch.empty_like(val) for _ in range(world)]
-        ib = [torch.empty_like(idx) for _ in range(world)]
-        dist.all_gather(vb, val.contiguous(), group=group)
-        dist.all_gather(ib, idx.contiguous(), group=group)
-        val, idx = torch.cat(vb, dim=1), torch.cat(ib, dim=1)
+        nq = val.shape[0]
+        send = torch.stack([val, idx.view(torch.float32)], dim=0).contiguous()        # (2, nq, k): one message
+        recv = torch.empty((world * 2, nq, k), dtype=torch.float32, device=send.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view(world, 2, nq, k)
+        val = recv[:, 0].permute(1, 0, 2).reshape(nq, world * k).contiguous()
+        idx = recv[:, 1].contiguous().view(torch.int32).permute(1, 0, 2).reshape(nq, world * k).contiguous()
     return merge_topk(val, idx, k, topk_fn)
 
 
 # ---------------------------------------------------------------------------------- drivers
+class HipHooks:
+    """The per-rank compute of the drivers on the HIP pipeline (cone_amd.inference)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.num_queries = model.num_queries
+
+    def prefilter(self, store, opt):
+        from . import inference as inf
+        return inf.prefilter(self.model, store, opt)
+
+    def project_video(self, store, row_range=None):
+        from . import inference as inf
+        return inf.project_video(self.model, store, row_range)
+
+    def window_rows(self, store, opt, wt, video):
+        """(Nw, Nq, 4) rows of the windows of table ``wt`` (all of them queries of ``store``)."""
+        from . import inference as inf
+        return inf.run_windows(self.model, store, opt, wt, inf.project_features(self.model, store, video))["rows"]
+
+    def fuse_nms(self, cand, n_valid, opt):
+        from . import ops
+        rows, n, _ = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
+        return rows, n
+
+
+def _slice_table(wt, lo, hi, q_lo, tok_base):
+    """Rows [lo, hi) of a window table of the whole split, re-based onto the view that starts at query q_lo
+    (whose first text token is row ``tok_base`` of the split's token arena)."""
+    sl = {k: v[lo:hi] for k, v in wt.items()}
+    sl["q_of"] = sl["q_of"] - q_lo
+    sl["cls_row"] = sl["cls_row"] - q_lo
+    sl["txt_row0"] = sl["txt_row0"] - tok_base
+    return sl
+
+
 @torch.no_grad()
-def predict_split_distributed(model, store, opt, mode: str = "window", group=None):
-    """Stages A->C across the ranks of `group`; rank 0 returns the three submission lists, the other
-    ranks return None.  Every rank holds the same FeatureStore (features replicated: an Ego4D split
-    is < 1 GB, the MAD-scale stress video 12.7 GB of the 288 GB per GPU)."""
+def predict_split_distributed(model, store, opt, mode: str = "window", group=None, hooks=None,
+                              format_shard: bool = False):
+    """Stages A->C across the ranks of `group`.  Every rank holds the same FeatureStore (features replicated:
+    an Ego4D split is < 1 GB, the MAD-scale stress video 12.7 GB of the 288 GB per GPU).
+
+    Returns ``(lists, info)``: ``info['rows'] / info['n']`` = the kept rows of ALL queries, on every rank (tensors);
+    ``lists`` = the three submission lists -- of all queries on rank 0 and ``None`` elsewhere, or, with
+    ``format_shard=True``, of the rank's own query shard ``info['shard']`` on every rank (the host formatting
+    shards with the queries; a caller that wants one file concatenates the shards in rank order)."""
     from . import inference as inf
-    from . import ops
-    rank = dist.get_rank(group)
+    hooks = hooks or HipHooks(model)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     nq = len(store.ann)
-    Nq = model.num_queries
+    Nq = hooks.num_queries
+    win_idx = hooks.prefilter(store, opt)               # replicated: HBM-bound and cheap (SURVEY 8e)
+    batch_pad = inf.reference_batch_pad(store, opt, win_idx)
+    q_lo, q_hi = shard_range(nq, rank, world)
     if mode == "query":
         def kept(lo, hi):
+            if hi == lo:
+                A = opt.max_after_nms
+                return (torch.zeros(3, 0, A, 5, dtype=torch.float64, device=win_idx.device),
+                        torch.zeros(3, 0, dtype=torch.int32, device=win_idx.device))
             sub = inf.FeatureStore.subset(store, lo, hi)
-            dp = inf.device_pipeline(model, sub, opt)
-            return dp["rows"], dp["n"]
+            wi = win_idx[lo:hi].contiguous()
+            wt = inf.window_table(sub, opt, wi, batch_pad)
+            vid_rows = _video_row_range(store, lo, hi)
+            rows = hooks.window_rows(sub, opt, wt, hooks.project_video(store, vid_rows))
+            cand, n_valid = inf.candidate_lists(rows, wt, wi, Nq)
+            return hooks.fuse_nms(cand, n_valid, opt)
         rows, n = run_query_sharded(nq, kept, group)
+        n_windows = int((win_idx >= 0).sum()) if not _dense(store, opt, win_idx) else nq * win_idx.shape[1]
     elif mode == "window":
-        win_idx = inf.prefilter(model, store, opt)          # replicated: HBM-bound and cheap (SURVEY 8e)
-        wt = inf.window_table(store, opt, win_idx)
-        feats = inf.project_features(model, store)
+        wt = inf.window_table(store, opt, win_idx, batch_pad)
         n_win = int(wt["vid_row0"].shape[0])
+        lo, hi = shard_range(n_win, rank, world)
 
         def rows_of(lo, hi):
-            sl = {k: v[lo:hi] for k, v in wt.items()}
             if hi == lo:
-                return torch.zeros(0, Nq, 4, device=store.device)
-            return inf.run_windows(model, store, opt, sl, feats)["rows"]
+                return torch.zeros(0, Nq, 4, device=win_idx.device)
+            # the slice's queries [a, b]: only their text tokens and the clips of their videos are projected
+            a, b = _query_span(store, opt, win_idx, wt, lo, hi)
+            sub = inf.FeatureStore.subset(store, a, b + 1)
+            video = hooks.project_video(store, _video_row_range(store, a, b + 1))
+            return hooks.window_rows(sub, opt, _slice_table(wt, lo, hi, a, int(store.tok_off[a])), video)
         rows_all = run_window_sharded(n_win, rows_of, group)
-        K = win_idx.shape[1]
-        cand = assemble_candidates(rows_all, wt["q_of"], wt["slot"], nq, K)
-        n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
-
-        def kept(lo, hi):
-            r, n_, _ = ops.fuse_nms(cand[lo:hi].contiguous(), n_valid[lo:hi].contiguous(), opt.nms_thd,
-                                    opt.max_before_nms, opt.max_after_nms)
-            return r, n_
-        rows, n = run_query_sharded(nq, kept, group)
+        cand, n_valid = inf.candidate_lists(rows_all, wt, win_idx, Nq)
+        rows, n = hooks.fuse_nms(cand, n_valid, opt)    # every rank, all queries: cheaper than a second collective
+        n_windows = n_win
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
+    info = dict(rows=rows, n=n, win_idx=win_idx, n_windows=n_windows, shard=(q_lo, q_hi), world=world)
+    if format_shard:
+        return inf.format_results(store.ann[q_lo:q_hi], opt, rows[:, q_lo:q_hi], n[:, q_lo:q_hi]), info
     if rank != 0:
-        return None
-    return inf.format_results(store.ann, opt, rows, n)
+        return None, info
+    return inf.format_results(store.ann, opt, rows, n), info
+
+
+def _dense(store, opt, win_idx):
+    K, S = win_idx.shape[1], int(opt.max_v_l / 2)
+    return min(store.ctx_l) > (K - 2) * S
+
+
+def _query_span(store, opt, win_idx, wt, lo, hi):
+    """First and last query (annotation index) that own a window in rows [lo, hi) of the table."""
+    if _dense(store, opt, win_idx):                     # row r belongs to query r // K: no device read
+        K = win_idx.shape[1]
+        return lo // K, (hi - 1) // K
+    ends = wt["q_of"][[lo, hi - 1]].tolist()
+    return int(ends[0]), int(ends[1])
+
+
+def _video_row_range(store, q_lo, q_hi):
+    """Arena rows [r0, r1) of the videos the queries [q_lo, q_hi) refer to (queries of a video are adjacent in the
+    reference's annotation files, so this is a narrow band; correctness does not depend on it)."""
+    vids = np.asarray(store.q_vid[q_lo:q_hi])
+    v0, v1 = int(vids.min()), int(vids.max())
+    return int(store.vid_off[v0]), int(store.vid_off[v1 + 1])

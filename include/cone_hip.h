@@ -15,8 +15,10 @@
  *     it, nothing synchronises, nothing allocates (scratch comes in through `ws`);
  *   - return value 0 = success, negative = error (CONE_E_*), text in cone_last_error();
  *     nothing throws across the ABI;
- *   - a cone_model is immutable after creation: one handle may be used from several
- *     streams/threads concurrently as long as each call has its own workspace.
+ *   - a cone_model is immutable after creation (cone_model_set_option, a parity-test hook, is the
+ *     one exception and must not race with calls on the handle): one handle may be used from several
+ *     streams/threads concurrently as long as each call has its own workspace.  The library keeps no
+ *     other mutable state besides the opt-in launch timer (cone_prof_*).
  */
 #ifndef CONE_HIP_H
 #define CONE_HIP_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 1
+#define CONE_HIP_ABI_VERSION 2
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -151,18 +153,31 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
  * [txt_row0[b], +txt_len[b]).  This is how the eval driver avoids re-projecting the clips shared by
  * overlapping windows and the text replicated across a query's windows.
  * Lv_max/Lq_max bound the lengths (host-known); saliency is (B, Lv_max). */
-/* Optional cache of the FIRST encoder layer's in_proj, which is row-wise like the input projections:
- * (x + pos) W^T + b = (x W^T + b) + pos W^T.  qkv_vid (n_clips, 3d) / qkv_txt (n_tokens, 3d) =
- * cone_layer0_project of the projected arenas (once per clip / per text token instead of once per
- * window row); pos_qk (cone_layer0_pos_rows(max_v_l), 2d) = cone_layer0_pos_table (static per model):
- * row Lv(Lv-1)/2 + p holds PositionEmbeddingSine(Lv, p) [W_q | W_k]^T.  With it, layer 0's q|k|v
- * rows are gathered instead of multiplied (two M-row GEMMs, ~10 % of the FLOPs, become a copy). */
-typedef struct { const float* qkv_vid; const float* qkv_txt; const float* pos_qk; int32_t max_v_l; } cone_layer0;
-int64_t cone_layer0_pos_rows(int max_v_l);
-int cone_layer0_pos_table(const cone_model* m, int max_v_l, float* pos_qk, void* ws, size_t ws_bytes, void* stream);
+/* Optional row caches + static position tables.  Everything ahead of the first attention is row-wise, and the
+ * position term enters every attention through a LINEAR map, so it can be split off and tabulated:
+ *   (x + pos) W^T + b = (x W^T + b) + pos W^T.
+ * qkv_vid (n_clips, 3d) / qkv_txt (n_tokens, 3d) = cone_layer0_project of the projected arenas: the FIRST encoder
+ *   layer's in_proj once per clip / per text token instead of once per window row (two M-row GEMMs, ~10 % of the
+ *   FLOPs, become a gather inside the attention kernel);
+ * pos_rows (R, d), R = cone_pos_table_rows(max_v_l): row Lv(Lv-1)/2 + p = PositionEmbeddingSine of clip p of a
+ *   window with Lv valid clips (cone/position_encoding.py:51-72; text tokens carry no position, cone/model.py:106);
+ * pos_qk (enc_layers, R, 2d): pos_rows [W_q | W_k]^T of every encoder layer (no bias).
+ * With the tables the later encoder layers run ONE N = 3d GEMM on x (the attention kernel adds the pos_qk row to
+ * q | k in its staging loads) and the decoder's cross-attention forms its keys memory + pos from pos_rows: no
+ * x + pos matrix is ever written.  pos_rows may be NULL: then only layer 0 uses the cache (pos_qk layer 0) and the
+ * later layers read an x + pos matrix written by the previous layer's epilogue. */
+typedef struct {
+    const float* qkv_vid; const float* qkv_txt;
+    const float* pos_qk; const float* pos_rows;
+    int32_t max_v_l;
+} cone_layer0;
+int64_t cone_pos_table_rows(int max_v_l);
+int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream);
 int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* stream);
 
-size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max);
+/* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows) with the tables, 13 KiB without. */
+size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
+                                     const cone_layer0* l0 /* as passed to cone_forward_packed */);
 int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                         const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
                         const int32_t* txt_len, int B, int Lv_max, int Lq_max,
@@ -244,23 +259,26 @@ int cone_eval_window_recall(const int32_t* win_idx, int nq, int k, const double*
  * line).  cone_prof_enable(1) clears and starts recording, (0) stops.  After synchronising the
  * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
  * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
- * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, 0); kind 4 = frame-score
+ * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, source mode); kind 4 = frame-score
  * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq).  Returns the record count.  Not thread-safe. */
 int cone_prof_enable(int on);
 int64_t cone_prof_collect(double* out, int64_t max_rec);
 
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
-/* Process-wide A/B switches for the parity tests.  "dec_fold" (default 1): decoder cross-attention with the
- * memory K/V projections folded into one kernel per layer; 0 = two stacked K/V GEMMs + per-head attention.
+/* A/B switches of ONE model handle for the parity tests (not thread-safe; set them before using the handle).
+ * "dec_fold" (default 1): decoder cross-attention with the memory K/V projections folded into one kernel per layer;
+ *   0 = two stacked K/V GEMMs + per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
- * caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
+ *   caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
+ * "pos_tables" (default 1): later encoder layers and the decoder keys take the position term from the static
+ *   tables of cone_layer0; 0 = from an x + pos matrix written by the previous layer's GEMM epilogue.
  * "dec0_const" (default 1): the first decoder layer's self-attention block and cross-attention queries (tgt = 0:
- * the same for every window) are computed for one window and replicated; 0 = for all windows.  Bit-identical.
- * "gemm_waves" (default 8): row-owning GEMM tile as 8 waves x 16 rows on 16x16x4 MFMA; 4 = 4 waves x 32 rows on
- * 32x32x2 (same slabs; both are exact-fp32 fma chains per output element that walk k in different orders).
- * "attn16" (default 1): encoder attention on 16x16x4 MFMA tiles, one wave per 16 queries; 0 = 32x32x2 tiles. */
-int cone_test_set_option(const char* name, int value);
+ *   the same for every window) are computed for one window and replicated; 0 = for all windows.  Bit-identical.
+ * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
+ *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
+ *   exact-fp32 fma chains per output element that walk k in different orders. */
+int cone_model_set_option(cone_model* m, const char* name, int value);
 /* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
  * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning LDS-DMA tile
  * with 4 waves x 32 rows, 3 = the same tile with 8 waves x 16 rows, 0 = automatic = 3 where the shape allows).  Optional second output C2 = C + ADD (row tile only). */

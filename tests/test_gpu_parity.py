@@ -231,33 +231,29 @@ def test_stage_b_window_length_boundaries(Lv, Lq):
 
 
 @pytest.mark.parametrize("preset", ["ego4d", "mad"])
-def test_encoder_attention_tile_variants_agree(preset):
-    """The 16x16x4-tile encoder attention (one wave per 16 queries, default) and the 32x32x2-tile kernel compute the
-    same softmax(QK^T)V up to fp32 summation order."""
-    from cone_amd import _lib
-    model, opt, _ = get_model(preset, 0 if preset == "ego4d" else 1)
-    rng = np.random.default_rng(5)
-    B = 19
-    lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
-    lens_v[0], lens_v[1], lens_v[2] = opt.max_v_l, 1, 16
-    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
-    lens_q[0], lens_q[1], lens_q[2] = opt.max_q_l, 1, 16
-    inp = gi.stage_b_inputs(opt, 321, lens_v, lens_q)
-    dev = _gpu()
-    g = lambda a: torch.from_numpy(a).to(dev)
-    lib = _lib.load()
+def test_position_tables_equal_materialised_pos_path(preset):
+    """Later encoder layers / decoder keys with the position term taken from the static tables ((x + pos) W^T =
+    x W^T + pos W^T, one N = 768 GEMM per layer, no x + pos matrix) against the path that materialises x + pos in
+    the previous layer's epilogue: same math up to fp32 re-association, on ragged windows of both presets."""
+    from cone_amd import inference as inf
+    model, opt0, _ = get_model(preset, 0 if preset == "ego4d" else 1)
+    opt = make_opt(preset, nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8, need_saliency=True)
+    ann, vf, qf = synth.make_dataset(opt, 19, 3, seed=15, ctx_range=(40, 420))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    wt = inf.window_table(store, opt, inf.prefilter(model, store, opt))
     outs = []
     try:
-        for v in (1, 0):
-            _lib.check(lib.cone_test_set_option(b"attn16", v))
-            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
-            outs.append({k: o[k].cpu() for k in ("pred_logits", "pred_spans", "hs", "memory")})
+        for tab in (1, 0):
+            model.set_option("pos_tables", tab)
+            outs.append(inf.run_windows(model, store, opt, wt))
     finally:
-        _lib.check(lib.cone_test_set_option(b"attn16", 1))
-    vm = _valid_token_mask(lens_v, lens_q, inp["src_vid"].shape[1], inp["src_txt"].shape[1])
-    assert (outs[0]["memory"] - outs[1]["memory"]).abs().numpy()[vm].max() < 2e-5
-    for k in ("pred_logits", "pred_spans", "hs"):
-        assert maxdiff(outs[0][k], outs[1][k]) < 5e-5, k      # measured 2.2e-5 on logits of magnitude 6
+        model.set_option("pos_tables", 1)
+    assert int((wt["vid_len"] < opt.max_v_l).sum()) > 0          # ragged windows are in the batch
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert maxdiff(outs[0][k], outs[1][k].cpu()) < 5e-5, k
+    safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
+    d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
+    assert float(d[safe].max()) < 5e-5
 
 
 def test_padding_independence_and_determinism():
@@ -518,6 +514,25 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path):
     assert worst <= 2e-4, worst                      # proposal probability, after 4-dp rounding
     # seconds = span * window_len * clip_length: the 1e-4 span tolerance scales accordingly
     assert worst_sec <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4, worst_sec
+    # matching column (index 3) against the reference rows.  Rows of a window are sorted by proposal score, so
+    # compare window by window after aligning on the (unique) proposal scores; a proposal whose floor / ceil clip
+    # boundary sits within 1e-3 of an integer may legitimately pool one clip more or less -- those are
+    # masked through the raw spans of a separate forward pass, everything else must agree to 1e-4 + 4-dp rounding
+    wt = inf.window_table(store, opt, win_idx)
+    raw = inf.run_windows(model, store, opt, wt)
+    safe = _safe_proposals(raw["pred_spans"].cpu(), wt["vid_len"].cpu().numpy()).numpy()
+    order = torch.argsort(torch.softmax(raw["pred_logits"], -1)[..., 0], dim=1, descending=True, stable=True).cpu().numpy()
+    n_cmp, worst_match = 0, 0.0
+    for w, (a, b) in enumerate(zip(mr, fx["mr_res"])):
+        ra, rb = np.array(a["pred_relevant_windows"]), np.array(b["pred_relevant_windows"])
+        if np.abs(ra[:, 2] - rb[:, 2]).max() > 2e-4 or len(set(rb[:, 2].tolist())) < len(rb):
+            continue                                   # (never happens on the fixtures: guarded for clarity)
+        ok = safe[w][order[w]]
+        if ok.any():
+            worst_match = max(worst_match, np.abs(ra[ok, 3] - rb[ok, 3]).max())
+            n_cmp += int(ok.sum())
+    assert n_cmp >= 0.9 * safe.size, (n_cmp, safe.size)
+    assert worst_match <= 2e-4, worst_match            # matching score, after 4-dp rounding
     # stage C on the REFERENCE's own window rows reproduces its files exactly
     f2, p2, m2 = (inf.postprocessing_format_mad if preset == "mad" else inf.postprocessing_format_ego4d)(fx["mr_res"], opt)
     ext = "jsonl" if preset == "mad" else "json"
@@ -526,11 +541,36 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path):
         fn = f"inference_{preset}_test_golden_{tag}preds.{ext}"
         ref_rows = [json.loads(l) for l in files[fn].split("\n")] if preset == "mad" else json.loads(files[fn])["results"]
         assert json.loads(json.dumps(got)) == ref_rows
-    # and the full device pipeline writes files of the same structure
+    # and the full device pipeline writes the reference's files: same structure, and the same kept moments
+    # wherever the candidate rows upstream round to the same 4-dp values (a candidate within float noise of a
+    # rounding boundary can change the min-max normalisation of its whole query, so whole queries are compared)
     res, _, strs, paths = inf.eval_epoch(model, store, opt, f"inference_{preset}_test_golden_preds.{ext}")
     written = [os.path.join(str(tmp_path), f"inference_{preset}_test_golden_{tag}preds.{ext}")
                for tag in ("", "proposal_", "matching_")]
     assert all(os.path.exists(p) for p in written)
+    same_rows = {}
+    for a, b in zip(mr, fx["mr_res"]):
+        same_rows[a["query_id"]] = same_rows.get(a["query_id"], True) and \
+            a["pred_relevant_windows"] == b["pred_relevant_windows"]
+    n_same = n_close = 0
+    for tag, path in zip(("", "proposal_", "matching_"), written):
+        fn = os.path.basename(path)
+        ref_rows = [json.loads(l) for l in files[fn].split("\n")] if preset == "mad" else json.loads(files[fn])["results"]
+        with open(path) as fh:
+            got_rows = [json.loads(l) for l in fh.read().split("\n")] if preset == "mad" else json.load(fh)["results"]
+        assert len(got_rows) == len(ref_rows)
+        for g_, r_, row in zip(got_rows, ref_rows, ann):
+            assert {k: v for k, v in g_.items() if k != "predicted_times"} == \
+                {k: v for k, v in r_.items() if k != "predicted_times"}
+            if same_rows[row["query_id"]]:
+                assert g_["predicted_times"] == r_["predicted_times"], (tag, row["query_id"])
+                n_same += 1
+            else:   # rows differ in the last printed digit somewhere: the kept moments still agree closely
+                ga, rb_ = np.array(g_["predicted_times"]), np.array(r_["predicted_times"])
+                if ga.shape == rb_.shape and np.abs(ga[:, :2] - rb_[:, :2]).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
+                    n_close += 1
+    assert n_same + n_close >= 0.9 * 3 * len(ann), (n_same, n_close, len(ann))
+    assert n_same > 0
     if preset == "mad":     # the reference scores the MAD test split too (cone/inference.py:332): .txt + tables
         assert paths[0].endswith(".txt") and paths[1] == written[0] and len(strs) == 4 and res.shape == (5, 3)
     else:                   # Ego4D test: files only (the reference exits there, :476-477)
@@ -575,7 +615,7 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
 
 def test_distributed_drivers_single_rank_equal_plain_pipeline():
     """Window- and query-sharded drivers (RCCL backend, world_size 1 on the one-GPU box) reproduce the
-    plain pipeline bit for bit; the 2-rank exchange logic itself is covered on gloo in
+    plain pipeline bit for bit; the multi-rank sharding / exchange logic itself runs on gloo with 2 and 3 ranks in
     tests/test_parallel_cpu.py."""
     import torch.distributed as dist
     from cone_amd import inference as inf
@@ -590,14 +630,57 @@ def test_distributed_drivers_single_rank_equal_plain_pipeline():
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         for mode in ("window", "query"):
-            got = par.predict_split_distributed(model, store, opt, mode=mode)
+            got, info = par.predict_split_distributed(model, store, opt, mode=mode)
             assert got == plain, mode
-        # a query shard in the middle of the split sees the right arenas
-        sub = inf.FeatureStore.subset(store, 3, 8)
-        part, _ = inf.predict_split(model, sub, opt)
-        assert part[0] == plain[0][3:8]
+            assert info["shard"] == (0, 11) and info["world"] == 1
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["window", "query"])
+def test_virtual_rank_shards_reproduce_the_full_run(mode):
+    """What each rank of an N-rank run computes, replayed rank by rank on the one GPU (same code path as
+    predict_split_distributed: shard_range cuts, FeatureStore.subset views, the split's padding table, the banded
+    clip projection): the per-window rows / kept rows of every shard are BIT-identical to the single-GPU run, also
+    when a cut falls inside a reference batch of short videos (hazard H3: pad_len differs between batches)."""
+    from cone_amd import inference as inf
+    from cone_amd import parallel as par
+    model, _, _ = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=4, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(opt, 10, 3, seed=9, ctx_range=(20, 120))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    full = inf.device_pipeline(model, store, opt)
+    win_idx = full["win_idx"]
+    batch_pad = inf.reference_batch_pad(store, opt, win_idx)
+    assert len(set(full["windows"]["pad_len"].cpu().tolist())) > 1       # sensitive to the batch a window sits in
+    hooks = par.HipHooks(model)
+    for world in (3, 8):
+        if mode == "query":
+            for r in range(world):
+                lo, hi = par.shard_range(len(ann), r, world)
+                if hi == lo:
+                    continue
+                sub = inf.FeatureStore.subset(store, lo, hi)
+                dp = inf.device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi].contiguous(), batch_pad=batch_pad,
+                                         video=inf.project_video(model, store, par._video_row_range(store, lo, hi)))
+                assert torch.equal(dp["rows"], full["rows"][:, lo:hi]) and torch.equal(dp["n"], full["n"][:, lo:hi])
+                assert torch.equal(dp["cand"], full["cand"][lo:hi])
+        else:
+            wt = full["windows"]
+            n_win = int(wt["vid_row0"].shape[0])
+            ref_rows = full["outputs"]["rows"]
+            for r in range(world):
+                lo, hi = par.shard_range(n_win, r, world)
+                if hi == lo:
+                    continue
+                a, b = par._query_span(store, opt, win_idx, wt, lo, hi)
+                sub = inf.FeatureStore.subset(store, a, b + 1)
+                video = hooks.project_video(store, par._video_row_range(store, a, b + 1))
+                rows = hooks.window_rows(sub, opt, par._slice_table(wt, lo, hi, a, int(store.tok_off[a])), video)
+                assert torch.equal(rows, ref_rows[lo:hi]), (world, r)
+    # an unaligned view without the split's table is refused instead of silently re-deriving the padding
+    with pytest.raises(ValueError):
+        inf.device_pipeline(model, inf.FeatureStore.subset(store, 3, 8), opt, win_idx=win_idx[3:8].contiguous())
 
 
 def test_layer0_gather_cache_equals_gemm_path():
@@ -616,19 +699,22 @@ def test_layer0_gather_cache_equals_gemm_path():
     for k in ("pred_logits", "pred_spans"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < TOL, k     # measured ~3e-5 on logits of magnitude 10
     # the in-kernel gather of the first layer's q|k|v is the same arithmetic as the packing kernel: bit-identical
-    from cone_amd import _lib
-    lib = _lib.load()
     try:
-        _lib.check(lib.cone_test_set_option(b"l0_gather", 0))
+        model.set_option("l0_gather", 0)
         opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8, layer0_cache=True)
         ann, vf, qf = synth.make_dataset(opt, 17, 3, seed=5, ctx_range=(60, 300))
         store = inf.FeatureStore(opt, ann, vf, qf)
         wt = inf.window_table(store, opt, inf.prefilter(model, store, opt))
         packed = inf.run_windows(model, store, opt, wt)
+        model.set_option("l0_gather", 1)
+        model.set_option("pos_tables", 0)        # the gather with the materialised x + pos path behind it
+        gathered = inf.run_windows(model, store, opt, wt)
     finally:
-        _lib.check(lib.cone_test_set_option(b"l0_gather", 1))
+        model.set_option("l0_gather", 1)
+        model.set_option("pos_tables", 1)
     for k in ("pred_logits", "pred_spans", "matching"):
-        assert torch.equal(outs[0][k], packed[k]), k
+        assert torch.equal(gathered[k], packed[k]), k
+        assert maxdiff(outs[0][k], packed[k].cpu()) < TOL, k
 
 
 @pytest.mark.parametrize("preset", ["ego4d", "mad"])
@@ -651,22 +737,32 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
     outs = []
     try:
         for fold in (1, 0):
-            _lib.check(lib.cone_test_set_option(b"dec_fold", fold))
+            model.set_option("dec_fold", fold)
             o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
             outs.append({k: o[k].cpu() for k in ("pred_logits", "pred_spans", "hs")})
     finally:
-        _lib.check(lib.cone_test_set_option(b"dec_fold", 1))
-    assert lib.cone_test_set_option(b"no_such_option", 1) != 0
+        model.set_option("dec_fold", 1)
+    with pytest.raises(_lib.ConeHipError):
+        model.set_option("no_such_option", 1)
     for k in ("pred_logits", "pred_spans", "hs"):
         assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
     # the first decoder layer's window-independent rows (tgt = 0) computed once and replicated: identical bits
     try:
-        _lib.check(lib.cone_test_set_option(b"dec0_const", 0))
+        model.set_option("dec0_const", 0)
         o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
     finally:
-        _lib.check(lib.cone_test_set_option(b"dec0_const", 1))
+        model.set_option("dec0_const", 1)
     for k in ("pred_logits", "pred_spans", "hs"):
         assert torch.equal(o[k].cpu(), outs[0][k]), k
+    # every GEMM tile family computes the same layers (exact-fp32 fma chains in different k orders)
+    try:
+        for fam in (1, 2):
+            model.set_option("gemm", fam)
+            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+            for k in ("pred_logits", "pred_spans", "hs"):
+                assert maxdiff(o[k], outs[0][k]) < 5e-5, (fam, k)
+    finally:
+        model.set_option("gemm", 0)
 
 
 @pytest.mark.parametrize("ctx_l,W,dv,nq,k,world", [(901, 90, 256, 3, 20, 8), (131, 90, 256, 2, 5, 8),
@@ -957,4 +1053,151 @@ def test_localizer_matches_reference_golden(golden_dir):
         assert len(got) == len(ref)
         got = np.array(got)
         assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1e-4 * 90 * fx["clip_length"] + 1e-4     # seconds
-        assert np.abs(got[:, 2] - ref[:, 2]).max() < 2e-3                                        # fused (min-max normalised)
+        # fused = minmax(proposal) + minmax(matching) over the 100 candidates of the query (run_on_video/
+        # cone_localizator.py:200-209): a score error e becomes e / (max - min) after the normalisation, and both
+        # extremes carry an error too, so the bound is 3 * 1e-4 / range per term.  The candidates' matching scores
+        # are cosines that span only ~0.1-0.2 on these inputs (proposal probabilities span ~1), i.e. the 1e-4 score
+        # tolerance maps to ~3e-3 on the fused value; the assertion keeps the tighter 2e-3.
+        assert np.abs(got[:, 2] - ref[:, 2]).max() < 2e-3
+
+
+# ------------------------------------------------------------------------------- the reference's data sources
+def _checkpoint_dir(tmp_path, saved, seed):
+    sdn = synth.make_state_dict(saved, seed)
+    ckpt_dir = tmp_path / "run"
+    ckpt_dir.mkdir()
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in sdn.items()}, "epoch": 3}, ckpt_dir / "model_best.ckpt")
+    with open(ckpt_dir / "opt.json", "w") as f:
+        json.dump({k: v for k, v in vars(saved).items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
+    return ckpt_dir, sdn
+
+
+def test_cli_on_reference_lmdb_stores_and_debug_flag(tmp_path, monkeypatch):
+    """The reference's command line WITHOUT the packed-store extension: annotations + the two LMDBs of np.savez
+    blobs (test-only lmdb backend, the package is not in the image) -> FeatureStore.from_lmdb -> the same three
+    prediction files as the packed path; ``--debug`` stops the window model after the first batch of eval_bsz
+    queries like cone/inference.py:93-94."""
+    import sys
+    import fake_lmdb
+    from test_host_cpu import _write_reference_stores
+    from cone_amd import inference as inf, pack_features
+    monkeypatch.setitem(sys.modules, "lmdb", fake_lmdb)
+    base = make_opt("ego4d", nms_thd=0.5, topk_window=4, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(base, 11, 2, seed=12, ctx_range=(150, 400))
+    vdir, tdir, eval_path = _write_reference_stores(tmp_path, base, ann, vf, qf)
+    saved = make_opt("ego4d", nms_thd=0.5, topk_window=4, eval_bsz=4, motion_feat_dir=vdir, appearance_feat_dir=vdir,
+                     t_feat_dir=tdir, results_dir=str(tmp_path / "train_dir"))
+    ckpt_dir, _ = _checkpoint_dir(tmp_path, saved, 5)
+    outs = {}
+    for tag, extra in (("lmdb", []), ("packed", None), ("debug", ["--debug"])):
+        out_dir = tmp_path / f"out_{tag}"
+        out_dir.mkdir()
+        argv = ["--resume", str(ckpt_dir / "model_best.ckpt"), "--eval_split_name", "test", "--eval_path", eval_path,
+                "--eval_id", "x", "--eval_results_dir", str(out_dir), "--nms_thd", "0.5", "--save_all"]
+        if extra is None:
+            packed = str(tmp_path / "split.conefs")
+            pack_features.main(argv[:6] + ["--out", packed])
+            extra = ["--packed_features", packed]
+        res, _, strs, paths = inf.start_inference(argv + extra)
+        assert res is None and len(paths) == 3
+        outs[tag] = [json.load(open(p))["results"] for p in paths]
+    assert outs["lmdb"] == outs["packed"]
+    assert all(len(x) == 11 for x in outs["lmdb"])
+    assert all(len(x) == 4 for x in outs["debug"]) and outs["debug"][0] == outs["lmdb"][0][:4]
+
+
+def test_eval_epoch_accepts_the_reference_dataset_objects(tmp_path):
+    """cone/inference.py:227-228's call shape, as cone/train.py:164-168 uses it: eval_epoch(model, inter_ds, intra_ds,
+    opt, filename, epoch_i, criterion, tb_writer).  Text features arrive already normalised by the dataset object (on
+    the host, numpy) instead of by the device kernel: same rank lists, rows equal within the logit tolerance."""
+    from test_host_cpu import RefLikeDatasets
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=4, save_all=True,
+                   results_dir=str(tmp_path))
+    ann, vf, qf = synth.make_dataset(opt, 9, 2, seed=14, ctx_range=(150, 400))
+    ds = RefLikeDatasets(opt, ann, vf, qf)
+    res, miou, strs, paths = inf.eval_epoch(model, ds, ds, opt, "inference_ego4d_test_ds_preds.json", 7, None, None)
+    assert res is None and len(paths) == 3 and hasattr(ds, "_cone_amd_store")
+    got = json.load(open(paths[0]))["results"]
+    (fusion, _, _), info = inf.predict_split(model, inf.FeatureStore(opt, ann, vf, qf), opt)
+    assert torch.equal(inf.prefilter(model, ds._cone_amd_store, opt), info["win_idx"])
+    close = 0
+    for a, b in zip(got, json.loads(json.dumps(fusion))):
+        assert {k: v for k, v in a.items() if k != "predicted_times"} == {k: v for k, v in b.items() if k != "predicted_times"}
+        pa, pb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        close += pa.shape == pb.shape and np.abs(pa - pb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4
+    assert close >= len(got) - 1
+
+
+# ------------------------------------------------------------------------------- BASELINE configs 3 and 5 at full size
+@pytest.mark.parametrize("nq", [1, 64])
+def test_mad_scale_prefilter_full_size(nq):
+    """BASELINE configs[2] at its real size: ctx_l = 6.2 M clips x 512 = 3.2e9 elements (past 2^31; 12.7 GB resident),
+    100 001 windows of 125 clips; 1 query (streaming kernel) and 64 queries (fp32-MFMA GEMM whose N is ctx_l).
+    Frame scores on rows sampled over the whole range (first, last, around element 2^31 and 2^32 / 4) against a torch
+    product on those rows; window max exact against the frame scores; stable top-30 == torch.sort(stable=True)."""
+    from cone_amd import ops
+    dev = _gpu()
+    ctx_l, dv, W, k = 6_200_000, 512, 125, 30
+    S = W // 2
+    g = torch.Generator(device=dev).manual_seed(3)
+    vid = torch.randn(ctx_l, dv, device=dev, generator=g)
+    vid = ops.l2_normalize(vid, 1e-5)
+    txt = ops.l2_normalize(torch.randn(nq, dv, device=dev, generator=g), 1e-5)
+    vid[4_000_000] = vid[1_000]                    # exact ties between far-apart windows
+    vid[5_999_999] = vid[1_000]
+    fs, ws = ops.prefilter_scores(vid, txt, W)
+    nw = ops.num_windows(ctx_l, W)
+    assert fs.shape == (nq, ctx_l) and ws.shape == (nq, nw) and nw == 100_001
+    edge = (1 << 31) // dv
+    rows = torch.cat([torch.arange(0, 300), torch.arange(edge - 300, edge + 300), torch.arange(2 * edge - 300, 2 * edge + 300),
+                      torch.arange(ctx_l - 300, ctx_l), torch.randint(0, ctx_l, (4000,))]).to(dev)
+    ref = (vid[rows].double() @ txt.double().t()).t()
+    assert float((fs[:, rows].double() - ref).abs().max()) < 1e-6
+    # window max: exact (max is order-free) -- all windows of a few queries via unfold on the interior + the edges
+    for q in range(min(nq, 2)):
+        f = fs[q]
+        inner = f[:(nw - 3) * S + W].unfold(0, W, S).max(dim=1).values          # windows 1 .. nw-2 start at (i-1)*S
+        assert torch.equal(ws[q, 1:1 + inner.shape[0]], inner)
+        assert float(ws[q, 0]) == float(f[:S].max())
+        last = nw - 1
+        assert float(ws[q, last]) == float(f[(last - 1) * S:min((last - 1) * S + W, ctx_l)].max())
+    idx, val = ops.topk_windows(ws, k)
+    sv, si = torch.sort(ws, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.long(), si[:, :k]) and torch.equal(val, sv[:, :k])
+    del vid, fs, ws
+    torch.cuda.empty_cache()
+
+
+def test_config5_64_queries_one_mad_length_video():
+    """BASELINE configs[4] on one GPU: 64 concurrent queries over ONE MAD-length video (ctx_l 33 000, d 512,
+    window_len 125, top-30 => 1 920 windows) end to end; rank lists of all queries and the full pipeline of a sample
+    of queries against the oracle."""
+    from cone_amd import inference as inf
+    model, opt0, sd = get_model("mad", 1)
+    opt = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=30, eval_bsz=16)
+    ann, vf, qf = synth.make_dataset(opt, 64, 1, seed=0, ctx_range=(33_000, 33_001))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    (fusion, prop, match), info = inf.predict_split(model, store, opt)
+    assert info["n_windows"] == 64 * 30 and len(fusion) == 64
+    with torch.no_grad():
+        ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+    for qi, row in enumerate(ann):
+        assert info["win_idx"][qi].cpu().tolist() == ranks[row["query_id"]][:30], qi
+    # the oracle end to end on the first reference batch (16 queries = 480 windows): same batch composition, so the
+    # H3 padding is the reference's
+    sub_ann = ann[:16]
+    with torch.no_grad():
+        mr = O.compute_mr_results(sd, opt, sub_ann, vf, qf, ranks)
+    mine, _ = inf.compute_mr_results(model, inf.FeatureStore.subset(store, 0, 16), opt, info["win_idx"][:16].contiguous())
+    assert len(mine) == len(mr) == 480
+    A = lambda r: np.array(r["pred_relevant_windows"])
+    assert max(np.abs(A(a)[:, 2] - A(b)[:, 2]).max() for a, b in zip(mine, mr)) <= 2e-4
+    assert max(np.abs(A(a)[:, :2] - A(b)[:, :2]).max() for a, b in zip(mine, mr)) <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
+    fo, _, _ = O.postprocess(mr, opt)
+    agree = 0
+    for a, b in zip(fusion[:16], fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        agree += ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4
+    assert agree >= 14, agree

@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cone_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-    assert lib.cone_abi_version() == 1
+    assert lib.cone_abi_version() == 2
     assert lib.cone_num_windows(901, 90) == 22 and lib.cone_num_windows(1250, 125) == 22
 
 
@@ -72,7 +72,8 @@ def test_test_options_opt_json_round_trip(tmp_path):
                               "--eval_id", "e1", "--nms_thd", "0.5", "--topk_window", "20", "--max_v_l", "7"])
     assert opt.nms_thd == 0.5 and opt.topk_window == 20          # CLI wins (cone/config.py:190-193)
     assert opt.max_v_l == 90 and opt.clip_length == 0.535         # opt.json wins
-    assert opt.results_dir == str(tmp_path) and opt.model_dir == str(tmp_path)
+    assert opt.model_dir == str(tmp_path)
+    assert opt.results_dir == saved["results_dir"]                # the saved one, unless --eval_results_dir (:194-195)
 
 
 def test_window_table_matches_oracle_collate():
@@ -137,3 +138,106 @@ def test_packed_feature_store_round_trip(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         FeatureStore.from_packed(opt, str(bad), device=cpu)
+
+
+def _write_reference_stores(tmp_path, opt, ann, vf, qf, eot=False):
+    """The reference's on-disk inputs: annotation jsonl + the two LMDBs of np.savez blobs (fake lmdb backend)."""
+    import fake_lmdb
+    vdir = fake_lmdb.write_env(str(tmp_path / "vid_lmdb"), {c: {"features": v} for c, v in vf.items()})
+    cls_key = "eot_features" if eot else "cls_features"
+    tdir = fake_lmdb.write_env(str(tmp_path / "txt_lmdb"),
+                               {q: {"token_features": d["token_features"],
+                                    cls_key: d["cls_features"][None] if eot else d["cls_features"]}
+                                for q, d in qf.items()})
+    eval_path = tmp_path / "split.jsonl"
+    eval_path.write_text("\n".join(json.dumps(r) for r in ann))
+    return vdir, tdir, str(eval_path)
+
+
+def test_feature_store_from_reference_lmdbs(tmp_path, monkeypatch):
+    """FeatureStore.from_lmdb reads the reference's feature stores (np.savez blobs keyed by clip_id / query_id,
+    ``features`` / ``token_features`` + ``cls_features`` or a 2-D ``eot_features``): same arenas as building the
+    store from the arrays; data_ratio keeps a prefix; pack_features converts them to the packed arena file."""
+    import sys
+    import fake_lmdb
+    from cone_amd.inference import FeatureStore
+    from cone_amd import pack_features
+    monkeypatch.setitem(sys.modules, "lmdb", fake_lmdb)
+    cpu = torch.device("cpu")
+    for preset, eot in (("ego4d", False), ("mad", True)):
+        base = make_opt(preset)
+        ann, vf, qf = synth.make_dataset(base, 9, 3, seed=2, ctx_range=(30, 90), lq_range=(3, 30))
+        d = tmp_path / preset
+        d.mkdir()
+        vdir, tdir, eval_path = _write_reference_stores(d, base, ann, vf, qf, eot=eot)
+        opt = make_opt(preset, eval_path=eval_path, motion_feat_dir=vdir, appearance_feat_dir=vdir, t_feat_dir=tdir)
+        a = FeatureStore(opt, ann, vf, qf, device=cpu)
+        b = FeatureStore.from_lmdb(opt, device=cpu)
+        assert b.ann == a.ann and b.clip_ids == a.clip_ids and b.tok_len == a.tok_len
+        assert max(b.tok_len) == base.max_q_l                       # tokens truncated to max_q_l (dataloader :272-273)
+        for k in ("vid_raw", "tok_raw", "cls_raw"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (preset, k)
+        half = FeatureStore.from_lmdb(make_opt(preset, eval_path=eval_path, motion_feat_dir=vdir,
+                                               appearance_feat_dir=vdir, t_feat_dir=tdir, data_ratio=0.5), device=cpu)
+        assert len(half.ann) == 4 and half.cls_raw.shape[0] == 4
+        # python -m cone_amd.pack_features: LMDBs -> one packed arena file
+        saved = {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, type(None)))}
+        (d / "opt.json").write_text(json.dumps(saved))
+        (d / "model_best.ckpt").write_bytes(b"")
+        out = str(d / "split.conefs")
+        pack_features.main(["--resume", str(d / "model_best.ckpt"), "--eval_path", eval_path, "--eval_split_name",
+                            "val", "--out", out])
+        c = FeatureStore.from_packed(opt, out, device=cpu)
+        for k in ("vid_raw", "tok_raw", "cls_raw"):
+            assert torch.equal(getattr(a, k), getattr(c, k)), (preset, k)
+    with pytest.raises(KeyError):
+        FeatureStore.from_lmdb(make_opt("ego4d", eval_path=eval_path, motion_feat_dir=vdir, appearance_feat_dir=vdir,
+                                        t_feat_dir=vdir), device=cpu)       # queries looked up in the video store
+
+
+class RefLikeDatasets:
+    """Objects with the attributes of the reference's PreFilteringDataset / StartEndDataset that eval_epoch's
+    reference call shape reads (cone/ego4d_mad_dataloader.py:19-103, 258-282, 397-431), over in-memory features."""
+
+    def __init__(self, opt, ann, vf, qf, normalize_t=True):
+        self.data = self.query_data = ann
+        self.videofeat = {c: torch.from_numpy(v) for c, v in vf.items()}      # RAW features (hazard H2)
+        self.same_visual_path, self.normalize_t, self.load_labels = True, normalize_t, False
+        self._opt, self._qf = opt, qf
+        self.query_id2windowidx = None
+
+    def _get_query_feat_by_qid(self, qid):
+        tok, cls = O.prepare_query_inputs(self._opt, self._qf[qid])
+        if not self.normalize_t:
+            tok = torch.from_numpy(np.asarray(self._qf[qid]["token_features"], dtype=np.float32)[:self._opt.max_q_l])
+        return tok, cls.numpy()
+
+
+def test_feature_store_from_reference_dataset_objects():
+    from cone_amd.inference import FeatureStore
+    opt = make_opt("ego4d")
+    ann, vf, qf = synth.make_dataset(opt, 7, 2, seed=3, ctx_range=(30, 90), lq_range=(3, 30))
+    ds = RefLikeDatasets(opt, ann, vf, qf)
+    st = FeatureStore.from_datasets(opt, ds, ds, device=torch.device("cpu"))
+    plain = FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+    assert st.tok_normalized and st.cls_normalized and not plain.tok_normalized
+    assert torch.equal(st.vid_raw, plain.vid_raw) and st.tok_len == plain.tok_len
+    ref_tok = torch.cat([O.prepare_query_inputs(opt, qf[r["query_id"]])[0] for r in ann])
+    assert torch.equal(st.tok_raw, ref_tok)                                    # already normalised: taken as is
+    raw = FeatureStore.from_datasets(opt, ds, RefLikeDatasets(opt, ann, vf, qf, normalize_t=False),
+                                     device=torch.device("cpu"))
+    assert not raw.tok_normalized and torch.equal(raw.tok_raw, plain.tok_raw)
+
+
+def test_debug_and_results_dir_options(tmp_path):
+    saved = vars(make_opt("ego4d"))
+    saved.update(results_dir="/some/training/dir", results_root="runs/cone_results")
+    (tmp_path / "opt.json").write_text(json.dumps(saved))
+    ckpt = tmp_path / "model_best.ckpt"
+    ckpt.write_bytes(b"")
+    base = ["--resume", str(ckpt), "--eval_split_name", "test", "--eval_path", "x.jsonl", "--eval_id", "e"]
+    opt = parse_test_options(base)
+    assert opt.results_dir == "/some/training/dir" and not opt.debug           # saved results_dir stays (:194-195)
+    opt = parse_test_options(base + ["--eval_results_dir", str(tmp_path), "--debug", "--results_root", "a/b"])
+    assert opt.results_dir == str(tmp_path) and opt.debug and opt.num_workers == 0
+    assert opt.results_root == os.path.join("a", "debug_results")             # cone/config.py:179-181

@@ -1,6 +1,7 @@
-"""World-size-2 tests of the multi-GPU plumbing on the gloo backend (CPU tensors): shard ranges, the
-padded all_gather of per-window proposal rows, window- and query-sharded drivers.  The per-rank compute
-is injected (here: the CPU oracle), so no GPU is needed."""
+"""World-size-2 and -3 tests of the multi-GPU path on the gloo backend (CPU tensors): shard ranges, the
+fixed-size all_gather of per-window proposal rows / kept rows, and the window- and query-sharded drivers of
+cone_amd.parallel themselves -- real FeatureStore (on the CPU device), real window table, real sharding and
+assembly; only the per-rank compute is injected (the CPU oracle), so no GPU is needed."""
 import os
 import socket
 
@@ -47,66 +48,161 @@ def _oracle_rows(opt, sd, ann, vf, qf, ranks):
     return torch.tensor(rows, dtype=torch.float32)
 
 
+class CheckerHooks:
+    """Per-rank compute of predict_split_distributed on the CPU: the oracle's window rows, looked up by (query,
+    rank slot), and its fusion + NMS.  While serving a window it CHECKS the window-table row the driver built
+    for it -- clip range, text range, and the reference-batch padding of hazard H3 -- against the oracle's own
+    collate of the whole split, so a shard that re-derives any of them from its own queries fails here."""
+    num_queries = 5
+
+    def __init__(self, opt, sd, ann, vf, qf, store):
+        self.opt, self.ann, self.store = opt, ann, store
+        self.ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+        sdt = O.as_torch_sd(sd)
+        self.rows, self.meta = {}, {}
+        with torch.no_grad():
+            for b0 in range(0, len(ann), opt.eval_bsz):
+                metas, mi, ci = O.build_batch(opt, ann[b0:b0 + opt.eval_bsz], vf, qf, self.ranks)
+                out = O.cone_forward(sdt, opt, **mi)
+                match = O.clip_matching(sdt, opt, proposal=out["pred_spans"], **ci)
+                comp = O.compose_rows(opt, out["pred_logits"], out["pred_spans"], match,
+                                      [m["duration"] for m in metas], [m["video_start"] for m in metas])
+                pad = int(mi["src_vid_motion"].shape[1])
+                qpos = {r["query_id"]: b0 + i for i, r in enumerate(ann[b0:b0 + opt.eval_bsz])}
+                seen = {}
+                for m, r in zip(metas, comp):
+                    q = qpos[m["query_id"]]
+                    slot = seen.get(q, 0)
+                    seen[q] = slot + 1
+                    self.rows[(q, slot)] = torch.tensor(r, dtype=torch.float32)
+                    self.meta[(q, slot)] = (m["duration"], m["video_start"], pad)
+        self.served = 0
+
+    def prefilter(self, store, opt):
+        K = opt.topk_window
+        wi = torch.full((len(store.ann), K), -1, dtype=torch.int32)
+        for i, r in enumerate(store.ann):
+            lst = self.ranks[r["query_id"]][:K]
+            wi[i, :len(lst)] = torch.tensor(lst, dtype=torch.int32)
+        return wi
+
+    def project_video(self, store, row_range=None):
+        r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
+        return dict(vid_base=r0, rows=(r0, r1))
+
+    def window_rows(self, sub, opt, wt, video):
+        out = []
+        r0, r1 = video["rows"]
+        for w in range(int(wt["vid_row0"].shape[0])):
+            lq = int(wt["q_of"][w])
+            assert 0 <= lq < len(sub.ann)
+            q = lq + sub.q_base
+            dur, vstart, pad = self.meta[(q, int(wt["slot"][w]))]
+            assert int(wt["vid_len"][w]) == dur and int(wt["video_start"][w]) == vstart
+            assert int(wt["pad_len"][w]) == pad, ("H3 padding", q, int(wt["pad_len"][w]), pad)
+            row0 = int(self.store.vid_off[self.store.q_vid[q]]) + vstart
+            assert int(wt["vid_row0"][w]) == row0 and r0 <= row0 and row0 + dur <= r1      # inside the projected band
+            assert int(wt["txt_len"][w]) == sub.tok_len[lq] and int(wt["txt_row0"][w]) == int(sub.tok_off[lq])
+            assert int(wt["cls_row"][w]) == lq
+            out.append(self.rows[(q, int(wt["slot"][w]))])
+            self.served += 1
+        return torch.stack(out) if out else torch.zeros(0, 5, 4)
+
+    def fuse_nms(self, cand, n_valid, opt):
+        A = opt.max_after_nms
+        nq = cand.shape[0]
+        r = torch.zeros(3, nq, A, 5, dtype=torch.float64)
+        n = torch.zeros(3, nq, dtype=torch.int32)
+        for qi in range(nq):
+            rd = O.score_fusion(O.round4_rows(cand[qi, :int(n_valid[qi])].tolist()))
+            for t, idx in enumerate((2, 0, 1)):
+                keep = O.post_processing_mr_nms(opt, rd, idx)
+                n[t, qi] = len(keep)
+                if keep:
+                    r[t, qi, :len(keep)] = torch.tensor(keep, dtype=torch.float64)
+        return r, n
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # 1. ragged all_gather
+        # 1. gathers: ragged (sizes exchanged) and fixed (sizes = shard_range, no exchange)
         local = torch.arange((rank + 1) * 6, dtype=torch.float32).view(rank + 1, 2, 3) + 100 * rank
         got = par.all_gather_rows(local)
         exp = torch.cat([torch.arange((r + 1) * 6, dtype=torch.float32).view(r + 1, 2, 3) + 100 * r
                          for r in range(world)])
         assert torch.equal(got, exp)
         assert par.all_gather_rows(torch.zeros(0, 5)).shape == (0, 5)
+        for n_total in (0, 1, world - 1, world, world + 1, 7 * world + 2):
+            lo, hi = par.shard_range(n_total, rank, world)
+            mine = torch.arange(lo, hi, dtype=torch.float64).view(-1, 1).repeat(1, 3)
+            got = par.all_gather_fixed(mine, n_total)
+            assert torch.equal(got, torch.arange(n_total, dtype=torch.float64).view(-1, 1).repeat(1, 3)), n_total
+        rows = torch.rand(3, 4, 5, 5, dtype=torch.float64)
+        n = torch.randint(0, 6, (3, 4), dtype=torch.int32)
+        r2, n2 = par.unpack_kept(par.pack_kept(rows, n))
+        assert torch.equal(r2, rows) and torch.equal(n2, n)
 
-        # 2. window-sharded stage B + owner-side stage C == single-process oracle
-        opt = make_opt("ego4d", nms_thd=0.5, topk_window=3, eval_bsz=2, max_after_nms=5)
+        # 2. the drivers themselves (real window table, shard cuts INSIDE reference batches, short videos so
+        # that the H3 padding differs between batches) == the single-process oracle, bit for bit
+        from cone_amd import inference as inf
+        opt = make_opt("ego4d", nms_thd=0.5, topk_window=3, eval_bsz=4, max_after_nms=5, eval_split_name="test")
         sd = synth.make_state_dict(opt, 0)
-        ann, vf, qf = synth.make_dataset(opt, 5, 2, seed=9, ctx_range=(60, 200))
-        ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
-        all_rows = _oracle_rows(opt, sd, ann, vf, qf, ranks)          # every rank could compute all; it only uses its slice
-        n_win = all_rows.shape[0]
-        rows = par.run_window_sharded(n_win, lambda lo, hi: all_rows[lo:hi].clone())
-        assert torch.equal(rows, all_rows)
-        K = opt.topk_window
-        q_of = torch.tensor([qi for qi, r in enumerate(ann) for _ in ranks[r["query_id"]][:K]])
-        slot = torch.tensor([s for r in ann for s in range(len(ranks[r["query_id"]][:K]))])
-        cand = par.assemble_candidates(rows, q_of, slot, len(ann), K)
-
-        def kept(lo, hi):          # owner-side fusion + NMS with the oracle (python doubles)
-            A = opt.max_after_nms
-            r = torch.zeros(3, hi - lo, A, 5, dtype=torch.float64)
-            n = torch.zeros(3, hi - lo, dtype=torch.int32)
-            for qi in range(lo, hi):
-                nv = len(ranks[ann[qi]["query_id"]][:K]) * 5
-                rd = O.score_fusion(O.round4_rows(cand[qi, :nv].tolist()))
-                for t, idx in enumerate((2, 0, 1)):
-                    keep = O.post_processing_mr_nms(opt, rd, idx)
-                    n[t, qi - lo] = len(keep)
-                    if keep:
-                        r[t, qi - lo, :len(keep)] = torch.tensor(keep, dtype=torch.float64)
-            return r, n
-        rows_k, n_k = par.run_query_sharded(len(ann), kept)
-        if rank == 0:
+        for nq, nv, seed, ctx_range in ((10, 3, 9, (20, 120)), (5, 2, 4, (60, 200)), (2, 1, 1, (30, 50))):
+            ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=seed, ctx_range=ctx_range)
+            store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+            hooks = CheckerHooks(opt, sd, ann, vf, qf, store)
             (fo, po, mo), _, _ = O.eval_epoch(sd, opt, ann, vf, qf)
-            for t, ref in enumerate((fo, po, mo)):
-                for qi in range(len(ann)):
-                    got_rows = rows_k[t, qi, :int(n_k[t, qi])].tolist()
-                    assert got_rows == ref[qi]["predicted_times"], (t, qi)
+            for mode in ("window", "query"):
+                hooks.served = 0
+                lists, info = par.predict_split_distributed(None, store, opt, mode=mode, hooks=hooks)
+                assert info["world"] == world
+                for t, ref in enumerate((fo, po, mo)):        # every rank holds every query's kept rows
+                    for qi in range(nq):
+                        got_rows = info["rows"][t, qi, :int(info["n"][t, qi])].tolist()
+                        assert got_rows == ref[qi]["predicted_times"], (mode, t, qi)
+                if rank == 0:
+                    assert lists == (fo, po, mo), mode
+                else:
+                    assert lists is None
+                # the window model ran on a shard only, not on the whole split
+                assert hooks.served <= -(-info["n_windows"] // world) + opt.topk_window, (mode, hooks.served)
+                part, info2 = par.predict_split_distributed(None, store, opt, mode=mode, hooks=hooks, format_shard=True)
+                lo, hi = info2["shard"]
+                assert part == tuple(x[lo:hi] for x in (fo, po, mo)), mode
+        # a view cut inside a reference batch refuses to derive the padding from its own windows
+        ann, vf, qf = synth.make_dataset(opt, 10, 3, seed=9, ctx_range=(20, 120))
+        store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+        hooks = CheckerHooks(opt, sd, ann, vf, qf, store)
+        wi = hooks.prefilter(store, opt)
+        sub = inf.FeatureStore.subset(store, 3, 8)
+        try:
+            inf.window_table(sub, opt, wi[3:8])
+            raise AssertionError("unaligned view accepted without the split's padding table")
+        except ValueError:
+            pass
+        full = inf.window_table(store, opt, wi)
+        part = inf.window_table(sub, opt, wi[3:8], inf.reference_batch_pad(store, opt, wi))
+        sel = (full["q_of"] >= 3) & (full["q_of"] < 8)
+        assert torch.equal(part["pad_len"], full["pad_len"][sel]) and torch.equal(part["vid_row0"], full["vid_row0"][sel])
+        assert len(set(full["pad_len"].tolist())) > 1         # the case is sensitive to the batch a window sits in
+        if rank == 0:
             out.put("ok")
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_window_and_query_sharding():
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_window_and_query_sharded_drivers(world):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=240)
+        p.join(timeout=400)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out.get(timeout=5) == "ok"
 
