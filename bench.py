@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--set_option", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostics: flip an A/B switch of the model handle (cone_model_set_option), e.g. pos_tables=0")
     ap.add_argument("--window_batch", type=int, default=32768)
+    ap.add_argument("--pipeline_tail", type=float, default=None,
+                    help="fraction of the queries in the tail chunk of the host/GPU pipeline (default 1/8; 0 = one chunk)")
     ap.add_argument("--need_saliency", action="store_true",
                     help="A/B: also run the saliency head (the reference computes it and never reads it)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -282,7 +284,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
-                   window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks,
+                   window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks, pipeline_tail=args.pipeline_tail,
                    need_saliency=args.need_saliency)
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)

@@ -106,6 +106,10 @@ class FeatureStore:
         sub.q_vid = store.q_vid[lo:hi]
         sub._plan = None
         sub._index = None
+        if getattr(store, "_index", None) is not None:      # slice the parent's device-side metadata: no H2D copy
+            ix = store._index                               # (a pageable copy would wait for the stream to drain)
+            sub._index = dict(q_ctx_l=ix["q_ctx_l"][lo:hi], q_vid_off=ix["q_vid_off"][lo:hi],
+                              tok_off=ix["tok_off"][lo:hi + 1] - t0, tok_len=ix["tok_len"][lo:hi])
         return sub
 
     def index_tensors(self):
@@ -590,15 +594,21 @@ def _format_results(ann, opt, rows, n):
 
 
 def query_chunks(nq: int, opt):
-    """Query ranges for the software pipeline of predict_split: a few chunks, cut at multiples of eval_bsz so
-    that every reference batch (and with it the padded length of hazard H3) stays inside one chunk."""
+    """Query ranges for the software pipeline of predict_split, cut at multiples of eval_bsz (every reference batch
+    stays inside one chunk).  ``opt.pipeline_chunks = n``: n near-equal chunks; ``opt.pipeline_tail = f``: one head
+    chunk and a tail of fraction f of the queries (the host builds the head's submission rows while the GPU runs
+    the tail).  Default: ONE chunk.  Measured on MI355X (config 2, 20 000 windows, round 2): tails of 1/16, 1/8,
+    1/4 give 60.3 / 60.1 / 60.0 ms per step against 60.1 unchunked -- every extra chunk replays the ~110-launch
+    sequence whose small dependent kernels cost about as much GPU time as the host's list building it hides."""
+    nb = -(-nq // opt.eval_bsz)
     want = getattr(opt, "pipeline_chunks", None)
     if want is None:
-        # measured on MI355X (config 2, 20 000 windows): 1 chunk 68.0 ms, 2 chunks 71.0, 4 chunks 77.8 -- the tall
-        # GEMMs lose more to shorter launches than the overlap of the host's list building wins back; pipeline only
-        # splits that are several window batches long anyway
-        want = (nq * opt.topk_window) // (2 * int(getattr(opt, "window_batch", 32768)))
-    nb = -(-nq // opt.eval_bsz)
+        tail = float(getattr(opt, "pipeline_tail", None) or 0.0)
+        if tail <= 0 or nb < 8:
+            return [(0, nq)]
+        tb = max(1, int(round(nb * tail)))
+        cut = (nb - tb) * opt.eval_bsz
+        return [(0, cut), (cut, nq)]
     want = max(1, min(int(want), nb))
     cuts = sorted({min(nq, (-(-nb * i // want)) * opt.eval_bsz) for i in range(want + 1)})
     return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
@@ -630,6 +640,7 @@ def predict_split(model, store: FeatureStore, opt):
         dp["model_seconds"] = time.time() - t0
         return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
     # clip-side work once for the split, shared by the chunks (they are views of one arena)
+    store.index_tensors()
     win_idx = prefilter(model, store, opt)
     video = project_video(model, store)
     pend = []
@@ -649,7 +660,8 @@ def predict_split(model, store: FeatureStore, opt):
     model_seconds = time.time() - t0
     info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
                 n_windows=sum(p[1]["n_windows"] for p in pend), model_seconds=model_seconds, chunks=chunks,
-                win_idx=win_idx)
+                win_idx=win_idx,
+                windows={k: torch.cat([p[1]["windows"][k] for p in pend]) for k in ("vid_len", "txt_len")})
     return outs, info
 
 
