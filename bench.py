@@ -44,8 +44,19 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak F
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E peak BW (spec); 6.29 TB/s measured float4 copy
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn16_kernel", 4: "frame_score_kernel",
-                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_kernel"}
-GEMM_KINDS = (0, 1, 2, 5, 6)
+                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_kernel", 8: "ffn_fused_kernel<false>",
+                9: "ffn_fused_kernel<true>"}
+GEMM_KINDS = (0, 1, 2, 5, 6, 8, 9)   # records (kind, M, N, K, ms): 2*M*N*K FLOPs; kinds 8 / 9 (N = ff, K = 256): the
+#                                      feed-forward block = two such GEMMs, kind 9 + the 256 x 256 output projection
+
+
+def rec_flops(kind, a, b, c):
+    f = 2.0 * a * b * c
+    if kind in (8, 9):
+        f *= 2.0
+    if kind == 9:
+        f += 2.0 * a * 256 * 256
+    return f
 PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
@@ -103,7 +114,7 @@ def roofline_from_profile(rec):
             continue
         d = per.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
         d["ms"] += ms
-        d["flops"] += 2.0 * a * b * c
+        d["flops"] += rec_flops(k, a, b, c)
         d["launches"] += 1
     if not per:
         return None, {}
@@ -123,7 +134,7 @@ def roofline_from_profile(rec):
     for kind, a, b, c, ms in rec:       # the dominant kernel by (N, K): which layers pull the average down
         if int(kind) == dom and a >= 65536:
             d2 = shapes.setdefault(f"N{int(b)}_K{int(c)}", [0.0, 0.0, 0])
-            d2[0] += 2.0 * a * b * c
+            d2[0] += rec_flops(dom, a, b, c)
             d2[1] += ms
             d2[2] += 1
     roof["by_shape_tflops"] = {k: [round(v[0] / (v[1] * 1e-3) / 1e12, 1), v[2]] for k, v in sorted(shapes.items())}

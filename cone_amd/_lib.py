@@ -121,6 +121,8 @@ _SIGNATURES = {
     "cone_test_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_void_p]),
+    "cone_test_ffn": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]),
+    "cone_test_proj_ffn": (C.c_int, [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p]),
     "cone_test_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                       C.c_void_p]),
 }

@@ -49,6 +49,8 @@ struct cone_model {
     int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
     int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
     int opt_gemm = 0;         // GEMM tile family forced for every dense layer (GEMM_AUTO = by shape)
+    int opt_ffn_fused = 2;    // 1: linear1 + ReLU + linear2 + residual + LayerNorm as one kernel (ffn.hip); 2: the attention
+                              // output projection + residual + LayerNorm ahead of it in the same kernel as well; 0: GEMMs
 };
 
 namespace cone {
@@ -354,14 +356,26 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             src.Q = QK; src.K = QK + 256; src.V = V; src.ldq = src.ldk = 512; src.ldv = 256;
         }
         RUN(launch_enc_attn(mode, src, f.ATT, f.off, B, Lmax, s));
+        const bool fuse_ffn = plan.tables && m->opt_ffn_fused && ffn_fused_supported(ff);
+        if (fuse_ffn && m->opt_ffn_fused >= 2) {
+            // everything behind the attention in ONE launch: norm2(x1 + ffn(x1)), x1 = norm1(x + attn Wo^T + bo); a
+            // workgroup reads its 128 rows of x before it writes them, and nobody else touches them: in place
+            RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, f.X, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b, e.l2.w,
+                                      e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s));
+            continue;
+        }
         g = G(m, f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
         g.R = f.X; g.ldr = 256; g.ln_g = e.n1.g; g.ln_b = e.n1.b;
         RUN(launch_gemm(g, s));                                                             // norm1(x + attn)
-        RUN(launch_gemm(G(m, f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
-        g = G(m, f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
-        g.R = f.X1; g.ldr = 256; g.ln_g = e.n2.g; g.ln_b = e.n2.b;
-        if (!plan.tables) { g.C2 = f.XP; g.ADD = f.POS; }   // x + pos for the next layer's q/k / the decoder's keys
-        RUN(launch_gemm(g, s));                                                             // norm2(x + ffn)
+        if (fuse_ffn) {                                                                     // norm2(x + ffn), one kernel
+            RUN(launch_ffn_fused(f.X1, 256, e.l1.w, e.l1.b, e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s));
+        } else {
+            RUN(launch_gemm(G(m, f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
+            g = G(m, f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL | EPI_LN);
+            g.R = f.X1; g.ldr = 256; g.ln_g = e.n2.g; g.ln_b = e.n2.b;
+            if (!plan.tables) { g.C2 = f.XP; g.ADD = f.POS; }   // x + pos for the next layer's q/k / the decoder's keys
+            RUN(launch_gemm(g, s));                                                         // norm2(x + ffn)
+        }
     }
     const float* MEM = f.X;
 
@@ -403,13 +417,22 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         else
             RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
                                   m->nq, Lmax, s));
-        g = G(m, f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
-        g.R = f.TGT1; g.ldr = 256; g.ln_g = dl.n2.g; g.ln_b = dl.n2.b;
-        RUN(launch_gemm(g, s));
-        RUN(launch_gemm(G(m, f.TGT2, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
-        g = G(m, f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
-        g.R = f.TGT2; g.ldr = 256; g.ln_g = dl.n3.g; g.ln_b = dl.n3.b;
-        RUN(launch_gemm(g, s));
+        if (m->opt_ffn_fused >= 2 && ffn_fused_supported(ff)) {
+            RUN(launch_proj_ffn_fused(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b, dl.l1.w, dl.l1.b,
+                                      dl.l2.w, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
+        } else {
+            g = G(m, f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT2, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+            g.R = f.TGT1; g.ldr = 256; g.ln_g = dl.n2.g; g.ln_b = dl.n2.b;
+            RUN(launch_gemm(g, s));
+            if (m->opt_ffn_fused && ffn_fused_supported(ff)) {
+                RUN(launch_ffn_fused(f.TGT2, 256, dl.l1.w, dl.l1.b, dl.l2.w, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
+            } else {
+                RUN(launch_gemm(G(m, f.TGT2, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
+                g = G(m, f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL | EPI_LN);
+                g.R = f.TGT2; g.ldr = 256; g.ln_g = dl.n3.g; g.ln_b = dl.n3.b;
+                RUN(launch_gemm(g, s));
+            }
+        }
         // decoder.norm + heads on an intermediate layer only feed aux_outputs / the hs tap (unused by inference,
         // cone/inference.py:54-59): computed on request only
         if (l == nd - 1 || want_aux)
@@ -629,6 +652,11 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
     if (!strcmp(name, "l0_gather")) { m->opt_l0_gather = value != 0; return 0; }
     if (!strcmp(name, "dec0_const")) { m->opt_dec0_const = value != 0; return 0; }
     if (!strcmp(name, "pos_tables")) { m->opt_pos_tables = value != 0; return 0; }
+    if (!strcmp(name, "ffn_fused")) {
+        CONE_REQUIRE(value >= 0 && value <= 2, "set_option: ffn_fused %d not in [0, 2]", value);
+        m->opt_ffn_fused = value;
+        return 0;
+    }
     if (!strcmp(name, "gemm")) {
         CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
         m->opt_gemm = value;
@@ -646,6 +674,16 @@ extern "C" int cone_test_gemm(const float* A, const float* A2, int a2_mod, const
     g.A2 = A2; g.lda2 = K; g.a2_mod = a2_mod; g.R = R; g.ldr = N; g.ln_g = ln_g; g.ln_b = ln_b;
     g.C2 = C2; g.ADD = ADD;
     return launch_gemm(g, (hipStream_t)stream);
+}
+extern "C" int cone_test_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* stream) {
+    return launch_ffn_fused(X, 256, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff, (hipStream_t)stream);
+}
+extern "C" int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,
+                                  const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                                  const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* stream) {
+    return launch_proj_ffn_fused(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
+                                 (hipStream_t)stream);
 }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                                    int dim, void* stream) {

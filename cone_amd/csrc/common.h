@@ -61,7 +61,7 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 
 // ---------------------------------------------------------------- opt-in launch timing (prof.hip)
 enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4,
-                PK_GEMM_ROWS = 5, PK_GEMM_ROWS16 = 6, PK_DEC_CROSS = 7 };
+                PK_GEMM_ROWS = 5, PK_GEMM_ROWS16 = 6, PK_DEC_CROSS = 7, PK_FFN_FUSED = 8, PK_FFN_PROJ = 9 };
 bool prof_enabled();
 struct ProfScope {
     ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
@@ -92,6 +92,20 @@ struct GemmArgs {
 // whatever batch it sits in.
 enum { GEMM_AUTO = 0, GEMM_SQUARE = 1, GEMM_ROWS4 = 2, GEMM_ROWS8 = 3 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- fused feed-forward block (ffn.hip)
+// OUT = LayerNorm(X + W2 relu(W1 X + b1) + b2): X, OUT (M, 256); W1 (ff, 256); W2 (256, ff).  OUT may alias nothing
+// the kernel reads (X is re-read as the residual from registers only, but other workgroups read other rows).
+bool ffn_fused_supported(int ff);
+int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
+                     hipStream_t s);
+// The same with the block input computed in the kernel too: X = LayerNorm_p(R + A Wo^T + bo) (attention output
+// projection + residual + norm), i.e. everything of a transformer layer behind its attention in one launch.
+int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
+                          const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
+                          const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
+                          const int* M_dev, int ff, hipStream_t s);
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,

@@ -26,15 +26,15 @@
 // Weight stream.  Per 16-unit hidden chunk the workgroup needs W1[h0 .. h0+15][0..255] (16 KiB) and
 // W2[0..255][h0 .. h0+15] (16 KiB).  Both are staged by LDS-DMA (global_load_lds_dwordx4, no VGPRs) as 16 + 16 slabs of
 // [16 rows][16 floats] -- the operand-slab format of gemm.hip's row tile: unpadded 64-B rows, 16-B chunk XOR-swizzled
-// on the SOURCE address and on the ds_read_b128 address (conflict-free for lane = (row, chunk)) -- into a 3-stage
-// ring (96 KiB): chunk c+2 streams in while chunk c is multiplied, one counted s_waitcnt vmcnt + raw s_barrier per
+// on the SOURCE address and on the ds_read_b128 address (conflict-free for lane = (row, chunk)) -- into a 4-stage
+// ring (128 KiB): chunk c+2 streams in while chunk c is multiplied, one counted s_waitcnt vmcnt + raw s_barrier per
 // chunk (128 MFMAs per wave).  b1 is copied to LDS once so that no ordinary global load sits inside the loop (hipcc
 // would drain the DMA queue for it, cdna_hip_programming.md section 5 "Three .s-level traps" (b)).
 //
-// One 8-wave workgroup per CU (100 KiB of LDS, <= 256 VGPRs): two waves per SIMD keep the matrix pipe fed across each
-// other's GEMM1 -> GEMM2 hand-over; the prologue (x tile: 16 KiB per wave) and the epilogue (bias + residual +
-// LayerNorm in registers: a token's 256 channels sit in 4 lanes x 64 registers, two shuffle steps per moment; 64-B
-// row segments per store instruction) cost ~2 % of a tile's 8 192 MFMAs per wave.
+// One PERSISTENT 8-wave workgroup per CU (132 KiB of LDS, <= 256 VGPRs) walks the 128-row tiles: two waves per SIMD
+// keep the matrix pipe fed; GEMM1 of chunk i and GEMM2 of chunk i-1 share the units of one iteration (software
+// pipelining across chunks), so bias + ReLU never stall a chunk; the epilogue is bias + residual + LayerNorm in
+// registers (a token's 256 channels sit in 4 lanes x 64 registers, two shuffle steps per moment).
 #include <mutex>
 
 #include "common.h"
@@ -51,123 +51,29 @@ __device__ __forceinline__ int ffn_swz16(int row) { return (0x1230 >> (((row >> 
 
 constexpr int FFN_ROWS = 128;                     // token rows per workgroup (8 waves x 16)
 constexpr int FFN_STAGE = 2 * 16 * 256;           // floats per ring stage: W1 image (16 slabs) + W2 image (16 slabs)
-constexpr int FFN_NST = 3;
+constexpr int FFN_NST = 4;                        // ring depth: a stage is refilled two barriers after its last read
 constexpr int FFN_NPIECE = 4;                     // 1-KiB LDS-DMA pieces per wave per chunk (32 pieces / 8 waves)
 
 struct FfnArgs {
-    const float* X; int ldx;                      // (M, 256) input = residual
+    const float* X; int ldx;                      // (M, 256) block input = residual of the feed-forward block
     const float* W1; const float* b1;             // (ff, 256), (ff)
     const float* W2; const float* b2;             // (256, ff), (256)
     const float* ln_g; const float* ln_b;         // (256)
     float* OUT; int ldo;                          // (M, 256)
     int M; const int* M_dev;                      // rows; *M_dev wins when non-null (grid sized by M)
     int ff;
+    // PROJ: the block input is itself  LayerNorm(R + A Wo^T + bo)  (attention output projection + residual + norm,
+    // cone/transformer.py:239-241, 308-312), computed here instead of being read: A (M, 256) attention output,
+    // R (M, 256) residual; X is unused.
+    const float* A; int lda; const float* R; int ldr;
+    const float* Wo; const float* bo; const float* pg; const float* pb;
 };
 
-__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* b1s = smem + FFN_NST * FFN_STAGE;
-    int M = p.M;
-    if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
-    const int m_tile = blockIdx.x * FFN_ROWS;
-    if (m_tile >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    const int ff = p.ff, nc = ff >> 4;
-
-    // ---- this wave's input tile: x[token li][16 q + 4 lg .. + 3], q = 0 .. 15 (B operand of GEMM1 + the residual)
-    const int my_row = m_tile + wave * 16 + li;
-    const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);       // rows past M feed unstored outputs
-    f32x4f xr[16];
-    {
-        const float* xp = p.X + ld_row * p.ldx + 4 * lg;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const f32x4f*>(xp + 16 * q);
-    }
-    for (int i = tid; i < (ff >> 2); i += 512)
-        reinterpret_cast<f32x4f*>(b1s)[i] = reinterpret_cast<const f32x4f*>(p.b1)[i];
-
-    // ---- LDS-DMA pieces of a chunk: 32 slabs of [16 rows][16 floats]; wave w issues slabs 4w .. 4w+3 (0-15 = W1, 16-31
-    // = W2); lane -> (row = lane / 4, physical chunk = lane % 4), the source chunk is XOR-swizzled
-    const float* src[FFN_NPIECE];
-    int step[FFN_NPIECE], dst[FFN_NPIECE];
-#pragma unroll
-    for (int i = 0; i < FFN_NPIECE; ++i) {
-        const int pid = wave * FFN_NPIECE + i;
-        const int row = lane >> 2;
-        const int ch = (lane & 3) ^ ffn_swz16(row);
-        if (pid < 16) {     // W1[h0 + row][16 pid + 4 ch ..]; next chunk: 16 rows further
-            src[i] = p.W1 + (size_t)row * 256 + 16 * pid + 4 * ch;
-            step[i] = 16 * 256;
-        } else {            // W2[16 (pid - 16) + row][h0 + 4 ch ..]; next chunk: 16 columns further
-            src[i] = p.W2 + (size_t)(16 * (pid - 16) + row) * ff + 4 * ch;
-            step[i] = 16;
-        }
-        dst[i] = pid * 256;
-    }
-    auto stream_piece = [&](int c, int i) {
-        FFN_GLDS16(src[i] + (size_t)c * step[i], smem + (c % FFN_NST) * FFN_STAGE + dst[i]);
-    };
-
-    f32x4f y[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) y[t] = f32x4f{0.f, 0.f, 0.f, 0.f};
-    const int rd = li * 16 + ((lg ^ ffn_swz16(li)) << 2);          // this lane's 16-B chunk inside a slab
-
-#pragma unroll
-    for (int i = 0; i < FFN_NPIECE; ++i) stream_piece(0, i);
-    if (nc > 1) {
-#pragma unroll
-        for (int i = 0; i < FFN_NPIECE; ++i) stream_piece(1, i);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FFN_NPIECE) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();                                               // chunk 0 and the b1 image are in LDS
-    for (int c = 0; c < nc; ++c) {
-        const float* st = smem + (c % FFN_NST) * FFN_STAGE;
-        const bool more = c + 2 < nc;
-        // GEMM1: H^T chunk, four independent partial chains (one per k step of a slab)
-        f32x4f hp[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hp[r] = f32x4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const f32x4f w = *reinterpret_cast<const f32x4f*>(st + q * 256 + rd);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hp[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], xr[q][r], hp[r], 0, 0, 0);
-            if (more && (q & 3) == 1) stream_piece(c + 2, q >> 2);  // the next-but-one chunk's pieces ride behind MFMAs
-        }
-        const f32x4f bb = *reinterpret_cast<const f32x4f*>(b1s + 16 * c + 4 * lg);
-        f32x4f h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + bb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
-        // GEMM2: Y^T += W2[:, chunk] . H^T chunk, two output tiles at a time (independent accumulators)
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-            const f32x4f w0 = *reinterpret_cast<const f32x4f*>(st + 4096 + t * 256 + rd);
-            const f32x4f w1 = *reinterpret_cast<const f32x4f*>(st + 4096 + (t + 1) * 256 + rd);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], h[r], y[t], 0, 0, 0);
-                y[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], h[r], y[t + 1], 0, 0, 0);
-            }
-        }
-        // chunk c+1 must have landed (all but the pieces of chunk c+2 just issued), then everyone is done with chunk c
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FFN_NPIECE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- epilogue: + b2 + residual, LayerNorm over the token's 256 channels (4 lanes x 64 registers), store
+// LayerNorm over a token's 256 channels held as v[16] (channel 16 t + 4 lg + r in v[t][r]): 4 lanes x 64 registers.
+__device__ __forceinline__ void ffn_layernorm_regs(f32x4f (&v)[16], float& rstd) {
     float s1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const f32x4f b2v = *reinterpret_cast<const f32x4f*>(p.b2 + 16 * t + 4 * lg);
-        y[t] = y[t] + b2v + xr[t];
-        s1 += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
-    }
+    for (int t = 0; t < 16; ++t) s1 += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
     s1 += __shfl_xor(s1, 16, 64);
     s1 += __shfl_xor(s1, 32, 64);
     const float mean = s1 * (1.0f / 256.0f);
@@ -175,26 +81,378 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { y[t][r] -= mean; s2 = fmaf(y[t][r], y[t][r], s2); }
+        for (int r = 0; r < 4; ++r) { v[t][r] -= mean; s2 = fmaf(v[t][r], v[t][r], s2); }
     }
     s2 += __shfl_xor(s2, 16, 64);
     s2 += __shfl_xor(s2, 32, 64);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
+    rstd = 1.0f / sqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
+}
+
+template <bool PROJ>
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* b1s = smem + FFN_NST * FFN_STAGE;
+    int M = p.M;
+    if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
+    const int n_tiles = (M + FFN_ROWS - 1) / FFN_ROWS;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int ff = p.ff, nc = ff >> 4;
+    constexpr int NP = PROJ ? 8 : 0;              // leading chunks of the output projection (32 channels each)
+    const int G = NP + nc;                        // weight chunks per tile; the ring runs on across tiles
+
+    // every per-channel parameter vector goes to LDS once per workgroup: b1 (ff), then 6 x 256: b2, ln_g, ln_b and
+    // (PROJ) bo, pg, pb -- no ordinary global load remains inside the tile loop besides the tile's own rows
+    float* prm = b1s + ff;
+    for (int i = tid; i < (ff >> 2); i += 512)
+        reinterpret_cast<f32x4f*>(b1s)[i] = reinterpret_cast<const f32x4f*>(p.b1)[i];
+    if (tid < 64) {
+        reinterpret_cast<f32x4f*>(prm)[tid] = reinterpret_cast<const f32x4f*>(p.b2)[tid];
+        reinterpret_cast<f32x4f*>(prm + 256)[tid] = reinterpret_cast<const f32x4f*>(p.ln_g)[tid];
+        reinterpret_cast<f32x4f*>(prm + 512)[tid] = reinterpret_cast<const f32x4f*>(p.ln_b)[tid];
+        if (PROJ) {
+            reinterpret_cast<f32x4f*>(prm + 768)[tid] = reinterpret_cast<const f32x4f*>(p.bo)[tid];
+            reinterpret_cast<f32x4f*>(prm + 1024)[tid] = reinterpret_cast<const f32x4f*>(p.pg)[tid];
+            reinterpret_cast<f32x4f*>(prm + 1280)[tid] = reinterpret_cast<const f32x4f*>(p.pb)[tid];
+        }
+    }
+
+    // ---- LDS-DMA pieces.  A feed-forward chunk = 32 slabs of [16 rows][16 floats]; wave w issues slabs 4w .. 4w+3
+    // (0-15 = W1, 16-31 = W2); lane -> (row = lane / 4, physical chunk = lane % 4), the source chunk is XOR-swizzled.
+    // A projection chunk = 32 slabs too: Wo rows [32 g, 32 g + 16) in the first half of the stage, rows [32 g + 16,
+    // 32 g + 32) in the second half, both in the W1 slab format -- every chunk of the kernel costs the same 4 pieces
+    // per wave and one counted s_waitcnt serves all of it.
+    // Addressing: all four pieces of a wave lie on one side (waves 0-3: W1 slabs 4w .. 4w+3, waves 4-7: W2 slabs), so a
+    // piece's source is a wave-uniform base (SGPRs) + ONE per-lane offset + scalar multiples of the piece / chunk index.
+    const int drow = lane >> 2;
+    const int dch = (lane & 3) ^ ffn_swz16(drow);
+    const bool w2side = wave >= 4;
+    const float* fbase = w2side ? p.W2 : p.W1;                         // wave-uniform
+    const int foff = w2side ? (16 * 4 * (wave - 4) + drow) * ff + 4 * dch   // W2[16 t + row][h0 + 4 ch ..], t = 4 (w - 4) + i
+                            : drow * 256 + 16 * 4 * wave + 4 * dch;         // W1[h0 + row][16 q + 4 ch ..],  q = 4 w + i
+    const int fpiece = w2side ? 16 * ff : 16;                          // + i * fpiece
+    const int fchunk = w2side ? 16 : 16 * 256;                         // + c * fchunk
+    // projection chunk g: Wo[32 g + 16 (pid / 16) + row][16 (pid % 16) + 4 ch ..], pid = 4 w + i
+    const int poff = PROJ ? (16 * (wave >> 2) + drow) * 256 + 16 * 4 * (wave & 3) + 4 * dch : 0;
+    // piece i of chunk g of the current tile (projection chunks first, then the feed-forward chunks); g >= G = the
+    // first chunks of the NEXT tile this workgroup will run -- the same weights, so the ring simply runs on (after
+    // the last tile they land in stages nobody reads again).  sb = (chunks consumed before this tile) % FFN_NST.
+    int sb = 0;
+    auto stream_piece = [&](int g, int i) {
+        float* dstp = smem + ((sb + g) % FFN_NST) * FFN_STAGE + (wave * FFN_NPIECE + i) * 256;
+        const int gg = g < G ? g : g - G;
+        // wave-uniform pointer + zero-extended 32-bit lane offset: the saddr + voffset form of global_load_lds (one
+        // address VGPR for all pieces instead of a hoisted 64-bit VGPR pair per piece)
+        if (PROJ && gg < NP) {
+            const char* ub = reinterpret_cast<const char*>(p.Wo + ((size_t)gg * (32 * 256) + 16 * i));
+            FFN_GLDS16(ub + (unsigned)(poff * 4), dstp);
+        } else {
+            const char* ub = reinterpret_cast<const char*>(fbase + ((size_t)(gg - NP) * fchunk + (size_t)i * fpiece));
+            FFN_GLDS16(ub + (unsigned)(foff * 4), dstp);
+        }
+    };
+
+    const int rd = li * 16 + ((lg ^ ffn_swz16(li)) << 2);          // this lane's 16-B chunk inside a slab
+#define FFN_RD(stg, off) (*reinterpret_cast<const f32x4f*>((stg) + (off) + rd))
+#define FFN_STAGE_OF(g) (smem + ((sb + (g)) % FFN_NST) * FFN_STAGE)
+#define FFN_SB() __builtin_amdgcn_sched_barrier(0)
+    // a counted wait + barrier ends every chunk: the next chunk has landed (all but the 4 pieces issued last, which
+    // belong to the chunk after it), and every wave is done reading the stage that the next pieces will overwrite
+#define FFN_END_CHUNK()                                                           \
+    {                                                                             \
+        FFN_SB();                                                                 \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FFN_NPIECE) : "memory");         \
+        __builtin_amdgcn_s_barrier();                                             \
+        FFN_SB();                                                                 \
+    }
+    // MFMA issue order is pinned (a sched_barrier after every MFMA): hipcc otherwise regroups the MFMAs of a unit by
+    // accumulator, and back-to-back MFMAs on one accumulator wait out the 40-cycle dependent latency of the 32-cycle
+    // v_mfma_f32_16x16x4_f32 (measured: 139 -> 131 TFLOP/s).  In every sequence below an accumulator is reused at the
+    // earliest two MFMAs (64 cycles) later.
+#define FFN_MFMA(acc, a, b) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); FFN_SB(); }
+    // 8 MFMAs of a weight-slab pair against a register tile: four independent partial chains acc[0..3]
+#define FFN_MM_A(acc, w0, w1, B, q)                                                   \
+    {                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) FFN_MFMA(acc[r], w0[r], B[q][r])         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) FFN_MFMA(acc[r], w1[r], B[(q) + 1][r])   \
+    }
+    // 8 MFMAs of GEMM2: two output tiles, alternating accumulators
+#define FFN_MM_Y(w0, w1, hh, t)                                                       \
+    {                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+            FFN_MFMA(y[t], w0[r], hh[r])                                              \
+            FFN_MFMA(y[(t) + 1], w1[r], hh[r])                                        \
+        }                                                                             \
+    }
+    // 16 MFMAs: GEMM1 slab pair and GEMM2 tile pair interleaved (accumulator reuse distance 4)
+#define FFN_MM_AY(acc, w0, w1, B, q, v0, v1, hh, t)                                   \
+    {                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+            FFN_MFMA(acc[r], w0[r], B[q][r])                                          \
+            FFN_MFMA(y[(t) + (r & 1)], ((r & 1) ? v1 : v0)[r >> 1], hh[r >> 1])       \
+        }                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+            FFN_MFMA(acc[r], w1[r], B[(q) + 1][r])                                    \
+            FFN_MFMA(y[(t) + (r & 1)], ((r & 1) ? v1 : v0)[2 + (r >> 1)], hh[2 + (r >> 1)]) \
+        }                                                                             \
+    }
+
+#pragma unroll
+    for (int i = 0; i < FFN_NPIECE; ++i) stream_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < FFN_NPIECE; ++i) stream_piece(1 < G ? 1 : 0, i);
+
+    // Schedule.  Every chunk is walked as 8 units of 16 MFMAs (two slabs of each half of the stage).  The ds_read_b128
+    // of unit u+1 are issued right ahead of the MFMAs of unit u and consumed (the empty asm at the top of unit u+1 is
+    // where hipcc puts its lgkmcnt wait -- BEFORE the next reads are issued, so it never covers a read that was only
+    // just issued) after them: LDS latency hides under 512 matrix-pipe cycles.  Loop bodies are straight-line code: the
+    // ring is refilled unconditionally (the last iterations re-stream the final chunk into stages nobody reads again).
+    f32x4f wa, wb, na, nb;      // W1-format fragments (current / next unit)
+    f32x4f va, vb, nva, nvb;    // second-half fragments
+
+    // Persistent workgroup: one per CU, walking tiles blockIdx.x, + gridDim.x, ...  A tile's fixed costs -- its
+    // input rows (16 KiB per wave, 64-B row segments per load), the output stores, the dispatch of a fresh workgroup --
+    // are not covered by another workgroup at this occupancy (measured 18 us per 128-row tile against 3.7 us per
+    // chunk = 7 % at ff = 1024); here the next tile's rows are requested while the previous tile's stores drain and
+    // the weight ring never restarts.
+    // register tiles: v[q][r] = row[token li][16 q + 4 lg + r], q = 0 .. 15.  xr = block input: B operand of GEMM1 and
+    // the residual of the block (PROJ: starts as the residual of the projection, becomes the block input); ar (PROJ) =
+    // attention rows, B operand of the projection.  The NEXT tile's rows are requested from the epilogue, ahead of
+    // this tile's stores (vmcnt retires in order: loads queued behind stores would wait for the stores' acks).
+    f32x4f xr[16];
+    f32x4f ar[PROJ ? 16 : 1];
+    auto load_tile = [&](int tile) {
+        const int row = tile * FFN_ROWS + wave * 16 + li;
+        const size_t ld_row = (size_t)(row < M ? row : M - 1);         // rows past M feed unstored outputs
+        if (PROJ) {
+            const float* ap = p.A + ld_row * p.lda + 4 * lg;
+            const float* rp = p.R + ld_row * p.ldr + 4 * lg;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                ar[q] = *reinterpret_cast<const f32x4f*>(ap + 16 * q);
+                xr[q] = *reinterpret_cast<const f32x4f*>(rp + 16 * q);
+            }
+        } else {
+            const float* xp = p.X + ld_row * p.ldx + 4 * lg;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const f32x4f*>(xp + 16 * q);
+        }
+    };
+    load_tile(blockIdx.x);
+    bool first = true;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int my_row = tile * FFN_ROWS + wave * 16 + li;
+    if (first) {        // chunk 0 and the b1 image are in LDS (later tiles: the previous tile's last barrier covers chunk 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FFN_NPIECE) : "memory");
+        __syncthreads();
+        first = false;
+    }
+
+    if (PROJ) {
+        // ---- attention output projection + residual + LayerNorm: pair g computes channels [32 g, 32 g + 32) of
+        // A Wo^T into xr[2 g], xr[2 g + 1] (which start as residual + bias); fully unrolled: xr[] is indexed statically
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const float* st = FFN_STAGE_OF(g);
+            f32x4f ha[2], hb[2];        // two partial chains per tile: with both tiles interleaved, four MFMAs apart
+            ha[0] = xr[2 * g]; hb[0] = xr[2 * g + 1];
+            ha[1] = f32x4f{0.f, 0.f, 0.f, 0.f}; hb[1] = ha[1];
+            wa = FFN_RD(st, 0); wb = FFN_RD(st, 256); va = FFN_RD(st, 4096); vb = FFN_RD(st, 4096 + 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                FFN_SB();
+                asm volatile("" : "+v"(wa), "+v"(wb), "+v"(va), "+v"(vb));
+                FFN_SB();
+                if (u < 7) {
+                    na = FFN_RD(st, (2 * u + 2) * 256); nb = FFN_RD(st, (2 * u + 3) * 256);
+                    nva = FFN_RD(st, 4096 + (2 * u + 2) * 256); nvb = FFN_RD(st, 4096 + (2 * u + 3) * 256);
+                }
+                FFN_SB();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    FFN_MFMA(ha[r & 1], wa[r], ar[2 * u][r])
+                    FFN_MFMA(hb[r & 1], va[r], ar[2 * u][r])
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    FFN_MFMA(ha[r & 1], wb[r], ar[2 * u + 1][r])
+                    FFN_MFMA(hb[r & 1], vb[r], ar[2 * u + 1][r])
+                }
+                if (u & 1) stream_piece(g + 2, u >> 1);            // the next-but-one chunk's pieces ride behind MFMAs
+                if (u < 7) { wa = na; wb = nb; va = nva; vb = nvb; }
+            }
+            xr[2 * g] = ha[0] + ha[1];
+            xr[2 * g + 1] = hb[0] + hb[1];
+            FFN_END_CHUNK()
+        }
+        FFN_SB();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xr[t] += *reinterpret_cast<const f32x4f*>(prm + 768 + 16 * t + 4 * lg);       // + bo
+        float rstd;
+        ffn_layernorm_regs(xr, rstd);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4f g4 = *reinterpret_cast<const f32x4f*>(prm + 1024 + 16 * t + 4 * lg);
+            const f32x4f b4 = *reinterpret_cast<const f32x4f*>(prm + 1280 + 16 * t + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[t][r] = xr[t][r] * rstd * g4[r] + b4[r];
+        }
+        FFN_SB();
+    }
+
+    // ---- feed-forward block, software-pipelined across chunks: iteration i multiplies GEMM1 of chunk i (W1 half of
+    // stage i) and GEMM2 of chunk i-1 (W2 half of stage i-1, hidden tile h of the previous iteration) in the same
+    // units, so the GEMM1 -> bias/ReLU -> GEMM2 dependency spans a whole iteration instead of stalling every chunk.
+    f32x4f y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] = f32x4f{0.f, 0.f, 0.f, 0.f};
+    f32x4f h, hp[4];
+    {   // iteration 0: GEMM1 of chunk 0 alone
+        const float* st = FFN_STAGE_OF(NP);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hp[r] = f32x4f{0.f, 0.f, 0.f, 0.f};
+        wa = FFN_RD(st, 0); wb = FFN_RD(st, 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            FFN_SB();
+            asm volatile("" : "+v"(wa), "+v"(wb));
+            FFN_SB();
+            if (u < 7) { na = FFN_RD(st, (2 * u + 2) * 256); nb = FFN_RD(st, (2 * u + 3) * 256); }
+            else { va = FFN_RD(st, 4096); vb = FFN_RD(st, 4096 + 256); }       // unit 0 of GEMM2(0), next iteration
+            FFN_SB();
+            FFN_MM_A(hp, wa, wb, xr, 2 * u)
+            if (u & 1) stream_piece(NP + 2, u >> 1);
+            if (u < 7) { wa = na; wb = nb; }
+        }
+        FFN_SB();
+        h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + *reinterpret_cast<const f32x4f*>(b1s + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+        FFN_END_CHUNK()
+    }
+    for (int i = 1; i < nc; ++i) {
+        const float* s1 = FFN_STAGE_OF(NP + i);             // W1 half: chunk i
+        const float* s2 = FFN_STAGE_OF(NP + i - 1);         // W2 half: chunk i - 1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hp[r] = f32x4f{0.f, 0.f, 0.f, 0.f};
+        wa = FFN_RD(s1, 0); wb = FFN_RD(s1, 256);           // only now visible (the barrier above); GEMM2's first
+#pragma unroll                                              // fragments were requested before it
+        for (int u = 0; u < 8; ++u) {
+            FFN_SB();
+            if (u == 0) {
+                // the first unit runs GEMM2 ahead of GEMM1: its fragments are already here, GEMM1's are in flight
+                asm volatile("" : "+v"(va), "+v"(vb));
+                FFN_SB();
+                nva = FFN_RD(s2, 4096 + 2 * 256); nvb = FFN_RD(s2, 4096 + 3 * 256);
+                FFN_SB();
+                FFN_MM_Y(va, vb, h, 0)
+                FFN_SB();
+                asm volatile("" : "+v"(wa), "+v"(wb));
+                FFN_SB();
+                na = FFN_RD(s1, 2 * 256); nb = FFN_RD(s1, 3 * 256);
+                FFN_SB();
+                FFN_MM_A(hp, wa, wb, xr, 0)
+            } else {
+                asm volatile("" : "+v"(wa), "+v"(wb), "+v"(va), "+v"(vb));
+                FFN_SB();
+                if (u < 7) {
+                    na = FFN_RD(s1, (2 * u + 2) * 256); nb = FFN_RD(s1, (2 * u + 3) * 256);
+                    nva = FFN_RD(s2, 4096 + (2 * u + 2) * 256); nvb = FFN_RD(s2, 4096 + (2 * u + 3) * 256);
+                } else {    // GEMM2's first fragments of the next iteration: W2 half of THIS chunk's stage
+                    nva = FFN_RD(s1, 4096); nvb = FFN_RD(s1, 4096 + 256);
+                }
+                FFN_SB();
+                FFN_MM_AY(hp, wa, wb, xr, 2 * u, va, vb, h, 2 * u)
+            }
+            if (u & 1) stream_piece(NP + i + 2, u >> 1);
+            if (u < 7) { wa = na; wb = nb; }
+            va = nva; vb = nvb;
+        }
+        FFN_SB();
+        // hidden tile of chunk i for the next iteration (the last GEMM1 MFMAs finished under the last GEMM2 ones)
+        h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + *reinterpret_cast<const f32x4f*>(b1s + 16 * i + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+        FFN_END_CHUNK()
+    }
+    {   // last iteration: GEMM2 of chunk nc - 1 alone
+        const float* st = FFN_STAGE_OF(NP + nc - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            FFN_SB();
+            asm volatile("" : "+v"(va), "+v"(vb));
+            FFN_SB();
+            if (u < 7) { nva = FFN_RD(st, 4096 + (2 * u + 2) * 256); nvb = FFN_RD(st, 4096 + (2 * u + 3) * 256); }
+            FFN_SB();
+            FFN_MM_Y(va, vb, h, 2 * u)
+            if (u < 7) { va = nva; vb = nvb; }
+        }
+    }
+    // ---- epilogue: + b2 + residual, LayerNorm over the token's 256 channels (4 lanes x 64 registers), store
+    FFN_SB();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] = y[t] + *reinterpret_cast<const f32x4f*>(prm + 16 * t + 4 * lg) + xr[t];
+    FFN_SB();
+    // in flight under the LayerNorm + stores (unconditional -- after the last tile a valid tile is simply re-read --
+    // so that the register tiles have ONE definition per iteration)
+    load_tile(tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile);
+    FFN_SB();
+    float rstd;
+    ffn_layernorm_regs(y, rstd);
     if (my_row < M) {
         float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const f32x4f g = *reinterpret_cast<const f32x4f*>(p.ln_g + 16 * t + 4 * lg);
-            const f32x4f be = *reinterpret_cast<const f32x4f*>(p.ln_b + 16 * t + 4 * lg);
+            const f32x4f g = *reinterpret_cast<const f32x4f*>(prm + 256 + 16 * t + 4 * lg);
+            const f32x4f be = *reinterpret_cast<const f32x4f*>(prm + 512 + 16 * t + 4 * lg);
             f32x4f o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * g[r] + be[r];
             *reinterpret_cast<f32x4f*>(op + 16 * t) = o;
         }
     }
+    sb = (sb + G) % FFN_NST;
+    }   // tile loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may outlive the workgroup's LDS
 }
 
+#undef FFN_MM_A
+#undef FFN_MM_Y
+#undef FFN_MM_AY
+#undef FFN_MFMA
+#undef FFN_END_CHUNK
+#undef FFN_SB
+#undef FFN_STAGE_OF
+#undef FFN_RD
+
 bool ffn_fused_supported(int ff) { return ff >= 32 && ff % 16 == 0 && ff <= 4096; }
+
+template <bool PROJ>
+static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256) * sizeof(float);
+    // once per process: the opt-in to > 64 KiB of LDS (a property of the code object) and the CU count that sizes
+    // the persistent grid (one workgroup per CU: 132 KiB of LDS, 512 threads at <= 256 VGPRs)
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    static int n_cu = 0;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (FFN_NST * FFN_STAGE + 4096 + 6 * 256) * (int)sizeof(float));
+        int dev = 0;
+        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
+        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    CONE_CHECK_HIP(attr_rc);
+    const int tiles = (a.M + FFN_ROWS - 1) / FFN_ROWS;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    // FLOPs of a record: 4 * M * ff * 256 for the block, + 2 * M * 256 * 256 with the projection
+    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff, 256, a.M_dev, s);
+    hipLaunchKernelGGL(ffn_fused_kernel<PROJ>, dim3((unsigned)grid), dim3(512), lds, s, a);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
                      const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
@@ -203,19 +461,25 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
     CONE_REQUIRE(X && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused FFN: null argument");
     CONE_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "fused FFN: row strides must be multiples of 4");
     if (M <= 0) return 0;
-    const size_t lds = (size_t)(FFN_NST * FFN_STAGE + ff) * sizeof(float);
-    static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (FFN_NST * FFN_STAGE + 4096) * (int)sizeof(float));
-    });
-    CONE_CHECK_HIP(attr_rc);
-    FfnArgs a{X, ldx, W1, b1, W2, b2, ln_g, ln_b, OUT, ldo, M, M_dev, ff};
-    ProfScope ps(PK_FFN_FUSED, M, ff, 256, M_dev, s);
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS)), dim3(512), lds, s, a);
-    CONE_LAUNCH_CHECK();
-    return 0;
+    FfnArgs a{};
+    a.X = X; a.ldx = ldx; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    return launch_ffn_t<false>(a, s);
+}
+
+int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
+                          const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
+                          const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
+                          const int* M_dev, int ff, hipStream_t s) {
+    CONE_REQUIRE(ffn_fused_supported(ff), "fused layer tail: dim_feedforward=%d unsupported", ff);
+    CONE_REQUIRE(A && Wo && bo && R && pg && pb && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused layer tail: null argument");
+    CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "fused layer tail: row strides must be multiples of 4");
+    if (M <= 0) return 0;
+    FfnArgs a{};
+    a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    return launch_ffn_t<true>(a, s);
 }
 
 }  // namespace cone

@@ -260,7 +260,7 @@ int cone_eval_window_recall(const int32_t* win_idx, int nq, int k, const double*
  * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
  * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
  * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, source mode); kind 4 = frame-score
- * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq).  Returns the record count.  Not thread-safe. */
+ * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq); kind 8 = fused feed-forward block (M rows, ff, 256): 4*M*ff*256 FLOPs; kind 9 = the same with the output projection: + 2*M*256*256.  Returns the record count.  Not thread-safe. */
 int cone_prof_enable(int on);
 int64_t cone_prof_collect(double* out, int64_t max_rec);
 
@@ -275,6 +275,10 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  *   tables of cone_layer0; 0 = from an x + pos matrix written by the previous layer's GEMM epilogue.
  * "dec0_const" (default 1): the first decoder layer's self-attention block and cross-attention queries (tgt = 0:
  *   the same for every window) are computed for one window and replicated; 0 = for all windows.  Bit-identical.
+ * "ffn_fused" (default 2): 1 = linear1 + ReLU + linear2 + residual + LayerNorm of every transformer layer as ONE kernel
+ *   that keeps the (M, dim_feedforward) hidden rows on chip (ffn.hip); 2 = the attention output projection + residual +
+ *   LayerNorm ahead of it in that kernel too (everything of a layer behind its attention: one launch, the layer's
+ *   intermediate rows never leave the CU); 0 = GEMMs through (M, 256) / (M, ff) buffers.
  * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
  *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
  *   exact-fp32 fma chains per output element that walk k in different orders. */
@@ -285,6 +289,14 @@ int cone_model_set_option(cone_model* m, const char* name, int value);
 int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,
                    const float* R, const float* ln_g, const float* ln_b, float* C, float* C2,
                    const float* ADD, int M, int N, int K, int flags, void* stream);
+/* OUT = LayerNorm(X + W2 relu(W1 X + b1) + b2), the fused feed-forward block: X, OUT (M, 256), W1 (ff, 256), W2 (256, ff). */
+int cone_test_ffn(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* stream);
+/* The same with the block input computed in the kernel: X = LayerNorm_p(R + A Wo^T + bo) -- the attention output projection,
+ * its residual and norm (A, R (M, 256); Wo (256, 256)).  OUT may be R (in place). */
+int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const float* R, const float* pg, const float* pb,
+                       const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_g,
+                       const float* ln_b, float* OUT, int M, int ff, void* stream);
 int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                         int dim, void* stream);
 

@@ -101,6 +101,50 @@ def test_gemm_matches_torch(M, N, K, flags, a2):
         assert torch.equal(C2, C + ADD)
 
 
+@pytest.mark.parametrize("M,ff", [(1, 1024), (16, 32), (127, 1024), (129, 1024), (1000, 2048), (4099, 1024), (300, 48)])
+def test_fused_ffn_matches_float64(M, ff):
+    """ffn.hip: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one kernel (hidden rows kept on chip, transposed MFMA
+    orientation, k index permuted) against a float64 evaluation; ragged last tile, 1-row and multi-tile cases,
+    hidden sizes of 2 / 3 / 64 / 128 chunks."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(M * 31 + ff)
+    X = torch.randn(M, 256, generator=g) * 1.5
+    W1 = torch.randn(ff, 256, generator=g) / 16
+    b1 = torch.randn(ff, generator=g) * 0.2
+    W2 = torch.randn(256, ff, generator=g) / ff ** 0.5
+    b2 = torch.randn(256, generator=g) * 0.2
+    lg, lb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    h = (X.double() @ W1.double().t() + b1.double()).clamp(min=0)
+    ref = torch.nn.functional.layer_norm(X.double() + h @ W2.double().t() + b2.double(), (256,), lg.double(), lb.double(), 1e-5)
+    d = lambda t: t.to(dev).contiguous()
+    Xd, W1d, b1d, W2d, b2d, lgd, lbd = map(d, (X, W1, b1, W2, b2, lg, lb))
+    out = torch.full((M + 3, 256), float("nan"), device=dev)            # rows past M must stay untouched
+    lib = _lib.load()
+    _lib.check(lib.cone_test_ffn(_lib.ptr(Xd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d), _lib.ptr(lgd),
+                                 _lib.ptr(lbd), _lib.ptr(out), M, ff, _lib.stream()))
+    torch.cuda.synchronize()
+    assert maxdiff(out[:M], ref) < 2e-5
+    assert bool(torch.isnan(out[M:]).all())
+    # with the attention output projection + residual + LayerNorm computed in the kernel as well, in place over R
+    A = torch.randn(M, 256, generator=g)
+    Wo = torch.randn(256, 256, generator=g) / 16
+    bo = torch.randn(256, generator=g) * 0.2
+    pg, pb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.3
+    x1 = torch.nn.functional.layer_norm(X.double() + A.double() @ Wo.double().t() + bo.double(), (256,), pg.double(), pb.double(), 1e-5)
+    h = (x1 @ W1.double().t() + b1.double()).clamp(min=0)
+    ref = torch.nn.functional.layer_norm(x1 + h @ W2.double().t() + b2.double(), (256,), lg.double(), lb.double(), 1e-5)
+    Ad, Wod, bod, pgd, pbd = map(d, (A, Wo, bo, pg, pb))
+    R = torch.full((M + 3, 256), float("nan"), device=dev)
+    R[:M] = Xd
+    _lib.check(lib.cone_test_proj_ffn(_lib.ptr(Ad), _lib.ptr(Wod), _lib.ptr(bod), _lib.ptr(R), _lib.ptr(pgd), _lib.ptr(pbd),
+                                      _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d), _lib.ptr(lgd),
+                                      _lib.ptr(lbd), _lib.ptr(R), M, ff, _lib.stream()))
+    torch.cuda.synchronize()
+    assert maxdiff(R[:M], ref) < 3e-5
+    assert bool(torch.isnan(R[M:]).all())
+
+
 @pytest.mark.parametrize("n,dim", [(5, 256), (1000, 768), (3, 512), (77, 1024)])
 def test_layernorm_matches_torch(n, dim):
     from cone_amd import _lib
@@ -246,11 +290,18 @@ def test_position_tables_equal_materialised_pos_path(preset):
         for tab in (1, 0):
             model.set_option("pos_tables", tab)
             outs.append(inf.run_windows(model, store, opt, wt))
+        model.set_option("pos_tables", 1)
+        for lvl in (0, 1):                       # the table path with GEMMs / with only the feed-forward block fused
+            model.set_option("ffn_fused", lvl)
+            outs.append(inf.run_windows(model, store, opt, wt))
     finally:
         model.set_option("pos_tables", 1)
+        model.set_option("ffn_fused", 2)
     assert int((wt["vid_len"] < opt.max_v_l).sum()) > 0          # ragged windows are in the batch
     for k in ("pred_logits", "pred_spans", "saliency_scores"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < 5e-5, k
+        assert maxdiff(outs[0][k], outs[2][k].cpu()) < 5e-5, ("ffn_fused 0", k)
+        assert maxdiff(outs[0][k], outs[3][k].cpu()) < 5e-5, ("ffn_fused 1", k)
     safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
     d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
     assert float(d[safe].max()) < 5e-5
@@ -758,6 +809,15 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
         model.set_option("dec0_const", 1)
     for k in ("pred_logits", "pred_spans", "hs"):
         assert torch.equal(o[k].cpu(), outs[0][k]), k
+    # the fused feed-forward kernel against linear1 / linear2 as two GEMMs through an (M, ff) buffer
+    try:
+        for lvl in (0, 1):
+            model.set_option("ffn_fused", lvl)
+            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+            for k in ("pred_logits", "pred_spans", "hs"):
+                assert maxdiff(o[k], outs[0][k]) < 5e-5, ("ffn_fused", lvl, k)
+    finally:
+        model.set_option("ffn_fused", 2)
     # every GEMM tile family computes the same layers (exact-fp32 fma chains in different k orders)
     try:
         for fam in (1, 2):

@@ -21,7 +21,10 @@ from collections import defaultdict
 def load(path):
     per = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
-        per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":          # one row per dispatch: its wall time rides along
+            per[k]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return per
 
 
@@ -40,14 +43,18 @@ for k in sorted(f, key=lambda k: -sum(f[k]["FETCH_SIZE"])):
     rd = 2.0 * 1024 * sum(fv) / len(fv)
     wr = 1024 * sum(wv) / len(wv)
     util = 100.0 * (busy / 1024) / (act / 8) if act else 0.0
-    rows.append((k, len(fv), rd, wr, rd + wr, util))
+    dur = sum(mm.get("_dur_ns", [0.0]))
+    ghz = (act / 8) / dur if dur else 0.0                   # effective shader clock under the profiler (guide: DVFS)
+    avg_us = dur / max(1, len(mm.get("_dur_ns", []))) / 1e3
+    rows.append((k, len(fv), rd, wr, rd + wr, util, avg_us, ghz))
     traffic[k] = {"launches": len(fv), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                  "hbm_bytes_per_launch": rd + wr, "mfma_busy_pct": round(util, 1)}
+                  "hbm_bytes_per_launch": rd + wr, "mfma_busy_pct": round(util, 1),
+                  "avg_us_profiled": round(avg_us, 1), "effective_clock_ghz": round(ghz, 3)}
 with open(dst + "_counters.csv", "w") as o:
     o.write("kernel,launches,hbm_read_bytes_per_launch(2xFETCH_SIZE),hbm_write_bytes_per_launch,hbm_bytes_per_launch,"
-            "mfma_busy_pct\n")
+            "mfma_busy_pct,avg_us_profiled,effective_clock_ghz\n")
     for r in rows:
-        o.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.1f}\n")
+        o.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.1f},{r[6]:.1f},{r[7]:.3f}\n")
 with open(dst + "_traffic.json", "w") as o:
     json.dump(traffic, o, indent=1, sort_keys=True)
 print(open(dst + "_counters.csv").read())
