@@ -110,6 +110,11 @@ _SIGNATURES = {
                                     C.c_void_p]),
     "cone_matcher_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_criterion_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "cone_adapter_nce": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "cone_prof_enable": (C.c_int, [C.c_int]),
     "cone_prof_collect": (C.c_int64, [C.c_void_p, C.c_int64]),
     "cone_eval_recall": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,

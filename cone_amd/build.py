@@ -15,11 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcone_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "rowops.hip", "attention.hip", "window_ops.hip", "prefilter.hip",
-           "postproc.hip", "prof.hip", "dec_cross.hip", "metrics.hip", "ffn.hip"]
+           "postproc.hip", "prof.hip", "dec_cross.hip", "metrics.hip", "ffn.hip", "criterion.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # Files whose scalar arithmetic must round operation by operation like the reference's torch / Python
 # code (HIP's __fmul_rn & co. are plain operators and would otherwise be contracted into fma).
-NO_CONTRACT = {"window_ops.hip", "postproc.hip", "metrics.hip"}
+NO_CONTRACT = {"window_ops.hip", "postproc.hip", "metrics.hip", "criterion.hip"}
 
 
 def _deps_mtime():

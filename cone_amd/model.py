@@ -6,8 +6,8 @@ meaning and output dict as ``cone/model.py:16-152`` -- but ``forward`` /
 torch stream instead of running torch.nn modules.  Tensors are torch CUDA(HIP) tensors; torch is
 only the allocator / stream owner here.
 
-Not mirrored (out of scope): ``SetCriterion`` and the training-only branches
-(``is_groundtruth`` matching, dropout).  ``build_model`` returns ``(model, None)``.
+Not mirrored (out of scope): the training-only branches (``is_groundtruth`` matching, dropout,
+autograd).  ``build_model`` returns ``(model, criterion)`` with the forward-value criterion of cone_amd.criterion.
 """
 from __future__ import annotations
 
@@ -326,6 +326,7 @@ class CONE:
 
 
 def build_model(args):
-    """``build_model(args) -> (model, criterion)`` of cone/model.py:468-521; the criterion is
-    training-only and not part of this package, so ``None`` is returned in its place."""
-    return CONE(args), None
+    """``build_model(args) -> (model, criterion)`` of cone/model.py:468-521.  The criterion is the forward-value mirror
+    of ``SetCriterion`` (cone_amd.criterion: losses as numbers for evaluation-side meters, no autograd)."""
+    from .criterion import build_criterion
+    return CONE(args), build_criterion(args)

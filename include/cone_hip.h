@@ -238,6 +238,25 @@ int cone_matcher_cost(const float* logits, const float* spans, const float* tgt,
                       float cost_span, float cost_giou, float cost_class, float* cost, int32_t* best,
                       void* stream);
 
+/* SetCriterion.forward (cone/model.py:213-425) with its HungarianMatcher (cone/matcher.py:37-106): forward values of
+ * one decoder layer's losses -- the matcher's exact assignment (<= 8 slots and <= 8 target spans per window, the
+ * reference calls scipy's linear_sum_assignment), then loss_span = mean L1 of the matched (center, width) pairs,
+ * loss_giou = mean (1 - GIoU), loss_label = mean over all slots (the negative window's too when neg_logits != NULL) of
+ * the class-weighted cross-entropy (foreground = class 0 for matched slots, weight 1; background weight eos_coef),
+ * class_error = 100 - top-1 accuracy of the matched slots, loss_saliency = hinge over the (pos, neg) clip pairs
+ * (+ the negative window's maximum when neg_saliency != NULL), 0 when saliency == NULL.
+ * logits, spans, neg_logits (B, Nq, 2); tgt (sum T, 2) (center, width), tgt_off (B + 1); tgt == NULL: no targets --
+ * every slot is background and only loss_label is meaningful (:385-388).  saliency (B, L), pos_idx / neg_idx (B, P).
+ * Outputs: assign (B, Nq) int32 (target index inside the window, -1 = unmatched; may be NULL), part (B, 8) scratch,
+ * losses (5) = loss_span, loss_giou, loss_label, class_error, loss_saliency. */
+int cone_criterion_forward(const float* logits, const float* spans, const float* tgt, const int32_t* tgt_off,
+                           const float* neg_logits, const float* saliency, int L, const int32_t* pos_idx,
+                           const int32_t* neg_idx, int P, const float* neg_saliency, int L2, int B, int Nq,
+                           float cost_span, float cost_giou, float cost_class, float eos_coef, float saliency_margin,
+                           int32_t* assign, float* part, float* losses, void* stream);
+/* loss_adapter (cone/model.py:249-264): (CE(sim / T, diag) + CE(sim^T / T, diag)) / 2 for sim (n, n); loss (1). */
+int cone_adapter_nce(const float* sim, int n, float temperature, float* loss, void* stream);
+
 /* -------------------------------------------------------------------- metrics on the device
  * Recall@K / IoU counts from the kept rows (layout of cone_fuse_nms: rows (nq, max_after, 5) fp64 [st, ed, ...],
  * n (nq) valid rows) and one target span per query gt (nq, 2) fp64 seconds -- device pointers.  thresholds /

@@ -605,3 +605,69 @@ def windows_selection(query_id2windowidx, ground_truth, topK, clip_length, max_v
             out[i] += float(any(inside[:k]))
     out /= len(query_id2windowidx)
     return out
+
+
+# ------------------------------------------------------------------ criterion forward
+def hungarian_indices(opt_costs, pred_logits, pred_spans, tgt_spans_list):
+    """HungarianMatcher.forward (cone/matcher.py:37-106): cost matrix over the whole batch, then an exact assignment per
+    window on its own targets' columns (scipy's linear_sum_assignment there; here brute force over the <= 8! x C(8, k)
+    candidate assignments, which is exact too).  Returns [(slot indices ascending, target indices)] per window."""
+    from itertools import permutations
+    B, Nq = pred_spans.shape[:2]
+    out = []
+    for b in range(B):
+        tg = tgt_spans_list[b]
+        C = matcher_cost(opt_costs, pred_logits[b:b + 1], pred_spans[b:b + 1], tg).view(Nq, -1)
+        T = C.shape[1]
+        k = min(Nq, T)
+        best, arg = None, None
+        if Nq <= T:
+            for perm in permutations(range(T), k):
+                c = sum(float(C[n, perm[n]]) for n in range(k))
+                if best is None or c < best:
+                    best, arg = c, [(n, perm[n]) for n in range(k)]
+        else:
+            for perm in permutations(range(Nq), k):
+                c = sum(float(C[perm[j], j]) for j in range(k))
+                if best is None or c < best:
+                    best, arg = c, sorted((perm[j], j) for j in range(k))
+        out.append(([p[0] for p in arg], [p[1] for p in arg]))
+    return out
+
+
+def criterion_layer(hyper, pred_logits, pred_spans, tgt_spans_list, neg_logits=None, saliency=None, pos_idx=None,
+                    neg_idx=None, neg_saliency=None):
+    """One decoder layer's losses of SetCriterion (cone/model.py:266-363): spans (L1 + GIoU on matched pairs), labels
+    (class-weighted CE over all slots, the negative window's appended), class_error, saliency hinge."""
+    costs = (hyper["set_cost_span"], hyper["set_cost_giou"], hyper["set_cost_class"])
+    idx = hungarian_indices(costs, pred_logits, pred_spans, tgt_spans_list)
+    src = torch.cat([pred_spans[b, i] for b, (i, _) in enumerate(idx)])
+    tgt = torch.cat([tgt_spans_list[b][j] for b, (_, j) in enumerate(idx)])
+    losses = {"loss_span": F.l1_loss(src, tgt, reduction="none").mean(),
+              "loss_giou": (1 - torch.diag(generalized_temporal_iou(span_cxw_to_xx(src), span_cxw_to_xx(tgt)))).mean()}
+    logits = pred_logits if neg_logits is None else torch.cat((pred_logits, neg_logits), dim=1)
+    target = torch.full(logits.shape[:2], 1, dtype=torch.int64)
+    for b, (i, _) in enumerate(idx):
+        target[b, i] = 0
+    w = torch.tensor([1.0, hyper["eos_coef"]])
+    losses["loss_label"] = F.cross_entropy(logits.transpose(1, 2), target, w, reduction="none").mean()
+    matched = torch.cat([pred_logits[b, i] for b, (i, _) in enumerate(idx)])
+    losses["class_error"] = 100 - 100.0 * (matched.argmax(-1) == 0).float().mean()
+    if saliency is not None:
+        ar = torch.arange(saliency.shape[0])
+        P = pos_idx.shape[1]
+        pos = torch.stack([saliency[ar, pos_idx[:, c]] for c in range(P)], 1)
+        neg = torch.stack([saliency[ar, neg_idx[:, c]] for c in range(P)], 1)
+        ls = torch.clamp(hyper["saliency_margin"] + neg - pos, min=0).sum() / (len(pos) * P) * 2
+        if neg_saliency is not None:
+            nm = neg_saliency.max(1).values[:, None]
+            ls = ls + torch.clamp(hyper["saliency_margin"] + nm - pos, min=0).sum() / (len(pos) * P) * 2
+        losses["loss_saliency"] = ls
+    return losses, idx
+
+
+def adapter_nce(sim, temperature):
+    """loss_adapter (cone/model.py:249-264)."""
+    lg = sim / temperature
+    d = torch.arange(len(lg))
+    return (F.cross_entropy(lg, d) + F.cross_entropy(lg.T, d)) / 2

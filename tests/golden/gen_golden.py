@@ -312,6 +312,55 @@ def gen_matcher(name, seed):
     print("wrote", name)
 
 
+def gen_criterion(name, seed):
+    """SetCriterion.forward (cone/model.py:213-425) + HungarianMatcher with 1-3 targets per window
+    (cone/matcher.py:37-106) on seeded random model outputs: every loss of the top layer and of the auxiliary
+    layer, with and without negative-window outputs; loss_adapter on a random similarity matrix."""
+    rng = np.random.default_rng(7000 + seed)
+    opt = ref_opt("ego4d")
+    _, criterion = build_model(opt)
+    criterion.eval()
+    B, Nq, L, P = 9, 5, 90, 2
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    mk_spans = lambda n: np.stack([rng.uniform(0.15, 0.85, n), rng.uniform(0.04, 0.5, n)], -1).astype(np.float32)
+    layers = []
+    for _ in range(2):
+        layers.append(dict(pred_logits=f32(rng.standard_normal((B, Nq, 2)) * 2), pred_spans=mk_spans((B, Nq)).reshape(B, Nq, 2)))
+    sal = f32(rng.standard_normal((B, L)))
+    n_tgt = [1, 2, 1, 3, 1, 1, 2, 1, 5]
+    tgt = [mk_spans(n) for n in n_tgt]
+    pos_idx = rng.integers(0, L, (B, P))
+    neg_idx = rng.integers(0, L, (B, P))
+    neg = dict(pred_logits=f32(rng.standard_normal((B, Nq, 2)) * 2), saliency_scores=f32(rng.standard_normal((B, L))))
+    t = torch.from_numpy
+    outputs = dict(pred_logits=t(layers[1]["pred_logits"]), pred_spans=t(layers[1]["pred_spans"]), saliency_scores=t(sal),
+                   aux_outputs=[dict(pred_logits=t(layers[0]["pred_logits"]), pred_spans=t(layers[0]["pred_spans"]))])
+    targets = dict(span_labels=[dict(spans=t(x)) for x in tgt], saliency_pos_labels=t(pos_idx), saliency_neg_labels=t(neg_idx))
+    neg_outputs = dict(pred_logits=t(neg["pred_logits"]), saliency_scores=t(neg["saliency_scores"]))
+    with torch.no_grad():
+        idx = criterion.matcher({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets)
+        idx_aux = criterion.matcher(outputs["aux_outputs"][0], targets)
+        with_neg = criterion(outputs, targets, neg_outputs)
+        without = criterion(outputs, targets, None)
+        no_targets = criterion(outputs, None)
+        sim = f32(rng.standard_normal((6, 6)))
+        adapter = criterion.loss_adapter(dict(logits_per_video=t(sim)))
+    tofl = lambda d: {k: float(v) for k, v in d.items()}
+    fx = dict(seed=seed, B=B, Nq=Nq, L=L, n_tgt=n_tgt,
+              layers=[{k: v.tolist() for k, v in l.items()} for l in layers], saliency=sal.tolist(),
+              tgt=[x.tolist() for x in tgt], pos_idx=pos_idx.tolist(), neg_idx=neg_idx.tolist(),
+              neg={k: v.tolist() for k, v in neg.items()}, sim=sim.tolist(),
+              hyper=dict(eos_coef=opt.eos_coef, temperature=opt.temperature, saliency_margin=opt.saliency_margin,
+                         set_cost_span=opt.set_cost_span, set_cost_giou=opt.set_cost_giou, set_cost_class=opt.set_cost_class),
+              weight_dict={k: float(v) for k, v in criterion.weight_dict.items()},
+              idx=[[i.tolist(), j.tolist()] for i, j in idx], idx_aux=[[i.tolist(), j.tolist()] for i, j in idx_aux],
+              losses_with_neg=tofl(with_neg), losses_without_neg=tofl(without), losses_no_targets=tofl(no_targets),
+              loss_adapter=tofl(adapter))
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(fx, f)
+    print("wrote", name, {k: round(v, 4) for k, v in fx["losses_with_neg"].items()})
+
+
 def gen_localizer(name, seed):
     """run_on_video CONELocalizator.predict_moment on two synthetic videos (ckpt loading bypassed)."""
     ed = types.ModuleType("easydict")
@@ -446,6 +495,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_metrics("metrics", 0)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "criterion":
+        gen_criterion("criterion", 0)
+        return
     gen_stage_b("stageB_ego4d", "ego4d", 0, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17])
     gen_stage_b("stageB_mad", "mad", 1, [125, 62, 3, 125], [25, 6, 11, 18])
     gen_stage_a("stageA_ego4d", "ego4d", 0, [901, 900, 44, 91])
@@ -455,6 +507,7 @@ def main():
     gen_e2e("e2e_mad", "mad", 1, 6, 2, (500, 800), topk_window=5)
     gen_stage_c("stageC", 0)
     gen_matcher("matcher", 0)
+    gen_criterion("criterion", 0)
     gen_localizer("localizer", 0)
     gen_metrics("metrics", 0)
 

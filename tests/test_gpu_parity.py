@@ -1271,3 +1271,49 @@ def test_config5_64_queries_one_mad_length_video():
         ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
         agree += ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4
     assert agree >= 14, agree
+
+
+def test_criterion_forward_matches_reference_golden(golden_dir):
+    """cone_amd.criterion.SetCriterion / HungarianMatcher (HIP: exact assignment by subset DP + every loss of
+    cone/model.py:266-363 per decoder layer) against the reference's own outputs; random cases against the oracle."""
+    from cone_amd.criterion import build_criterion
+    with open(os.path.join(golden_dir, "criterion.json")) as f:
+        fx = json.load(f)
+    dev = _gpu()
+    opt = make_opt("ego4d", **fx["hyper"])
+    crit = build_criterion(opt)
+    assert {k: float(v) for k, v in crit.weight_dict.items()} == fx["weight_dict"]
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    outputs = dict(pred_logits=t(fx["layers"][1]["pred_logits"]), pred_spans=t(fx["layers"][1]["pred_spans"]),
+                   saliency_scores=t(fx["saliency"]),
+                   aux_outputs=[dict(pred_logits=t(fx["layers"][0]["pred_logits"]), pred_spans=t(fx["layers"][0]["pred_spans"]))])
+    targets = dict(span_labels=[dict(spans=t(x)) for x in fx["tgt"]], saliency_pos_labels=torch.tensor(fx["pos_idx"]),
+                   saliency_neg_labels=torch.tensor(fx["neg_idx"]))
+    neg = dict(pred_logits=t(fx["neg"]["pred_logits"]), saliency_scores=t(fx["neg"]["saliency_scores"]))
+    idx = crit.matcher({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets)
+    assert [[i.tolist(), j.tolist()] for i, j in idx] == fx["idx"]
+    assert [[i.tolist(), j.tolist()] for i, j in crit.matcher(outputs["aux_outputs"][0], targets)] == fx["idx_aux"]
+    for key, n in (("losses_with_neg", neg), ("losses_without_neg", None)):
+        got = crit(outputs, targets, n)
+        assert set(got) == set(fx[key])
+        for k, v in fx[key].items():
+            assert abs(float(got[k]) - v) <= 1e-5 * max(1.0, abs(v)), (key, k, float(got[k]), v)
+    got = crit(outputs, None)
+    assert set(got) == {"loss_label"} and abs(float(got["loss_label"]) - fx["losses_no_targets"]["loss_label"]) < 1e-5
+    ad = crit.loss_adapter(dict(logits_per_video=t(fx["sim"])))
+    assert abs(float(ad["loss_adapter"]) - fx["loss_adapter"]["loss_adapter"]) < 1e-5
+    # random batches (8 slots, up to 8 targets: rectangular both ways) against the oracle
+    rng = np.random.default_rng(0)
+    for Nq in (5, 8, 2):
+        B = 40
+        cr = build_criterion(make_opt("ego4d", num_queries=Nq, **fx["hyper"]))
+        lg = torch.tensor(rng.standard_normal((B, Nq, 2)), dtype=torch.float32)
+        sp = torch.tensor(np.stack([rng.uniform(.1, .9, (B, Nq)), rng.uniform(.02, .6, (B, Nq))], -1), dtype=torch.float32)
+        tg = [torch.tensor(np.stack([rng.uniform(.1, .9, n), rng.uniform(.02, .6, n)], -1), dtype=torch.float32)
+              for n in rng.integers(1, 9, B)]
+        ref, ridx = O.criterion_layer(fx["hyper"], lg, sp, tg)
+        got = cr(dict(pred_logits=lg.to(dev), pred_spans=sp.to(dev)), dict(span_labels=[dict(spans=x) for x in tg]))
+        midx = cr.matcher(dict(pred_logits=lg.to(dev), pred_spans=sp.to(dev)), dict(span_labels=[dict(spans=x) for x in tg]))
+        assert [(i.tolist(), j.tolist()) for i, j in midx] == [(list(i), list(j)) for i, j in ridx]
+        for k in ("loss_span", "loss_giou", "loss_label", "class_error"):
+            assert abs(float(got[k]) - float(ref[k])) <= 1e-5 * max(1.0, abs(float(ref[k]))), (Nq, k)

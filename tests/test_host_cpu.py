@@ -38,7 +38,7 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     opt = make_opt("ego4d")
     model, crit = build_model(opt)
-    assert crit is None
+    assert crit is not None and crit.weight_dict["loss_span"] == 10 and "loss_giou_0" in crit.weight_dict
     with pytest.raises(_lib.ConeHipError):
         model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
 

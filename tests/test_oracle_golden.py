@@ -184,3 +184,27 @@ def test_metric_evaluators_match_reference(golden_dir):
     ov = O.iou_f64(fx["preds"][5], fx["gts"][5])
     assert ov[0] == 0.3 and ov[1] == 0.5 and not (ov[:2] > np.array([0.3, 0.5])).any()
     assert np.isnan(O.iou_f64(fx["preds"][3], fx["gts"][3])[1])
+
+
+def test_criterion_forward_matches_reference_golden(golden_dir):
+    """SetCriterion.forward + HungarianMatcher restated in the oracle against the reference's own losses and
+    assignments (cone/model.py:213-425, cone/matcher.py:37-106): 1-5 target spans per window, auxiliary layer,
+    with / without the negative window, and the adapter NCE loss."""
+    with open(os.path.join(golden_dir, "criterion.json")) as f:
+        fx = json.load(f)
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    tg = [t(x) for x in fx["tgt"]]
+    pos, neg = torch.tensor(fx["pos_idx"]), torch.tensor(fx["neg_idx"])
+    for key, use_neg in (("losses_with_neg", True), ("losses_without_neg", False)):
+        top, idx = O.criterion_layer(fx["hyper"], t(fx["layers"][1]["pred_logits"]), t(fx["layers"][1]["pred_spans"]), tg,
+                                     t(fx["neg"]["pred_logits"]) if use_neg else None, t(fx["saliency"]), pos, neg,
+                                     t(fx["neg"]["saliency_scores"]) if use_neg else None)
+        aux, idx_aux = O.criterion_layer(fx["hyper"], t(fx["layers"][0]["pred_logits"]), t(fx["layers"][0]["pred_spans"]),
+                                         tg, t(fx["neg"]["pred_logits"]) if use_neg else None)
+        assert [[list(i), list(j)] for i, j in idx] == fx["idx"]
+        assert [[list(i), list(j)] for i, j in idx_aux] == fx["idx_aux"]
+        got = {k: float(v) for k, v in top.items()}
+        got.update({k + "_0": float(v) for k, v in aux.items()})
+        for k, v in fx[key].items():
+            assert abs(got[k] - v) <= 1e-5 * max(1.0, abs(v)), (key, k, got[k], v)
+    assert abs(float(O.adapter_nce(t(fx["sim"]), fx["hyper"]["temperature"])) - fx["loss_adapter"]["loss_adapter"]) < 1e-5
