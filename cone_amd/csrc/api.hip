@@ -44,7 +44,8 @@ struct cone_model {
     // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
     const float* dec_vT[CONE_MAX_LAYERS] = {};
     // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
-    int opt_dec_fold = 1;     // decoder memory K/V projections folded into the cross-attention kernel
+    int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 = on the matrix
+                              // cores (dec_cross_mfma.hip), 1 = on the VALU (dec_cross.hip), 0 = K/V GEMMs + small_attn
     int opt_dec0_const = 1;   // first decoder layer's window-independent rows computed once and replicated
     int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
     int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
@@ -262,7 +263,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 struct FwdBuffers {
     int* off;
     float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
-    float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP;
+    float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS;
 };
 struct FwdPlan { bool tables, fold; };
 static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
@@ -290,6 +291,7 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
     f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
     f.HS = c.take<float>(nd * T * 256); f.S1 = c.take<float>(nd * T * 256); f.S2 = c.take<float>(nd * T * 256);
     f.LG = c.take<float>(nd * T * 2); f.SP = c.take<float>(nd * T * 2);
+    f.QKS = c.take<float>(dec_cross_mfma_slab_floats());
 }
 static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax, const FwdPlan& p) {
     Carver c(nullptr, ~(size_t)0);
@@ -411,7 +413,11 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             RUN(launch_tile_rows(f.TGT1, m->nq, T, s));
             RUN(launch_tile_rows(f.DQ, m->nq, T, s));
         }
-        if (fold)
+        if (fold && m->opt_dec_fold >= 2)
+            RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
+                                      f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax,
+                                      Tq != T ? f.QKS : nullptr, s));      // layer 0: the same queries for every window
+        else if (fold)
             RUN(launch_dec_cross(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                  f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, s));
         else
@@ -648,7 +654,11 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
 
 extern "C" int cone_model_set_option(cone_model* m, const char* name, int value) {
     CONE_REQUIRE(m && name, "set_option: null argument");
-    if (!strcmp(name, "dec_fold")) { m->opt_dec_fold = value != 0; return 0; }
+    if (!strcmp(name, "dec_fold")) {
+        CONE_REQUIRE(value >= 0 && value <= 2, "set_option: dec_fold %d not in [0, 2]", value);
+        m->opt_dec_fold = value;
+        return 0;
+    }
     if (!strcmp(name, "l0_gather")) { m->opt_l0_gather = value != 0; return 0; }
     if (!strcmp(name, "dec0_const")) { m->opt_dec0_const = value != 0; return 0; }
     if (!strcmp(name, "pos_tables")) { m->opt_pos_tables = value != 0; return 0; }

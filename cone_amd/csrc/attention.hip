@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
     constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
     __shared__ float KsT[32 * LDK];
     __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
-    const int b = blockIdx.x, head = blockIdx.y;
+    const int b = blockIdx.y, head = blockIdx.x;        // the 8 heads of a window are dispatched together
     const int t0 = off[b];
     const int L = off[b + 1] - t0;
     const int nkt = (L + 15) >> 4;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
 
 template <int MODE>
 static int launch_enc_attn_t(const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
-    dim3 grid(B, 8);
+    dim3 grid(8, B);
     const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
 #define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, MODE>), grid, dim3(64 * N), 0, s, a, OUT, off); break;
     switch (nkt) {

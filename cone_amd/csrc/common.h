@@ -138,6 +138,13 @@ bool dec_cross_supported(int nq, int Lmax);
 int launch_dec_cross(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                      const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
                      int Lmax, hipStream_t s);
+// the same on the matrix cores (dec_cross_mfma.hip): the two 256-channel contractions as v_mfma_f32_16x16x4_f32 tiles
+// qk_slabs (dec_cross_mfma_slab_floats() floats of scratch, or null): the queries are the same rows for every window
+// (first decoder layer): the folded-key operand is built once instead of per window
+size_t dec_cross_mfma_slab_floats();
+int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
+                          const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
+                          int Lmax, float* qk_slabs, hipStream_t s);
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 

@@ -286,7 +286,8 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
 /* A/B switches of ONE model handle for the parity tests (not thread-safe; set them before using the handle).
- * "dec_fold" (default 1): decoder cross-attention with the memory K/V projections folded into one kernel per layer;
+ * "dec_fold" (default 2): decoder cross-attention with the memory K/V projections folded into one kernel per layer,
+ *   2 = its two 256-channel contractions on the matrix cores (dec_cross_mfma.hip), 1 = on the VALU (dec_cross.hip);
  *   0 = two stacked K/V GEMMs + per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
  *   caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.

@@ -294,14 +294,19 @@ def test_position_tables_equal_materialised_pos_path(preset):
         for lvl in (0, 1):                       # the table path with GEMMs / with only the feed-forward block fused
             model.set_option("ffn_fused", lvl)
             outs.append(inf.run_windows(model, store, opt, wt))
+        model.set_option("ffn_fused", 2)
+        model.set_option("dec_fold", 1)          # the table path with the VALU cross-attention
+        outs.append(inf.run_windows(model, store, opt, wt))
     finally:
         model.set_option("pos_tables", 1)
         model.set_option("ffn_fused", 2)
+        model.set_option("dec_fold", 2)
     assert int((wt["vid_len"] < opt.max_v_l).sum()) > 0          # ragged windows are in the batch
     for k in ("pred_logits", "pred_spans", "saliency_scores"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < 5e-5, k
         assert maxdiff(outs[0][k], outs[2][k].cpu()) < 5e-5, ("ffn_fused 0", k)
         assert maxdiff(outs[0][k], outs[3][k].cpu()) < 5e-5, ("ffn_fused 1", k)
+        assert maxdiff(outs[0][k], outs[4][k].cpu()) < 5e-5, ("dec_fold 1", k)
     safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
     d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
     assert float(d[safe].max()) < 5e-5
@@ -791,16 +796,17 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
     lib = _lib.load()
     outs = []
     try:
-        for fold in (1, 0):
+        for fold in (2, 0, 1):      # matrix-core fold (default), K/V GEMMs + per-head attention, VALU fold
             model.set_option("dec_fold", fold)
             o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
             outs.append({k: o[k].cpu() for k in ("pred_logits", "pred_spans", "hs")})
     finally:
-        model.set_option("dec_fold", 1)
+        model.set_option("dec_fold", 2)
     with pytest.raises(_lib.ConeHipError):
         model.set_option("no_such_option", 1)
     for k in ("pred_logits", "pred_spans", "hs"):
         assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
+        assert maxdiff(outs[0][k], outs[2][k]) < 2e-5, ("valu fold", k)
     # the first decoder layer's window-independent rows (tgt = 0) computed once and replicated: identical bits
     try:
         model.set_option("dec0_const", 0)
