@@ -80,6 +80,9 @@ _SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cone_topk_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cone_topk_windows_workspace": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "cone_topk_windows_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
     "cone_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),
     "cone_project_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),

@@ -76,8 +76,10 @@ def topk_windows(win_scores: torch.Tensor, k: int):
     nq, nw = win_scores.shape
     idx = torch.empty(nq, k, dtype=torch.int32, device=win_scores.device)
     val = torch.empty(nq, k, device=win_scores.device)
-    _lib.check(lib.cone_topk_windows(_lib.ptr(win_scores, torch.float32), nq, nw, k, _lib.ptr(idx), _lib.ptr(val),
-                                     _lib.stream()))
+    nbytes = lib.cone_topk_windows_workspace(nq, nw, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=win_scores.device)
+    _lib.check(lib.cone_topk_windows_ws(_lib.ptr(win_scores, torch.float32), nq, nw, k, _lib.ptr(idx), _lib.ptr(val),
+                                        _lib.ptr(ws), ws.numel(), _lib.stream()))
     return idx, val
 
 

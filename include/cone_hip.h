@@ -105,6 +105,12 @@ int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* 
  * first (stable order).  idx (nq,k) int32, val (nq,k) fp32 (val may be NULL). */
 int cone_topk_windows(const float* win_scores, int nq, int64_t num_window, int k,
                       int32_t* idx, float* val, void* stream);
+/* The same with caller-owned scratch: rows longer than 8 192 windows (MAD scale) run as a two-level selection -- a
+ * stable top-k per 4 096-window chunk out of LDS, then a merge of the chunk lists (same order, bit for bit) -- instead
+ * of k passes over the whole row.  ws >= cone_topk_windows_workspace(...) bytes (0 for short rows). */
+size_t cone_topk_windows_workspace(int nq, int64_t num_window, int k);
+int cone_topk_windows_ws(const float* win_scores, int nq, int64_t num_window, int k, int32_t* idx, float* val,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* A3+A4 for a whole split in three launches.  The clip features of all videos sit back to back in
  * `arena` (rows, dv).  A group g = one video (rows g_row0[g] .. +g_ctx_l[g]) and up to 4 of its
