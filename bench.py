@@ -189,7 +189,7 @@ def _timed(fn, steps, warmup):
 def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
     """BASELINE configs[2]: MAD-scale long video (ctx_l x 512 fp32 = 12.7 GB resident in HBM, ~100 k windows of 125
     clips), frame scores + window max + stable top-30 for 1 query (streaming kernel) and for 64 queries at once
-    (fp32-MFMA GEMM over the clip arena).  Roofline: SURVEY 8d's algorithmic bytes 4*ctx_l*dv + Q*4*(dv + num_window)
+    (fp32-MFMA tiles with the queries as LDS operand slabs, frames read once).  Roofline: SURVEY 8d's algorithmic bytes 4*ctx_l*dv + Q*4*(dv + num_window)
     over the hipEvent time of the frame-score kernel(s) of one query batch (the dominant kernel, > 75 % of the
     path) and, as `path_frac`, over the wall time of the whole pre-filter call sequence."""
     lib = _lib.load()
@@ -216,7 +216,7 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
         ach = alg / (k_ms * 1e-3) / 1e9
         out[f"q{nq}"] = {"queries": nq, "ms_per_call": round(dt * 1e3, 3), "windows_per_s": round(nw * nq / dt, 1),
                          "frame_score_kernel_ms": round(k_ms, 3),
-                         "kernel": KERNEL_NAMES[4] if nq == 1 else KERNEL_NAMES[0],
+                         "kernel": KERNEL_NAMES[4] if nq < 8 else "frame_score_mq_kernel",
                          "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                       "algorithmic_bytes": int(alg)},
