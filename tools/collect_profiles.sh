@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect the per-round rocprofv3 evidence on the GPU box (run from the repo root through gpurun):
+#   tools/collect_profiles.sh r02
+# writes gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards.  Counters are collected in their own
+# passes (never together with API traces), each a separate run of the same bench command.
+set -u
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
+rm -rf $out/prof_$tag $out/pmc_fetch $out/pmc_write $out/pmc_mfma
+rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
+    > $out/${tag}_prof_bench.json 2> $out/prof_$tag.log
+python3 tools/rocpd_summary.py $out/prof_$tag/t_results.db > $out/${tag}_bench_kernel_stats_all.csv 2>> $out/prof_$tag.log
+rm -rf $out/prof_${tag}_step
+rocprofv3 --kernel-trace --stats -d $out/prof_${tag}_step -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
+    --no_extras > $out/${tag}_prof_step.json 2>> $out/prof_$tag.log
+# the timed region only: the last launches of the trace (3 steps), so that per-kernel averages are those of the step
+python3 tools/rocpd_summary.py $out/prof_${tag}_step/t_results.db 185 > $out/${tag}_bench_kernel_stats.csv 2>> $out/prof_$tag.log
+B="python3 bench.py --steps 2 --warmup 1 --cpu_queries 0 --no_extras"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $B > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $B > $out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv \
+    -d $out/pmc_mfma -o m -- $B > $out/pmc_mfma.log 2>&1
+python3 tools/pmc_summary.py $out $out/${tag}_pmc > $out/${tag}_pmc.log 2>&1
+tail -3 $out/${tag}_pmc.log
+cat $out/${tag}_bench_line.json
