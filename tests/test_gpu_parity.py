@@ -101,11 +101,13 @@ def test_gemm_matches_torch(M, N, K, flags, a2):
         assert torch.equal(C2, C + ADD)
 
 
-@pytest.mark.parametrize("M,ff", [(1, 1024), (16, 32), (127, 1024), (129, 1024), (1000, 2048), (4099, 1024), (300, 48)])
+@pytest.mark.parametrize("M,ff", [(1, 1024), (16, 32), (127, 1024), (129, 1024), (1000, 2048), (4099, 1024), (300, 48),
+                                  (70000, 1024)])
 def test_fused_ffn_matches_float64(M, ff):
     """ffn.hip: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one kernel (hidden rows kept on chip, transposed MFMA
     orientation, k index permuted) against a float64 evaluation; ragged last tile, 1-row and multi-tile cases,
-    hidden sizes of 2 / 3 / 64 / 128 chunks."""
+    hidden sizes of 2 / 3 / 64 / 128 chunks; 70 000 rows = more tiles than persistent workgroups (the ring runs on across
+    tiles)."""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(M * 31 + ff)
