@@ -284,6 +284,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test-only overrides so that the N > 1 code path can be exercised on a one-GPU box (tests/test_gpu_parity.py):
+    # CONE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, CONE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks
+    # on one device).  Neither is set by the driver's launch.
+    if os.environ.get("CONE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CONE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     # Host side of the step is launch glue + list building: a large intra-op pool only adds wake-up latency
     # (torch.distributed.run sets OMP_NUM_THREADS=1 for the same reason); cpu_baseline() sizes its own pool.
@@ -292,7 +298,10 @@ def main():
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with a single rank)
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
                    window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks, pipeline_tail=args.pipeline_tail,
@@ -314,11 +323,13 @@ def main():
             # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors; every rank has
             # built the submission rows of ITS OWN shard (the host work shards with the queries)
             rows, n = dp["rows"], dp["n"]
-            rows_all = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
-            n_all = torch.empty((world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
+            # output shaped (world * dim0, ...): the concatenation form every backend accepts
+            rows_all = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+            n_all = torch.empty((world * n.shape[0],) + tuple(n.shape[1:]), dtype=n.dtype, device=n.device)
             dist.all_gather_into_tensor(rows_all, rows.contiguous())
             dist.all_gather_into_tensor(n_all, n.contiguous())
-            dp["rows_all"], dp["n_all"] = rows_all, n_all
+            dp["rows_all"] = rows_all.view((world,) + tuple(rows.shape))
+            dp["n_all"] = n_all.view((world,) + tuple(n.shape))
         return [out], dp
 
     def fence():

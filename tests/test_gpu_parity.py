@@ -1325,3 +1325,33 @@ def test_criterion_forward_matches_reference_golden(golden_dir):
         assert [(i.tolist(), j.tolist()) for i, j in midx] == [(list(i), list(j)) for i, j in ridx]
         for k in ("loss_span", "loss_giou", "loss_label", "class_error"):
             assert abs(float(got[k]) - float(ref[k])) <= 1e-5 * max(1.0, abs(float(ref[k]))), (Nq, k)
+
+
+# ------------------------------------------------------------------------------------ bench.py launched with N > 1
+def test_bench_two_ranks_on_one_device():
+    """The driver launches bench.py for N > 1 through torch.distributed.run; a one-GPU box cannot host two RCCL ranks, so
+    this runs the SAME code path (weak step + all_gather of kept rows, strong-scaling window-sharded split, max-over-ranks
+    timing) with both ranks on cuda:0 over gloo -- the only two lines that differ are the backend name and the device id."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CONE_BENCH_ONE_DEVICE="1", CONE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--queries", "96", "--videos", "6"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["scaling"] == "weak"
+    nw = int(res["config"]["workload"].split(",")[-1].split()[0])
+    assert abs(res["value"] - 2 * nw * 2 / (res["ms_per_step"] * 2e-3)) < 0.01 * res["value"]       # whole-job aggregate
+    st = res["strong_scaling"]
+    assert st["ranks_seen"] == 2 and st["scaling"] == "strong" and st["collectives_per_step"] == 1
+    assert st["n_windows"] == nw and st["value"] > 0
+    assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
