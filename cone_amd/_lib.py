@@ -103,6 +103,8 @@ _SIGNATURES = {
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_clip_matching": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_window_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3
+                          + [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     "cone_compose_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cone_fuse_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,

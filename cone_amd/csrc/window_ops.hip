@@ -351,3 +351,68 @@ extern "C" int cone_compose_rows(const float* logits, const float* spans, const 
     CONE_LAUNCH_CHECK();
     return 0;
 }
+
+// A5 -- eval branch of StartEndDataset.__getitem__ + collate (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-344)
+// for a DENSE window list (every query owns exactly K selected windows, row b = query b / K, rank slot b % K): the
+// window's clip range, its text range and -- hazard H3 -- the zero-padded clip length of its reference batch (the
+// longest window among the eval_bsz consecutive queries of the SPLIT that the query belongs to).
+namespace cone {
+
+__global__ __launch_bounds__(256) void window_table_kernel(const int* __restrict__ win_idx, int B, int K,
+                                                           const int* __restrict__ q_ctx_l,
+                                                           const int* __restrict__ q_vid_off,
+                                                           const int* __restrict__ tok_off,
+                                                           const int* __restrict__ tok_len, int q_base, int eval_bsz,
+                                                           int W, int S, int* __restrict__ batch_max,
+                                                           int* __restrict__ vid_row0, int* __restrict__ vid_len,
+                                                           int* __restrict__ video_start, int* __restrict__ txt_row0,
+                                                           int* __restrict__ txt_len, int* __restrict__ cls_row) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int q = b / K;
+    const int wi = win_idx[b];
+    int start = (wi - 1) * S;                       // window 0 is the half window ahead of the video (:229-234)
+    int end = start + W;
+    start = start < 0 ? 0 : start;
+    const int cl = q_ctx_l[q];
+    end = end < cl ? end : cl;
+    const int vlen = end - start;
+    vid_row0[b] = q_vid_off[q] + start;
+    vid_len[b] = vlen;
+    video_start[b] = start;
+    txt_row0[b] = tok_off[q];
+    txt_len[b] = tok_len[q];
+    cls_row[b] = q;
+    if (batch_max) atomicMax(batch_max + (q + q_base) / eval_bsz, vlen);
+}
+
+__global__ __launch_bounds__(256) void window_pad_kernel(int B, int K, int q_base, int eval_bsz,
+                                                         const int* __restrict__ batch_pad, int* __restrict__ pad_len) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) pad_len[b] = batch_pad[(b / K + q_base) / eval_bsz];
+}
+
+}  // namespace cone
+
+extern "C" int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* q_ctx_l,
+                                 const int32_t* q_vid_off, const int32_t* tok_off, const int32_t* tok_len, int q_base,
+                                 int eval_bsz, int max_v_l, int32_t* batch_pad, int derive_pad, int n_batches,
+                                 int32_t* vid_row0, int32_t* vid_len, int32_t* video_start, int32_t* pad_len,
+                                 int32_t* txt_row0, int32_t* txt_len, int32_t* cls_row, void* stream) {
+    CONE_REQUIRE(win_idx && q_ctx_l && q_vid_off && tok_off && tok_len && batch_pad && vid_row0 && vid_len &&
+                     video_start && pad_len && txt_row0 && txt_len && cls_row, "window_table: null argument");
+    CONE_REQUIRE(K >= 1 && eval_bsz >= 1 && max_v_l >= 2 && q_base >= 0, "window_table: bad K / eval_bsz / max_v_l / q_base");
+    CONE_REQUIRE((q_base + (nq > 0 ? nq - 1 : 0)) / eval_bsz < n_batches, "window_table: batch_pad holds %d batches, queries reach batch %d",
+                 n_batches, (q_base + nq - 1) / eval_bsz);
+    const int B = nq * K;
+    if (B <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (derive_pad) CONE_CHECK_HIP(hipMemsetAsync(batch_pad, 0, sizeof(int32_t) * (size_t)n_batches, s));
+    hipLaunchKernelGGL(cone::window_table_kernel, dim3((B + 255) / 256), dim3(256), 0, s, win_idx, B, K, q_ctx_l, q_vid_off,
+                       tok_off, tok_len, q_base, eval_bsz, max_v_l, max_v_l / 2, derive_pad ? batch_pad : nullptr, vid_row0,
+                       vid_len, video_start, txt_row0, txt_len, cls_row);
+    CONE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cone::window_pad_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, K, q_base, eval_bsz, batch_pad, pad_len);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}

@@ -338,15 +338,31 @@ def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
     ``batch_pad`` = reference_batch_pad() of the whole split.  Without it the padding is derived from the
     windows of ``store`` alone, which is only the reference's when ``store`` holds whole reference batches --
     a view cut inside a batch must be given the split's table (checked)."""
-    nq = win_idx.shape[0]
-    q_of, slot, start, vlen = _window_geometry(store, opt, win_idx)
+    nq, K = win_idx.shape
     st = store.index_tensors()
-    voff = st["q_vid_off"][q_of]
     if batch_pad is None:
         hi = store.q_base + nq
         if store.q_base % opt.eval_bsz or (hi % opt.eval_bsz and hi != store.nq_split):
             raise ValueError(f"queries [{store.q_base}, {hi}) of a {store.nq_split}-query split cut a reference "
                              f"batch (eval_bsz {opt.eval_bsz}): pass batch_pad=reference_batch_pad(split, ...)")
+    if nq and win_idx.is_cuda and min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2) and not getattr(opt, "window_table_torch", False):
+        # dense selection (every video has at least K windows): the whole table is one launch (cone_window_table)
+        i32 = st.get("i32")
+        if i32 is None:
+            i32 = st["i32"] = tuple(st[k].to(torch.int32).contiguous() for k in ("q_ctx_l", "q_vid_off", "tok_off", "tok_len"))
+        dense = st.get(("dense", K))
+        if dense is None:
+            ar = torch.arange(nq * K, device=win_idx.device)
+            dense = st[("dense", K)] = (ar // K, ar % K)
+        nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
+        bp = None if batch_pad is None else batch_pad.to(torch.int32).contiguous()
+        wt = ops.window_table_dense(win_idx.contiguous(), *i32, store.q_base, opt.eval_bsz, opt.max_v_l, bp, nb)
+        wt.pop("batch_pad")
+        wt["q_of"], wt["slot"] = dense
+        return wt
+    q_of, slot, start, vlen = _window_geometry(store, opt, win_idx)
+    voff = st["q_vid_off"][q_of]
+    if batch_pad is None:
         batch_pad = reference_batch_pad(store, opt, win_idx)
     bid = (q_of + store.q_base) // opt.eval_bsz
     i32 = lambda t: t.to(torch.int32).contiguous()
@@ -579,14 +595,28 @@ def format_results(ann, opt, rows, n):
         return _format_results(ann, opt, rows, n)
 
 
+_EGO4D_KEYS = {}        # id(annotation list) -> (the list, parsed keys): the keys depend on the annotation file only
+
+
+def _ego4d_keys(ann):
+    hit = _EGO4D_KEYS.get(id(ann))
+    if hit is not None and hit[0] is ann and len(hit[1]) == len(ann):
+        return hit[1]
+    keys = []
+    for meta in ann:                                                # cone/inference.py:133-140
+        parts = meta["query_id"].split("_")
+        assert len(parts) == 2
+        keys.append((int(parts[1]), parts[0], meta["clip_id"]))
+    if len(_EGO4D_KEYS) > 64:
+        _EGO4D_KEYS.clear()
+    _EGO4D_KEYS[id(ann)] = (ann, keys)
+    return keys
+
+
 def _format_results(ann, opt, rows, n):
     lists = _rows_to_lists(rows, n)
     if opt.dset_name == "ego4d":
-        keys = []
-        for meta in ann:                                            # cone/inference.py:133-140
-            parts = meta["query_id"].split("_")
-            assert len(parts) == 2
-            keys.append((int(parts[1]), parts[0], meta["clip_id"]))
+        keys = _ego4d_keys(ann)
         return tuple([{"query_idx": k[0], "annotation_uid": k[1], "predicted_times": pt, "clip_uid": k[2]}
                       for k, pt in zip(keys, lists[t])] for t in range(3))
     return tuple([{"query_id": m["query_id"], "predicted_times": pt, "video_id": m["video_id"]}

@@ -83,6 +83,30 @@ def topk_windows(win_scores: torch.Tensor, k: int):
     return idx, val
 
 
+def window_table_dense(win_idx, q_ctx_l, q_vid_off, tok_off, tok_len, q_base: int, eval_bsz: int, max_v_l: int,
+                       batch_pad=None, n_batches: int = 0):
+    """A5 for a dense selection (every query owns exactly K windows), one launch instead of ~50 index operations.
+    win_idx (nq, K) int32; the per-query vectors int32.  batch_pad (n_batches) int32 = the split's padding table, or
+    None: derived from these windows (whole reference batches only).  Returns a dict of (nq * K) int32 columns +
+    ``batch_pad``."""
+    lib = _lib.load()
+    nq, K = win_idx.shape
+    dev = win_idx.device
+    out = torch.empty(7, nq * K, dtype=torch.int32, device=dev)
+    derive = batch_pad is None
+    if derive:
+        batch_pad = torch.empty(n_batches, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    _lib.check(lib.cone_window_table(p(win_idx, torch.int32), nq, K, p(q_ctx_l, torch.int32), p(q_vid_off, torch.int32),
+                                     p(tok_off, torch.int32), p(tok_len, torch.int32), int(q_base), int(eval_bsz),
+                                     int(max_v_l), p(batch_pad, torch.int32), int(derive), int(batch_pad.numel()),
+                                     *(p(out[i]) for i in range(7)), _lib.stream()))
+    names = ("vid_row0", "vid_len", "video_start", "pad_len", "txt_row0", "txt_len", "cls_row")
+    res = {k: out[i] for i, k in enumerate(names)}
+    res["batch_pad"] = batch_pad
+    return res
+
+
 def compose_rows(logits, spans, match, duration, video_start, clip_length: float, sort: bool = True):
     """cone/inference.py:47-82 -> (B, Nq, 4) fp32 rows [st, ed, prob, match]."""
     lib = _lib.load()

@@ -125,6 +125,22 @@ int cone_prefilter_batched(const float* arena, int dv, const float* cls, const i
                            int nq, int W, int S, float* frame_scores, float* win_scores, int k,
                            int32_t* topk_idx, void* stream);
 
+/* A5, eval branch of StartEndDataset.__getitem__ + collate (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-344) as
+ * index arithmetic, for a DENSE selection: win_idx (nq, K) int32 holds K valid window indices per query (row b of every
+ * output = query b / K, rank slot b % K).  Per-query metadata: q_ctx_l (clips of the query's video), q_vid_off (first arena
+ * row of that video), tok_off / tok_len (the query's text rows).  Outputs (nq * K) int32 each: vid_row0, vid_len,
+ * video_start (window i covers clips [max(0, (i-1) S), min(ctx_l, (i-1) S + max_v_l)), S = max_v_l / 2), txt_row0,
+ * txt_len, cls_row, and pad_len = the zero-padded clip length of the window's reference batch -- the longest window among
+ * the eval_bsz consecutive queries of the SPLIT it belongs to (hazard H3: cone/model.py:186-199 divides by a length
+ * clipped to it).  batch_pad (n_batches) int32 is that table, indexed by (q_base + query) / eval_bsz with q_base = the
+ * first query's index in the split: derive_pad != 0 computes it from these windows (only the reference's when the
+ * queries are whole reference batches -- the caller's responsibility), derive_pad == 0 reads the split's table. */
+int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* q_ctx_l, const int32_t* q_vid_off,
+                      const int32_t* tok_off, const int32_t* tok_len, int q_base, int eval_bsz, int max_v_l,
+                      int32_t* batch_pad, int derive_pad, int n_batches, int32_t* vid_row0, int32_t* vid_len,
+                      int32_t* video_start, int32_t* pad_len, int32_t* txt_row0, int32_t* txt_len, int32_t* cls_row,
+                      void* stream);
+
 /* --------------------------------------------------------- stage B: intra-window model */
 
 /* A6, cone/model.py:100-101 (input_vid_proj / input_txt_proj): row-wise LN->Linear->ReLU->LN->Linear.

@@ -1355,3 +1355,31 @@ def test_bench_two_ranks_on_one_device():
     assert st["ranks_seen"] == 2 and st["scaling"] == "strong" and st["collectives_per_step"] == 1
     assert st["n_windows"] == nw and st["value"] > 0
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
+
+
+@pytest.mark.parametrize("q_base", [0, 8])
+def test_window_table_kernel_matches_index_arithmetic(q_base):
+    """cone_window_table (one launch, dense selections) against the torch index arithmetic of window_table -- which the CPU
+    suite checks against the oracle's collate -- on ragged videos (short last windows, half window 0), on a split view
+    (q_base > 0, the split's padding table handed in) and with the padding derived from the windows themselves."""
+    from cone_amd import inference as inf
+    dev = _gpu()
+    opt = make_opt("ego4d", topk_window=4, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(opt, 20, 5, seed=9, ctx_range=(140, 400))
+    store = inf.FeatureStore(opt, ann, vf, qf, device=dev)
+    win_idx = inf.prefilter(get_model("ego4d", 0)[0], store, opt)
+    assert int((win_idx < 0).sum()) == 0
+    if q_base:
+        pad = inf.reference_batch_pad(store, opt, win_idx)
+        sub = inf.FeatureStore.subset(store, q_base, 17)
+        wi = win_idx[q_base:17].contiguous()
+        got = inf.window_table(sub, opt, wi, batch_pad=pad)
+        opt.window_table_torch = True
+        ref = inf.window_table(sub, opt, wi, batch_pad=pad)
+    else:
+        got = inf.window_table(store, opt, win_idx)
+        opt.window_table_torch = True
+        ref = inf.window_table(store, opt, win_idx)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
