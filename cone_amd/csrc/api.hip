@@ -695,6 +695,15 @@ extern "C" int cone_test_proj_ffn(const float* A, const float* Wo, const float* 
     return launch_proj_ffn_fused(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
                                  (hipStream_t)stream);
 }
+extern "C" int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen,
+                                   const int32_t* off, const float* Wk, const float* WvT, const float* bv, float* OUT,
+                                   int B, int nq, int Lmax, int variant, float* qk_slabs, void* stream) {
+    if (variant == 1)
+        return launch_dec_cross(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, (hipStream_t)stream);
+    return launch_dec_cross_mfma(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, qk_slabs,
+                                 (hipStream_t)stream);
+}
+extern "C" size_t cone_test_dec_cross_slab_floats(void) { return dec_cross_mfma_slab_floats(); }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                                    int dim, void* stream) {
     return launch_layernorm(x, dim, g, b, out, dim, n_rows, nullptr, dim, (hipStream_t)stream);

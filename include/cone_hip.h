@@ -339,6 +339,16 @@ int cone_test_ffn(const float* X, const float* W1, const float* b1, const float*
 int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const float* R, const float* pg, const float* pb,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_g,
                        const float* ln_b, float* OUT, int M, int ff, void* stream);
+/* Fused decoder cross-attention of one layer (cone/transformer.py:308-311) with the memory K / V projections folded in:
+ * DQ (B * nq, 256) projected queries (+ bias), X (M, 256) memory rows packed by off (B + 1), pos_rows / vlen = the sine
+ * table and the clip count of each window (keys = memory + position row for clip tokens), Wk (256, 256) = rows
+ * 256 .. 511 of in_proj_weight, WvT (256, 256) = W_v transposed, bv (256).  OUT (B * nq, 256) = attention output ahead
+ * of out_proj.  variant 2: matrix cores (qk_slabs != NULL: every window has the SAME nq query rows, the folded operand
+ * is built once into that scratch of cone_test_dec_cross_slab_floats() floats), 1: VALU kernel. */
+int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen, const int32_t* off,
+                        const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax,
+                        int variant, float* qk_slabs, void* stream);
+size_t cone_test_dec_cross_slab_floats(void);
 int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,
                         int dim, void* stream);
 

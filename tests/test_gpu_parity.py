@@ -1383,3 +1383,54 @@ def test_window_table_kernel_matches_index_arithmetic(q_base):
     assert set(got) == set(ref)
     for k in ref:
         assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
+
+
+@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("shared", [False, True])
+def test_fused_decoder_cross_attention_matches_float64(variant, shared):
+    """dec_cross_mfma.hip / dec_cross.hip called directly: attention of the nq query slots over a window's memory rows with
+    the K / V projections folded into the queries / the context (cone/transformer.py:308-311), keys = memory + sine row for
+    clip tokens, against nn.MultiheadAttention's arithmetic in float64.  Ragged windows: 1 clip, no text, 128 keys, a
+    window with text only; ``shared``: every window has the same query rows (first decoder layer)."""
+    from cone_amd import _lib
+    if shared and variant == 1:
+        pytest.skip("the VALU kernel has no shared-query form")
+    dev = _gpu()
+    g = torch.Generator().manual_seed(7 + variant)
+    vl = [90, 1, 45, 90, 0, 17, 90, 64]
+    tl = [20, 8, 12, 0, 9, 3, 38, 1]
+    B, nq = len(vl), 5
+    L = [a + b for a, b in zip(vl, tl)]
+    off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
+    M = int(off[-1])
+    X = torch.randn(M, 256, generator=g)
+    pos = torch.randn(4095, 256, generator=g)
+    DQ = torch.randn(nq, 256, generator=g).repeat(B, 1) if shared else torch.randn(B * nq, 256, generator=g)
+    Wk = torch.randn(256, 256, generator=g) / 16
+    Wv = torch.randn(256, 256, generator=g) / 16
+    bv = torch.randn(256, generator=g)
+    ref = torch.empty(B * nq, 256, dtype=torch.float64)
+    for b in range(B):
+        mem = X[off[b]:off[b + 1]].double()
+        keys = mem.clone()
+        lv = vl[b]
+        keys[:lv] += pos[lv * (lv - 1) // 2: lv * (lv - 1) // 2 + lv].double()
+        K = keys @ Wk.double().t()
+        V = mem @ Wv.double().t() + bv.double()
+        q = DQ[b * nq:(b + 1) * nq].double() * (1.0 / 32 ** 0.5)
+        for h in range(8):
+            sl = slice(32 * h, 32 * h + 32)
+            p = torch.softmax(q[:, sl] @ K[:, sl].t(), dim=1)
+            ref[b * nq:(b + 1) * nq, sl] = p @ V[:, sl]
+    d = lambda t: t.to(dev).contiguous()
+    lib = _lib.load()
+    out = torch.full((B * nq + 2, 256), float("nan"), device=dev)
+    slabs = torch.empty(lib.cone_test_dec_cross_slab_floats(), device=dev) if shared else None
+    Xd, pd, DQd, Wkd, WvTd, bvd = d(X), d(pos), d(DQ), d(Wk), d(Wv.t()), d(bv)
+    vld, offd = torch.tensor(vl, dtype=torch.int32, device=dev), torch.from_numpy(off).to(dev)
+    _lib.check(lib.cone_test_dec_cross(_lib.ptr(DQd), _lib.ptr(Xd), _lib.ptr(pd), _lib.ptr(vld), _lib.ptr(offd),
+                                       _lib.ptr(Wkd), _lib.ptr(WvTd), _lib.ptr(bvd), _lib.ptr(out), B, nq, max(L), variant,
+                                       _lib.ptr(slabs), _lib.stream()))
+    torch.cuda.synchronize()
+    assert maxdiff(out[:B * nq], ref) < 2e-5
+    assert bool(torch.isnan(out[B * nq:]).all())
