@@ -695,6 +695,14 @@ extern "C" int cone_test_proj_ffn(const float* A, const float* Wo, const float* 
     return launch_proj_ffn_fused(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
                                  (hipStream_t)stream);
 }
+extern "C" int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt,
+                                  const float* pos_qk, const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0,
+                                  const int32_t* off, float* OUT, int B, int Lmax, void* stream) {
+    AttnSrc a{};
+    a.Q = QKV; a.K = QKV ? QKV + 256 : nullptr; a.V = QKV ? QKV + 512 : nullptr; a.ldq = a.ldk = a.ldv = 768;
+    a.qkv_vid = qkv_vid; a.qkv_txt = qkv_txt; a.pos_qk = pos_qk; a.vrow0 = vrow0; a.vlen = vlen; a.trow0 = trow0;
+    return launch_enc_attn(mode, a, OUT, off, B, Lmax, (hipStream_t)stream);
+}
 extern "C" int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen,
                                    const int32_t* off, const float* Wk, const float* WvT, const float* bv, float* OUT,
                                    int B, int nq, int Lmax, int variant, float* qk_slabs, void* stream) {

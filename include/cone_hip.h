@@ -339,6 +339,13 @@ int cone_test_ffn(const float* X, const float* W1, const float* b1, const float*
 int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const float* R, const float* pg, const float* pb,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_g,
                        const float* ln_b, float* OUT, int M, int ff, void* stream);
+/* Encoder self-attention core (cone/transformer.py:239, 8 heads x 32) over windows of packed tokens off[b] .. off[b+1]:
+ * mode 0: QKV (M, 768) = q | k | v rows that already carry the position term; mode 2: the same without it, the kernel adds
+ * pos_qk[(vlen[b], p)] (R, 512) to q | k of clip token p; mode 1: q | k | v gathered from per-clip rows qkv_vid[vrow0[b] + p]
+ * and per-text-token rows qkv_txt[trow0[b] + t] (+ the pos_qk row for clips).  OUT (M, 256) ahead of out_proj. */
+int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt, const float* pos_qk,
+                       const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0, const int32_t* off, float* OUT,
+                       int B, int Lmax, void* stream);
 /* Fused decoder cross-attention of one layer (cone/transformer.py:308-311) with the memory K / V projections folded in:
  * DQ (B * nq, 256) projected queries (+ bias), X (M, 256) memory rows packed by off (B + 1), pos_rows / vlen = the sine
  * table and the clip count of each window (keys = memory + position row for clip tokens), Wk (256, 256) = rows

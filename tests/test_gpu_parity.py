@@ -1434,3 +1434,55 @@ def test_fused_decoder_cross_attention_matches_float64(variant, shared):
     torch.cuda.synchronize()
     assert maxdiff(out[:B * nq], ref) < 2e-5
     assert bool(torch.isnan(out[B * nq:]).all())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_encoder_attention_kernel_matches_float64(mode):
+    """attention.hip called directly in its three source modes (packed q|k|v; gathered from the per-clip / per-token
+    layer-0 caches + position table; packed + position table) against softmax(q k^T / sqrt(32)) v per head in float64, on
+    ragged windows: 1 token, text only, clips only, 16-multiples, the 192-token maximum."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(11 + mode)
+    vl = [90, 1, 0, 48, 90, 17, 125, 64, 150]
+    tl = [20, 0, 9, 0, 6, 3, 25, 32, 42]
+    B = len(vl)
+    L = [a + b for a, b in zip(vl, tl)]
+    off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
+    M = int(off[-1])
+    Wmax = 150
+    pos = torch.randn(Wmax * (Wmax + 1) // 2, 512, generator=g)
+    qkv_vid = torch.randn(400, 768, generator=g)
+    qkv_txt = torch.randn(120, 768, generator=g)
+    vrow0 = [0, 399, 5, 100, 200, 30, 250, 7, 120]
+    trow0 = [0, 50, 100, 0, 30, 117, 60, 80, 10]
+    QKV = torch.randn(M, 768, generator=g)
+    rows = torch.empty(M, 768, dtype=torch.float64)          # effective q | k | v rows of every packed token
+    for b in range(B):
+        lv, lt, t0 = vl[b], tl[b], int(off[b])
+        if mode == 1:
+            rows[t0:t0 + lv] = qkv_vid[vrow0[b]:vrow0[b] + lv].double()
+            rows[t0 + lv:t0 + lv + lt] = qkv_txt[trow0[b]:trow0[b] + lt].double()
+        else:
+            rows[t0:t0 + lv + lt] = QKV[t0:t0 + lv + lt].double()
+        if mode != 0:
+            rows[t0:t0 + lv, :512] += pos[lv * (lv - 1) // 2: lv * (lv - 1) // 2 + lv].double()
+    ref = torch.empty(M, 256, dtype=torch.float64)
+    for b in range(B):
+        r = rows[off[b]:off[b + 1]]
+        for h in range(8):
+            sl = slice(32 * h, 32 * h + 32)
+            p = torch.softmax((r[:, sl] / 32 ** 0.5) @ r[:, 256:512][:, sl].t(), dim=1)
+            ref[off[b]:off[b + 1], sl] = p @ r[:, 512:][:, sl]
+    d = lambda t: t.to(dev).contiguous()
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    out = torch.full((M + 1, 256), float("nan"), device=dev)
+    lib = _lib.load()
+    QKVd, vd, td, pd = d(QKV), d(qkv_vid), d(qkv_txt), d(pos)
+    vr, vlv, tr, offd = i32(vrow0), i32(vl), i32(trow0), torch.from_numpy(off).to(dev)
+    _lib.check(lib.cone_test_enc_attn(mode, _lib.ptr(QKVd), _lib.ptr(vd), _lib.ptr(td), _lib.ptr(pd), _lib.ptr(vr),
+                                      _lib.ptr(vlv), _lib.ptr(tr), _lib.ptr(offd), _lib.ptr(out), B, max(L),
+                                      _lib.stream()))
+    torch.cuda.synchronize()
+    assert maxdiff(out[:M], ref) < 2e-5
+    assert bool(torch.isnan(out[M:]).all())
