@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: random small splits (ragged videos from 1 clip up, 1..N queries, text lengths 1..max, top-k
+above and below the number of windows, every eval_bsz / NMS threshold / window batch), device pipeline against the CPU
+oracle: rank lists exact, window rows within the logit tolerance, fusion + NMS exact on identical candidates, results
+independent of window_batch.  Test infrastructure (imports oracle/).  usage: fuzz_parity.py [iterations] [seed0] [preset]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cone_amd import inference as inf, synth  # noqa: E402
+from cone_amd.config import make_opt  # noqa: E402
+from cone_amd.model import build_model  # noqa: E402
+from oracle import cone_oracle as O  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+preset = sys.argv[3] if len(sys.argv) > 3 else "ego4d"
+torch.cuda.set_device(0)
+base = make_opt(preset)
+sd = synth.make_state_dict(base, 0)
+model, _ = build_model(base)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+A = lambda r: np.array(r["pred_relevant_windows"])
+worst = dict(prop=0.0, sec=0.0, match_bad=0.0)
+t_start = time.time()
+for it in range(iters):
+    rng = np.random.default_rng(seed0 + it)
+    W = base.max_v_l
+    lo = int(rng.choice([1, 5, W // 2, W, W + 1, 2 * W]))
+    hi = lo + int(rng.choice([1, 7, W, 3 * W]))
+    opt = make_opt(preset, nms_thd=float(rng.choice([0.3, 0.5, 0.7, -1.0])), eval_split_name="test",
+                   topk_window=int(rng.choice([1, 2, 5, 9])), eval_bsz=int(rng.choice([1, 3, 4, 32])),
+                   window_batch=int(rng.choice([1, 7, 64, 32768])))
+    nq, nv = int(rng.choice([1, 2, 7, 13])), int(rng.choice([1, 2, 3]))
+    ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=seed0 + it, ctx_range=(lo, hi),
+                                     lq_range=(1, int(rng.choice([2, 8, opt.max_q_l + 1]))))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    (fusion, prop, match), info = inf.predict_split(model, store, opt)
+    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    tag = f"iter {it} (seed {seed0 + it}: ctx [{lo},{hi}) nq {nq} nv {nv} topk {opt.topk_window} bsz {opt.eval_bsz} nms {opt.nms_thd} wb {opt.window_batch})"
+    for qi, row in enumerate(ann):
+        got = [w for w in info["win_idx"][qi].cpu().tolist() if w >= 0]
+        assert got == ranks[row["query_id"]][:opt.topk_window], f"{tag}: rank list of query {qi}: {got} vs {ranks[row['query_id']]}"
+    mine, _ = inf.compute_mr_results(model, store, opt, info["win_idx"])
+    assert len(mine) == len(mr), f"{tag}: {len(mine)} windows vs {len(mr)}"
+    for a, b in zip(mine, mr):
+        assert a["query_id"] == b["query_id"], tag
+    dp = max(np.abs(A(a)[:, 2] - A(b)[:, 2]).max() for a, b in zip(mine, mr))
+    ds = max(np.abs(A(a)[:, :2] - A(b)[:, :2]).max() for a, b in zip(mine, mr))
+    dm = np.concatenate([np.abs(A(a)[:, 3] - A(b)[:, 3]) for a, b in zip(mine, mr)])
+    assert dp <= 2e-4, f"{tag}: proposal scores off by {dp}"
+    assert ds <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4, f"{tag}: spans off by {ds} s"
+    bad = float((dm > 2e-4).mean())
+    worst["prop"], worst["sec"], worst["match_bad"] = max(worst["prop"], dp), max(worst["sec"], ds), max(worst["match_bad"], bad)
+    fmt = inf.postprocessing_format_ego4d if opt.dset_name == "ego4d" else inf.postprocessing_format_mad
+    assert fmt(mr, opt) == (fo, po, mo), f"{tag}: fusion / NMS differ on identical candidates"
+    assert len(fusion) == len(fo) == nq, tag
+    opt2 = make_opt(preset, **{k: getattr(opt, k) for k in ("nms_thd", "eval_split_name", "topk_window", "eval_bsz")},
+                    window_batch=32768 if opt.window_batch != 32768 else 5)
+    again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
+    assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
+print(f"fuzz ok: {iters} random splits ({preset}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
+      f"worst span diff {worst['sec']:.2e} s, worst share of matching rows beyond 2e-4: {worst['match_bad']:.0%}")
