@@ -50,6 +50,7 @@ struct cone_model {
     int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
     int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
     int opt_gemm = 0;         // GEMM tile family forced for every dense layer (GEMM_AUTO = by shape)
+    int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
     int opt_ffn_fused = 2;    // 1: linear1 + ReLU + linear2 + residual + LayerNorm as one kernel (ffn.hip); 2: the attention
                               // output projection + residual + LayerNorm ahead of it in the same kernel as well; 0: GEMMs
 };
@@ -322,7 +323,14 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
     const bool gather0 = l0 && m->opt_l0_gather;
-    if (l0) {
+    // first layer entirely from the per-clip / per-token rows: attention gathers q|k|v, the fused layer tail gathers its
+    // residual rows through a row index (kept in the X1 region, unused by that path) -- no packed copy of the input
+    const bool gather_res = gather0 && plan.tables && m->opt_ffn_fused >= 2 && m->opt_res_gather && ffn_fused_supported(ff) &&
+                            m->n_enc > 0;
+    int* RIDX = reinterpret_cast<int*>(f.X1);
+    if (gather_res) {
+        RUN(launch_row_index(vrow0, vlen, trow0, qlen, f.off, RIDX, B, Lmax, s));
+    } else if (l0) {
         // X (and, off the table path, POS): the first layer's attention gathers q|k|v from the caches itself; with
         // the gather switched off a packing pass writes them out first
         RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, l0->qkv_vid, l0->qkv_txt,
@@ -362,8 +370,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (fuse_ffn && m->opt_ffn_fused >= 2) {
             // everything behind the attention in ONE launch: norm2(x1 + ffn(x1)), x1 = norm1(x + attn Wo^T + bo); a
             // workgroup reads its 128 rows of x before it writes them, and nobody else touches them: in place
-            RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, f.X, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b, e.l2.w,
-                                      e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s));
+            if (l == 0 && gather_res)
+                RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, vproj, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
+                                          e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s, RIDX, tproj));
+            else
+                RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, f.X, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
+                                          e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s));
             continue;
         }
         g = G(m, f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
@@ -667,6 +679,7 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
         m->opt_ffn_fused = value;
         return 0;
     }
+    if (!strcmp(name, "res_gather")) { m->opt_res_gather = value != 0; return 0; }
     if (!strcmp(name, "gemm")) {
         CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
         m->opt_gemm = value;

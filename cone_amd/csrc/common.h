@@ -105,7 +105,8 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
 int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
-                          const int* M_dev, int ff, hipStream_t s);
+                          const int* M_dev, int ff, hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
+// r_idx != null: residual row i is gathered -- r_idx[i] >= 0: row r_idx[i] of R, else row ~r_idx[i] of R2 (launch_row_index)
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
@@ -155,6 +156,8 @@ int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const
                     int Lmax, hipStream_t s);
 int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
 // X always; POS (sine rows) and QK / V (layer-0 q|k|v gathered from the caches) only when non-null
+int launch_row_index(const int* vrow0, const int* vlen, const int* trow0, const int* qlen, const int* off, int* ridx,
+                     int B, int Lmax, hipStream_t s);
 int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                    const int* qlen, const int* off, const float* dim_t, const float* qkv_vid, const float* qkv_txt,
                    const float* pos_qk, float* X, float* POS, float* QK, float* V, int B, int Lmax, hipStream_t s);

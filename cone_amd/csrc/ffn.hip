@@ -67,6 +67,8 @@ struct FfnArgs {
     // R (M, 256) residual; X is unused.
     const float* A; int lda; const float* R; int ldr;
     const float* Wo; const float* bo; const float* pg; const float* pb;
+    // r_idx != null: the residual rows are gathered: row i = R[r_idx[i]] (r_idx[i] >= 0) or R2[~r_idx[i]]
+    const int* r_idx; const float* R2;
 };
 
 // LayerNorm over a token's 256 channels held as v[16] (channel 16 t + 4 lg + r in v[t][r]): 4 lanes x 64 registers.
@@ -229,6 +231,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
         if (PROJ) {
             const float* ap = p.A + ld_row * p.lda + 4 * lg;
             const float* rp = p.R + ld_row * p.ldr + 4 * lg;
+            if (p.r_idx) {
+                const int ix = p.r_idx[ld_row];
+                rp = (ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr) + 4 * lg;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 ar[q] = *reinterpret_cast<const f32x4f*>(ap + 16 * q);
@@ -470,7 +476,8 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
 int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
-                          const int* M_dev, int ff, hipStream_t s) {
+                          const int* M_dev, int ff, hipStream_t s, const int* r_idx, const float* R2) {
+    CONE_REQUIRE(!r_idx || R2, "fused layer tail: a gathered residual needs both source matrices");
     CONE_REQUIRE(ffn_fused_supported(ff), "fused layer tail: dim_feedforward=%d unsupported", ff);
     CONE_REQUIRE(A && Wo && bo && R && pg && pb && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused layer tail: null argument");
     CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "fused layer tail: row strides must be multiples of 4");
@@ -478,7 +485,7 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
     FfnArgs a{};
     a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
-    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff; a.r_idx = r_idx; a.R2 = R2;
     return launch_ffn_t<true>(a, s);
 }
 

@@ -160,6 +160,27 @@ __global__ __launch_bounds__(256) void pack_l0_kernel(const float* __restrict__ 
     }
 }
 
+// Source row of every packed token (the residual stream entering the first encoder layer is a pure gather of the
+// projected clip / text rows): idx >= 0: vproj row idx; idx < 0: tproj row ~idx.  With it the fused layer tail reads its
+// residual rows from the per-clip / per-token matrices itself and the 2 GB packed copy is never written.
+__global__ __launch_bounds__(256) void row_index_kernel(const int* __restrict__ vrow0, const int* __restrict__ vlen,
+                                                        const int* __restrict__ trow0, const int* __restrict__ qlen,
+                                                        const int* __restrict__ off, int* __restrict__ ridx) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lv = vlen[b];
+    if (p >= lv + qlen[b]) return;
+    ridx[off[b] + p] = p < lv ? vrow0[b] + p : ~(trow0[b] + p - lv);
+}
+
+int launch_row_index(const int* vrow0, const int* vlen, const int* trow0, const int* qlen, const int* off, int* ridx,
+                     int B, int Lmax, hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(row_index_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, s, vrow0, vlen, trow0, qlen, off, ridx);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_pack_l0(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                    const int* qlen, const int* off, const float* dim_t, const float* qkv_vid, const float* qkv_txt,
                    const float* pos_qk, float* X, float* POS, float* QK, float* V, int B, int Lmax, hipStream_t s) {

@@ -321,6 +321,9 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  *   that keeps the (M, dim_feedforward) hidden rows on chip (ffn.hip); 2 = the attention output projection + residual +
  *   LayerNorm ahead of it in that kernel too (everything of a layer behind its attention: one launch, the layer's
  *   intermediate rows never leave the CU); 0 = GEMMs through (M, 256) / (M, ff) buffers.
+ * "res_gather" (default 1, with ffn_fused 2 + l0_gather + pos_tables): the first encoder layer's residual rows are read
+ *   by the fused layer tail straight from the projected clip / text rows through a row index; 0 = from a packed copy of
+ *   the layer input written by a packing pass.  Bit-identical.
  * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
  *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
  *   exact-fp32 fma chains per output element that walk k in different orders. */
