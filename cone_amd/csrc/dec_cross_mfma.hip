@@ -60,7 +60,6 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qkf = smem;                          // [3][16] slabs of [16 pairs][16 channels]; later ctx[48][260]
     float* Pt = smem + C::A_FLOATS;             // [KP][48]
-    float* qs = Pt;                             // [40][32] scaled queries (dead before Pt is written)
     float* smax = Pt + C::PT_FLOATS;            // [8][48]
     float* ssum = smax + 8 * C::NPP;            // [8][48]
     const int b = blockIdx.x;
@@ -98,40 +97,47 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
         for (int i = tid; i < C::QK_FLOATS / 4; i += 512)
             reinterpret_cast<g4v*>(qkf)[i] = reinterpret_cast<const g4v*>(QKS)[i];
     } else {
-    // ---- q * sqrt(1/32) into LDS as [pair = s*8+h][32]; rows 40 .. 47 of the last pair tile's slabs = 0
-    for (int i = tid; i < NQ * 256; i += 512) {
-        const int s = i >> 8, o = i & 255;
-        qs[(s * 8 + (o >> 5)) * 32 + (o & 31)] = DQ[(size_t)(b * NQ + s) * 256 + o] * 0.17677669529663687f;
-    }
+    // rows 40 .. 47 of the last pair tile's slabs = 0
     for (int i = tid; i < 16 * 8 * 16; i += 512) {          // (q, row 8 .. 15, 16 floats) of pair tile 2
         const int q = i >> 7, r = 8 + ((i >> 4) & 7), c = i & 15;
         qkf[(2 * 16 + q) * 256 + r * 16 + c] = 0.f;
     }
-    __syncthreads();
-
-    // ---- stage 0: qk[p][c] = sum_d qs[p][d] * Wk[h*32+d][c], thread = channel c (two thread groups split the heads);
-    // stored in slab (pair tile, c / 16), row pair % 16, physical chunk ((c / 4) % 4) ^ swz(row)
-    for (int h = 4 * half; h < 4 * half + 4; ++h) {
+    // ---- stage 0: qk[p][c] = sqrt(1/32) sum_d q[p][d] * Wk[h*32+d][c], thread = channel c (two thread groups split the
+    // heads); the window's query values are wave-uniform: they come through the scalar cache (s_load) straight into the
+    // FMAs' scalar operands -- no LDS staging, no LDS read per FMA pair.  Stored in slab (pair tile, c / 16), row
+    // pair % 16, physical chunk ((c / 4) % 4) ^ swz(row)
+    const float* __restrict__ qb = DQ + (size_t)b * NQ * 256;
+    const int h0 = __builtin_amdgcn_readfirstlane(4 * half);
+    for (int h = h0; h < h0 + 4; ++h) {
         g2v a[NQ];
 #pragma unroll
         for (int s = 0; s < NQ; ++s) a[s] = g2v{0.f, 0.f};
         const float* wcol = Wk + (size_t)h * 32 * 256 + col;
-#pragma unroll 4
-        for (int d4 = 0; d4 < 8; ++d4) {
-            const g2v w01 = {wcol[(d4 * 4 + 0) * 256], wcol[(d4 * 4 + 1) * 256]};
-            const g2v w23 = {wcol[(d4 * 4 + 2) * 256], wcol[(d4 * 4 + 3) * 256]};
+        // the head's 32 rows of W_k in four groups of 8, the next group requested ahead of this group's FMAs
+        float wn[8], wc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wn[i] = wcol[i * 256];
+#pragma unroll
+        for (int d8 = 0; d8 < 4; ++d8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wc[i] = wn[i];
+            if (d8 < 3) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wn[i] = wcol[((d8 + 1) * 8 + i) * 256];
+            }
 #pragma unroll
             for (int s = 0; s < NQ; ++s) {
-                const g4v q4 = *reinterpret_cast<const g4v*>(qs + (s * 8 + h) * 32 + d4 * 4);
-                a[s] = __builtin_elementwise_fma(q4.xy, w01, a[s]);
-                a[s] = __builtin_elementwise_fma(q4.zw, w23, a[s]);
+                const float* qp = qb + s * 256 + h * 32 + d8 * 8;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2)
+                    a[s] = __builtin_elementwise_fma(g2v{qp[i], qp[i + 1]}, g2v{wc[i], wc[i + 1]}, a[s]);
             }
         }
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
             const int p = s * 8 + h, row = p & 15;
             qkf[((p >> 4) * 16 + (col >> 4)) * 256 + row * 16 + ((((col >> 2) & 3) ^ dcm_swz16(row)) << 2) + (col & 3)] =
-                a[s].x + a[s].y;
+                (a[s].x + a[s].y) * 0.17677669529663687f;
         }
     }
     }
