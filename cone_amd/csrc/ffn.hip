@@ -147,13 +147,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
         const int gg = g < G ? g : g - G;
         // wave-uniform pointer + zero-extended 32-bit lane offset: the saddr + voffset form of global_load_lds (one
         // address VGPR for all pieces instead of a hoisted 64-bit VGPR pair per piece)
-        if (PROJ && gg < NP) {
-            const char* ub = reinterpret_cast<const char*>(p.Wo + ((size_t)gg * (32 * 256) + 16 * i));
-            FFN_GLDS16(ub + (unsigned)(poff * 4), dstp);
-        } else {
-            const char* ub = reinterpret_cast<const char*>(fbase + ((size_t)(gg - NP) * fchunk + (size_t)i * fpiece));
-            FFN_GLDS16(ub + (unsigned)(foff * 4), dstp);
-        }
+        // ONE scalar base (selected, not branched on) + ONE 32-bit lane offset; the empty asm pins the base in SGPRs at
+        // this point: hoisted out of the tile loop, base + lane offset becomes a 64-bit VGPR pair per piece, spilled,
+        // and every reload drains the DMA queue with a vmcnt(0)
+        const bool pj = PROJ && gg < NP;
+        const char* ub = reinterpret_cast<const char*>(
+            pj ? p.Wo + ((size_t)gg * (32 * 256) + 16 * i) : fbase + ((size_t)(gg - NP) * fchunk + (size_t)i * fpiece));
+        const unsigned vo = (unsigned)((pj ? poff : foff) * 4);
+        asm volatile("" : "+s"(ub));
+        FFN_GLDS16(ub + vo, dstp);
     };
 
     const int rd = li * 16 + ((lg ^ ffn_swz16(li)) << 2);          // this lane's 16-B chunk inside a slab
@@ -228,23 +230,29 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     auto load_tile = [&](int tile) {
         const int row = tile * FFN_ROWS + wave * 16 + li;
         const size_t ld_row = (size_t)(row < M ? row : M - 1);         // rows past M feed unstored outputs
-        if (PROJ) {
+        if (PROJ) {     // the attention rows; the residual rows follow at the top of the tile (load_res)
             const float* ap = p.A + ld_row * p.lda + 4 * lg;
-            const float* rp = p.R + ld_row * p.ldr + 4 * lg;
-            if (p.r_idx) {
-                const int ix = p.r_idx[ld_row];
-                rp = (ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr) + 4 * lg;
-            }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                ar[q] = *reinterpret_cast<const f32x4f*>(ap + 16 * q);
-                xr[q] = *reinterpret_cast<const f32x4f*>(rp + 16 * q);
-            }
+            for (int q = 0; q < 16; ++q) ar[q] = *reinterpret_cast<const f32x4f*>(ap + 16 * q);
         } else {
             const float* xp = p.X + ld_row * p.ldx + 4 * lg;
 #pragma unroll
             for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const f32x4f*>(xp + 16 * q);
         }
+    };
+    // PROJ: the residual rows of a tile are requested at its top and consumed at the end of each projection chunk (they
+    // land under the first chunk's MFMAs): at no point are the next tile's rows, this tile's outputs and both input
+    // tiles live together
+    auto load_res = [&](int tile) {
+        const int row = tile * FFN_ROWS + wave * 16 + li;
+        const size_t ld_row = (size_t)(row < M ? row : M - 1);
+        const float* rp = p.R + ld_row * p.ldr + 4 * lg;
+        if (p.r_idx) {
+            const int ix = p.r_idx[ld_row];
+            rp = (ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr) + 4 * lg;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const f32x4f*>(rp + 16 * q);
     };
     load_tile(blockIdx.x);
     bool first = true;
@@ -257,14 +265,15 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     }
 
     if (PROJ) {
+        load_res(tile);
         // ---- attention output projection + residual + LayerNorm: pair g computes channels [32 g, 32 g + 32) of
-        // A Wo^T into xr[2 g], xr[2 g + 1] (which start as residual + bias); fully unrolled: xr[] is indexed statically
+        // A Wo^T and adds them to xr[2 g], xr[2 g + 1] (the residual rows); fully unrolled: xr[] is indexed statically
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const float* st = FFN_STAGE_OF(g);
             f32x4f ha[2], hb[2];        // two partial chains per tile: with both tiles interleaved, four MFMAs apart
-            ha[0] = xr[2 * g]; hb[0] = xr[2 * g + 1];
-            ha[1] = f32x4f{0.f, 0.f, 0.f, 0.f}; hb[1] = ha[1];
+            ha[0] = f32x4f{0.f, 0.f, 0.f, 0.f}; hb[0] = ha[0];
+            ha[1] = ha[0]; hb[1] = ha[0];
             wa = FFN_RD(st, 0); wb = FFN_RD(st, 256); va = FFN_RD(st, 4096); vb = FFN_RD(st, 4096 + 256);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -289,8 +298,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
                 if (u & 1) stream_piece(g + 2, u >> 1);            // the next-but-one chunk's pieces ride behind MFMAs
                 if (u < 7) { wa = na; wb = nb; va = nva; vb = nvb; }
             }
-            xr[2 * g] = ha[0] + ha[1];
-            xr[2 * g + 1] = hb[0] + hb[1];
+            xr[2 * g] += ha[0] + ha[1];
+            xr[2 * g + 1] += hb[0] + hb[1];
             FFN_END_CHUNK()
         }
         FFN_SB();
