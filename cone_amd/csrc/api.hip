@@ -708,6 +708,16 @@ extern "C" int cone_test_proj_ffn(const float* A, const float* Wo, const float* 
     return launch_proj_ffn_fused(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
                                  (hipStream_t)stream);
 }
+extern "C" size_t cone_test_ffn_split_image_bytes(int ff) { return ffn_split_supported(ff) ? ffn_split_image_bytes(ff) : 0; }
+extern "C" int cone_test_ffn_split(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* img, int pack,
+                                   void* stream) {
+    if (pack) {
+        const int rc = launch_ffn_split_pack(W1, W2, ff, img, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_ffn_split(X, 256, img, b1, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff, (hipStream_t)stream);
+}
 extern "C" int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt,
                                   const float* pos_qk, const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0,
                                   const int32_t* off, float* OUT, int B, int Lmax, void* stream) {

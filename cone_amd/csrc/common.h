@@ -108,6 +108,16 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
                           const int* M_dev, int ff, hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
 // r_idx != null: residual row i is gathered -- r_idx[i] >= 0: row r_idx[i] of R, else row ~r_idx[i] of R2 (launch_row_index)
 
+// ---------------------------------------------------------------- the same on the bf16 matrix cores (ffn_split.hip)
+// fp32 products as six partial products of three-piece bf16 operands, fp32 accumulation: fp32-MFMA accuracy (measured),
+// 2.7x its rate.  Wimg = the layer's W1 / W2 split and laid out once by launch_ffn_split_pack
+// (ffn_split_image_bytes(ff) bytes).
+bool ffn_split_supported(int ff);
+size_t ffn_split_image_bytes(int ff);
+int launch_ffn_split_pack(const float* W1, const float* W2, int ff, void* img, hipStream_t s);
+int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1, const float* b2, const float* ln_g,
+                     const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s);
+
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
                      int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s);

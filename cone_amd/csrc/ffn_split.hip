@@ -1,0 +1,333 @@
+// Fused feed-forward block (ffn.hip's computation: out = LayerNorm(x + W2 relu(W1 x + b1) + b2)) with every fp32
+// product carried by the bf16 matrix cores as SIX partial products of three-piece operands:
+//     x = xh + xm + xl,  w = wh + wm + wl   (bf16 pieces: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): exact, 24 bits)
+//     x w ~= xl wh + xh wl + xm wm + xh wm + xm wh + xh wh        (the three dropped products are <= 2^-24 |x w|)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Measured on this part (tools/probe/split_bf16_probe.hip, K = 256 and
+// 1024, against float64): max |error| / sum |a b| = 1.5e-7 .. 2.4e-7, the exact-fp32 v_mfma_f32_16x16x4_f32 chain of
+// ffn.hip: 2.0e-7 .. 2.1e-7 -- the same accuracy, at 16 / 6 = 2.7x the matrix-core rate.  OPT-IN (cone_model_set_option
+// "split_bf16"): the default path stays on the fp32 MFMA.
+//
+// Orientation and operand maps are those of ffn.hip (a wave owns 16 token rows = the MFMA column index; accumulators feed
+// the next product without lane movement), on v_mfma_f32_16x16x32_bf16: lane (li = l % 16, lg = l / 16) holds
+// A[row li][k = 8 lg + j], B[k = 8 lg + j][col li], j = 0 .. 7, and D[row 4 lg + r][col li], r = 0 .. 3.  The k index is
+// permuted identically on both operands so that operands come out of the registers they already live in:
+//   GEMM1 (K = 256 channels, step s = 32 channels): k slot (lg, j) <-> channel 32 s + 16 (j / 4) + 4 lg + j % 4, i.e. the
+//          two float4 x[token][32 s + 4 lg ..] and x[token][32 s + 16 + 4 lg ..] -- which are also the accumulator
+//          layout of the output (channel 16 t + 4 lg + r), so the residual is rebuilt from the very same registers;
+//   GEMM2 (K = 32 hidden units of a chunk): k slot (lg, j) <-> unit 16 (j / 4) + 4 lg + j % 4 = accumulator register
+//          j % 4 of the chunk's GEMM1 tile j / 4.
+// Weights are static: they are split and laid out ONCE (cone_ffn_split_pack) in exactly the order the kernel reads them,
+// as 1-KiB operand slabs [lg][li][8 bf16] (a wave's ds_read_b128 of a slab is linear in the lane index: conflict-free),
+// 48 slabs = 48 KiB per ring slot: slot 2 c = W1 image of hidden chunk c ([tile 2][step 8][piece 3] slabs), slot
+// 2 c + 1 = W2 image ([channel tile 16][piece 3]).  The stream is linear, so a piece's LDS-DMA source is base + lane * 16.
+#include <mutex>
+
+#include "common.h"
+
+namespace cone {
+
+typedef float sp_f4 __attribute__((ext_vector_type(4)));
+typedef float sp_f2 __attribute__((ext_vector_type(2)));
+typedef short sp_s8 __attribute__((ext_vector_type(8)));
+typedef unsigned sp_u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sp_b2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_ROWS = 128;                       // token rows per workgroup (8 waves x 16)
+constexpr int SP_SLOT = 48 * 1024;                 // bytes per ring slot
+constexpr int SP_NSLOT = 3;
+constexpr int SP_NPIECE = 6;                       // 1-KiB LDS-DMA pieces per wave per slot (48 / 8)
+
+#define SP_GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// two floats -> packed bf16 pair (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned sp_pk(float a, float b) {
+    const sp_b2 v = __builtin_convertvector(sp_f2{a, b}, sp_b2);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float sp_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float sp_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// (a, b) -> the three packed piece pairs
+__device__ __forceinline__ void sp_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = sp_pk(a, b);
+    const float ra = a - sp_lo(h), rb = b - sp_hi(h);
+    m = sp_pk(ra, rb);
+    l = sp_pk(ra - sp_lo(m), rb - sp_hi(m));
+}
+// eight fp32 values (two float4) -> three 8-element bf16 operands
+__device__ __forceinline__ void sp_split8(const sp_f4& v0, const sp_f4& v1, sp_s8& h, sp_s8& m, sp_s8& l) {
+    unsigned a[4], b[4], c[4];
+    sp_split2(v0[0], v0[1], a[0], b[0], c[0]);
+    sp_split2(v0[2], v0[3], a[1], b[1], c[1]);
+    sp_split2(v1[0], v1[1], a[2], b[2], c[2]);
+    sp_split2(v1[2], v1[3], a[3], b[3], c[3]);
+    const sp_u4 uh = {a[0], a[1], a[2], a[3]}, um = {b[0], b[1], b[2], b[3]}, ul = {c[0], c[1], c[2], c[3]};
+    h = __builtin_bit_cast(sp_s8, uh); m = __builtin_bit_cast(sp_s8, um); l = __builtin_bit_cast(sp_s8, ul);
+}
+
+struct FfnSplitArgs {
+    const float* X; int ldx;                      // (M, 256) block input = residual
+    const void* Wimg;                             // packed weight image: 2 * (ff / 32) slots of 48 KiB
+    const float* b1; const float* b2;             // (ff), (256)
+    const float* ln_g; const float* ln_b;         // (256)
+    float* OUT; int ldo;
+    int M; const int* M_dev;
+    int ff;
+};
+
+#define SP_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+// the six partial products of one (weight fragment triple, activation triple), small terms first
+#define SP_MM6(acc, wh, wm, wl, xh, xm, xl) \
+    {                                        \
+        SP_MFMA(acc, wl, xh);                \
+        SP_MFMA(acc, wh, xl);                \
+        SP_MFMA(acc, wm, xm);                \
+        SP_MFMA(acc, wm, xh);                \
+        SP_MFMA(acc, wh, xm);                \
+        SP_MFMA(acc, wh, xh);                \
+    }
+
+__global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    float* b1s = reinterpret_cast<float*>(sp_smem + SP_NSLOT * SP_SLOT);
+    int M = p.M;
+    if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
+    const int n_tiles = (M + SP_ROWS - 1) / SP_ROWS;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int ff = p.ff, nc = ff >> 5;            // 32-unit hidden chunks
+    const int G = 2 * nc;                         // ring slots per tile
+
+    float* prm = b1s + ff;                        // b2, ln_g, ln_b
+    for (int i = tid; i < (ff >> 2); i += 512)
+        reinterpret_cast<sp_f4*>(b1s)[i] = reinterpret_cast<const sp_f4*>(p.b1)[i];
+    if (tid < 64) {
+        reinterpret_cast<sp_f4*>(prm)[tid] = reinterpret_cast<const sp_f4*>(p.b2)[tid];
+        reinterpret_cast<sp_f4*>(prm + 256)[tid] = reinterpret_cast<const sp_f4*>(p.ln_g)[tid];
+        reinterpret_cast<sp_f4*>(prm + 512)[tid] = reinterpret_cast<const sp_f4*>(p.ln_b)[tid];
+    }
+
+    // LDS-DMA: piece i of slot g (of the current tile; g >= G: the next tile's first slots, the same weights) = 1 KiB
+    // at image offset g * 48 KiB + (6 wave + i) KiB, lane * 16 B inside it; destination = the same offset in ring slot
+    // (sb + g) % 3.
+    int sb = 0;
+    const char* wimg = reinterpret_cast<const char*>(p.Wimg);
+    auto stream_piece = [&](int g, int i) {
+        const int gg = g < G ? g : g - G;
+        char* dstp = sp_smem + ((sb + g) % SP_NSLOT) * SP_SLOT + (wave * SP_NPIECE + i) * 1024;
+        const char* ub = wimg + ((size_t)gg * SP_SLOT + (size_t)(wave * SP_NPIECE + i) * 1024);
+        asm volatile("" : "+s"(ub));
+        SP_GLDS16(ub + (unsigned)(lane * 16), dstp);
+    };
+#define SP_SLOT_OF(g) (sp_smem + ((sb + (g)) % SP_NSLOT) * SP_SLOT)
+#define SP_RD(slot, slab) (*reinterpret_cast<const sp_s8*>((slot) + (slab) * 1024 + lane * 16))
+    // end of a slot: the next slot has landed (all but the pieces issued last, which belong to the slot after it), and
+    // every wave is done with the slot that the next pieces will overwrite
+#define SP_END_SLOT()                                                             \
+    {                                                                             \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_NPIECE) : "memory");          \
+        __builtin_amdgcn_s_barrier();                                             \
+    }
+
+#pragma unroll
+    for (int i = 0; i < SP_NPIECE; ++i) stream_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < SP_NPIECE; ++i) stream_piece(1, i);
+
+    bool first = true;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int my_row = tile * SP_ROWS + wave * 16 + li;
+    // the tile's rows, split once: xh / xm / xl [s] = B operand of GEMM1's step s (channels 32 s + 16 (j / 4) + 4 lg + j % 4)
+    sp_s8 xh[8], xm[8], xl[8];
+    {
+        const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
+        const float* xp = p.X + ld_row * p.ldx + 4 * lg;
+        sp_f4 xr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const sp_f4*>(xp + 16 * q);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sp_split8(xr[2 * s], xr[2 * s + 1], xh[s], xm[s], xl[s]);
+    }
+    if (first) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_NPIECE) : "memory");
+        __syncthreads();
+        first = false;
+    }
+    sp_f4 y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] = sp_f4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nc; ++c) {
+        // Both products walk 16 units of (3 fragments, 6 MFMAs); the fragments of unit u + 1 are requested ahead of the
+        // MFMAs of unit u (the empty asm is where the wait for them lands: after those MFMAs, before the next request).
+        // ---- GEMM1: the chunk's two 16-unit tiles over the 256 channels (slot 2 c: [tile][step][piece] slabs), tile by
+        // tile: bias + ReLU + split of tile 0 run under tile 1's MFMAs
+        const char* sa = SP_SLOT_OF(2 * c);
+        sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        sp_s8 wh = SP_RD(sa, 0), wm = SP_RD(sa, 1), wl = SP_RD(sa, 2), nh, nm, nl;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("" : "+v"(wh), "+v"(wm), "+v"(wl));
+            if (u < 15) { nh = SP_RD(sa, (u + 1) * 3 + 0); nm = SP_RD(sa, (u + 1) * 3 + 1); nl = SP_RD(sa, (u + 1) * 3 + 2); }
+            if (u < 8) { SP_MM6(a0, wh, wm, wl, xh[u & 7], xm[u & 7], xl[u & 7]) }
+            else { SP_MM6(a1, wh, wm, wl, xh[u & 7], xm[u & 7], xl[u & 7]) }
+            if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(2 * c + 2, u >> 1);
+            if (u < 15) { wh = nh; wm = nm; wl = nl; }
+        }
+        // bias + ReLU, split: the B operand of GEMM2 (k slot (lg, j) <-> unit 16 (j / 4) + 4 lg + j % 4)
+        sp_s8 hh, hm, hl;
+        {
+            const sp_f4 bb0 = *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 4 * lg);
+            const sp_f4 bb1 = *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 16 + 4 * lg);
+            a0 += bb0; a1 += bb1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
+            sp_split8(a0, a1, hh, hm, hl);
+        }
+        SP_END_SLOT()
+        // ---- GEMM2: all 256 output channels over the chunk's 32 hidden units (slot 2 c + 1: [channel tile][piece])
+        const char* sw = SP_SLOT_OF(2 * c + 1);
+        wh = SP_RD(sw, 0); wm = SP_RD(sw, 1); wl = SP_RD(sw, 2);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            asm volatile("" : "+v"(wh), "+v"(wm), "+v"(wl));
+            if (t < 15) { nh = SP_RD(sw, (t + 1) * 3 + 0); nm = SP_RD(sw, (t + 1) * 3 + 1); nl = SP_RD(sw, (t + 1) * 3 + 2); }
+            SP_MM6(y[t], wh, wm, wl, hh, hm, hl)
+            if ((t & 1) && (t >> 1) < SP_NPIECE) stream_piece(2 * c + 3, t >> 1);
+            if (t < 15) { wh = nh; wm = nm; wl = nl; }
+        }
+        SP_END_SLOT()
+    }
+    // ---- epilogue: + b2 + residual (x = xh + xm + xl exactly, in the accumulator layout), LayerNorm, store
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const sp_u4 uh = __builtin_bit_cast(sp_u4, xh[s]), um = __builtin_bit_cast(sp_u4, xm[s]), ul = __builtin_bit_cast(sp_u4, xl[s]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {           // pair e: elements 2 e, 2 e + 1 of the step = (tile 2 s + e / 2, r = 2 (e % 2) ..)
+            const float x0 = (sp_lo(uh[e]) + sp_lo(um[e])) + sp_lo(ul[e]);
+            const float x1 = (sp_hi(uh[e]) + sp_hi(um[e])) + sp_hi(ul[e]);
+            y[2 * s + (e >> 1)][2 * (e & 1)] += x0;
+            y[2 * s + (e >> 1)][2 * (e & 1) + 1] += x1;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] += *reinterpret_cast<const sp_f4*>(prm + 16 * t + 4 * lg);
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s1 += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / 256.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { y[t][r] -= mean; s2 = fmaf(y[t][r], y[t][r], s2); }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
+    if (my_row < M) {
+        float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const sp_f4 g = *reinterpret_cast<const sp_f4*>(prm + 256 + 16 * t + 4 * lg);
+            const sp_f4 be = *reinterpret_cast<const sp_f4*>(prm + 512 + 16 * t + 4 * lg);
+            sp_f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * g[r] + be[r];
+            *reinterpret_cast<sp_f4*>(op + 16 * t) = o;
+        }
+    }
+    sb = (sb + G) % SP_NSLOT;
+    }   // tile loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#undef SP_MM6
+#undef SP_MFMA
+#undef SP_END_SLOT
+#undef SP_RD
+#undef SP_SLOT_OF
+
+// three 48-KiB ring slots + b1 + three parameter rows within the CU's 160 KiB of LDS
+bool ffn_split_supported(int ff) { return ff >= 64 && ff % 32 == 0 && ff <= 2048; }
+size_t ffn_split_image_bytes(int ff) { return (size_t)2 * (ff / 32) * SP_SLOT; }
+
+int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1, const float* b2, const float* ln_g,
+                     const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s) {
+    CONE_REQUIRE(ffn_split_supported(ff), "split-bf16 fused FFN: dim_feedforward=%d unsupported", ff);
+    CONE_REQUIRE(X && Wimg && b1 && b2 && ln_g && ln_b && OUT, "split-bf16 fused FFN: null argument");
+    CONE_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "split-bf16 fused FFN: row strides must be multiples of 4");
+    if (M <= 0) return 0;
+    const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(ff + 3 * 256) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    static int n_cu = 0;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SP_NSLOT * SP_SLOT + (2048 + 3 * 256) * (int)sizeof(float));
+        int dev = 0;
+        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
+        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    CONE_CHECK_HIP(attr_rc);
+    FfnSplitArgs a{};
+    a.X = X; a.ldx = ldx; a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    const int tiles = (M + SP_ROWS - 1) / SP_ROWS;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    ProfScope ps(PK_FFN_FUSED, M, ff, 256, M_dev, s);
+    hipLaunchKernelGGL(ffn_split_kernel, dim3((unsigned)grid), dim3(512), lds, s, a);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- weight image (once per model): W1 (ff, 256), W2 (256, ff) fp32 -> 2 * (ff / 32) slots of 48 KiB.
+// One thread per 16-B fragment (8 bf16 of one piece): slot g, slab sl, lane l.
+__global__ __launch_bounds__(256) void ffn_split_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                             int ff, unsigned* __restrict__ img) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)2 * (ff / 32) * 48 * 64;
+    if (idx >= total) return;
+    const int l = (int)(idx & 63);
+    const int sl = (int)((idx >> 6) % 48);
+    const int g = (int)(idx / (48 * 64));
+    const int c = g >> 1, li = l & 15, lg = l >> 4;
+    float v[8];
+    int piece;
+    if ((g & 1) == 0) {     // W1 image: slab = tile * 24 + step * 3 + piece
+        const int t = sl / 24, s = (sl % 24) / 3;
+        piece = sl % 3;
+        const float* row = W1 + (size_t)(32 * c + 16 * t + li) * 256;
+        for (int j = 0; j < 8; ++j) v[j] = row[32 * s + 16 * (j >> 2) + 4 * lg + (j & 3)];
+    } else {                // W2 image: slab = channel tile * 3 + piece
+        const int t = sl / 3;
+        piece = sl % 3;
+        const float* row = W2 + (size_t)(16 * t + li) * ff + 32 * c;
+        for (int j = 0; j < 8; ++j) v[j] = row[16 * (j >> 2) + 4 * lg + (j & 3)];
+    }
+    unsigned out[4];
+    for (int e = 0; e < 4; ++e) {
+        unsigned h, m, lo;
+        sp_split2(v[2 * e], v[2 * e + 1], h, m, lo);
+        out[e] = piece == 0 ? h : (piece == 1 ? m : lo);
+    }
+    unsigned* dst = img + idx * 4;
+    dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+}
+
+int launch_ffn_split_pack(const float* W1, const float* W2, int ff, void* img, hipStream_t s) {
+    CONE_REQUIRE(ffn_split_supported(ff), "split-bf16 weight image: dim_feedforward=%d unsupported", ff);
+    CONE_REQUIRE(W1 && W2 && img, "split-bf16 weight image: null argument");
+    const size_t total = (size_t)2 * (ff / 32) * 48 * 64;
+    hipLaunchKernelGGL(ffn_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W1, W2, ff,
+                       reinterpret_cast<unsigned*>(img));
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cone

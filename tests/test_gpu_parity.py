@@ -1504,3 +1504,38 @@ def test_randomised_splits_against_oracle(preset, seed0):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "14", str(seed0), preset],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("M,ff", [(1, 1024), (16, 64), (127, 1024), (129, 1024), (1000, 2048), (300, 96), (70000, 1024)])
+def test_split_bf16_fused_ffn_matches_float64(M, ff):
+    """ffn_split.hip (opt-in): the feed-forward block with every fp32 product carried by the bf16 matrix cores as six
+    partial products of three-piece operands, fp32 accumulation -- against a float64 evaluation at the SAME tolerance as the
+    exact-fp32 kernel (test_fused_ffn_matches_float64), and not further from float64 than that kernel is."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(M * 31 + ff)
+    X = torch.randn(M, 256, generator=g) * 1.5
+    W1 = torch.randn(ff, 256, generator=g) / 16
+    b1 = torch.randn(ff, generator=g) * 0.2
+    W2 = torch.randn(256, ff, generator=g) / ff ** 0.5
+    b2 = torch.randn(256, generator=g) * 0.2
+    lg, lb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    h = (X.double() @ W1.double().t() + b1.double()).clamp(min=0)
+    ref = torch.nn.functional.layer_norm(X.double() + h @ W2.double().t() + b2.double(), (256,), lg.double(), lb.double(), 1e-5)
+    d = lambda t: t.to(dev).contiguous()
+    Xd, W1d, b1d, W2d, b2d, lgd, lbd = map(d, (X, W1, b1, W2, b2, lg, lb))
+    lib = _lib.load()
+    img = torch.empty(lib.cone_test_ffn_split_image_bytes(ff), dtype=torch.uint8, device=dev)
+    out = torch.full((M + 3, 256), float("nan"), device=dev)
+    _lib.check(lib.cone_test_ffn_split(_lib.ptr(Xd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d),
+                                       _lib.ptr(lgd), _lib.ptr(lbd), _lib.ptr(out), M, ff, _lib.ptr(img), 1, _lib.stream()))
+    torch.cuda.synchronize()
+    err_split = maxdiff(out[:M], ref)
+    assert err_split < 2e-5
+    assert bool(torch.isnan(out[M:]).all())
+    if ff % 16 == 0 and ff >= 32:
+        out32 = torch.empty(M, 256, device=dev)
+        _lib.check(lib.cone_test_ffn(_lib.ptr(Xd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d), _lib.ptr(lgd),
+                                     _lib.ptr(lbd), _lib.ptr(out32), M, ff, _lib.stream()))
+        torch.cuda.synchronize()
+        assert err_split <= 2.0 * maxdiff(out32, ref) + 1e-6, (err_split, maxdiff(out32, ref))

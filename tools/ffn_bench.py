@@ -40,6 +40,16 @@ def unfused():
                                   2 | 4, s))
 
 
+img = torch.empty(lib.cone_test_ffn_split_image_bytes(ff), dtype=torch.uint8, device=dev)
+out3 = torch.empty(M, 256, device=dev)
+_packed = [1]
+
+
+def fused_split():
+    _lib.check(lib.cone_test_ffn_split(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(out3), M, ff, P(img), _packed[0], s))
+    _packed[0] = 0
+
+
 A = torch.randn(M, 256, device=dev, generator=g)
 Wo = torch.randn(256, 256, device=dev, generator=g) / 16
 X1 = torch.empty(M, 256, device=dev)
@@ -59,6 +69,7 @@ def layer_unfused():
 
 flops = 4.0 * M * ff * 256
 for name, fn in (("fused", fused), ("two GEMMs", unfused), ("fused", fused), ("two GEMMs", unfused),
+                 ("fused bf16x3", fused_split), ("fused bf16x3", fused_split),
                  ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused), ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused)):
     if name == "proj+ffn":
         flops = 4.0 * M * ff * 256 + 2.0 * M * 256 * 256
@@ -74,3 +85,4 @@ for name, fn in (("fused", fused), ("two GEMMs", unfused), ("fused", fused), ("t
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:10s} M={M} ff={ff}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
 print("max |fused - two GEMMs| =", float((out - out2).abs().max()))
+print("max |fused bf16x3 - fused| =", float((out3 - out).abs().max()))
