@@ -718,6 +718,20 @@ extern "C" int cone_test_ffn_split(const float* X, const float* W1, const float*
     }
     return launch_ffn_split(X, 256, img, b1, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff, (hipStream_t)stream);
 }
+extern "C" size_t cone_test_proj_split_image_bytes(void) { return ffn_split_proj_image_bytes(); }
+extern "C" int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,
+                                        const float* pb, const float* W1, const float* b1, const float* W2,
+                                        const float* b2, const float* ln_g, const float* ln_b, float* OUT, int M, int ff,
+                                        void* img, void* wo_img, int pack, void* stream) {
+    if (pack) {
+        int rc = launch_ffn_split_pack(W1, W2, ff, img, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = launch_ffn_split_pack(Wo, nullptr, 256, wo_img, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_proj_ffn_split(A, 256, wo_img, bo, R, 256, pg, pb, img, b1, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
+                                 (hipStream_t)stream);
+}
 extern "C" int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt,
                                   const float* pos_qk, const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0,
                                   const int32_t* off, float* OUT, int B, int Lmax, void* stream) {

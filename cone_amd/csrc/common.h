@@ -117,6 +117,12 @@ size_t ffn_split_image_bytes(int ff);
 int launch_ffn_split_pack(const float* W1, const float* W2, int ff, void* img, hipStream_t s);
 int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1, const float* b2, const float* ln_g,
                      const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s);
+// launch_proj_ffn_fused's computation: Woimg = launch_ffn_split_pack(Wo, nullptr, 256, ...) (ffn_split_proj_image_bytes())
+size_t ffn_split_proj_image_bytes();
+int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,
+                          const float* pg, const float* pb, const void* Wimg, const float* b1, const float* b2,
+                          const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
+                          hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,

@@ -74,8 +74,13 @@ struct FfnSplitArgs {
     float* OUT; int ldo;
     int M; const int* M_dev;
     int ff;
+    // PROJ: the block input is LayerNorm(R + A Wo^T + bo), computed here (ffn.hip's PROJ form): A (M, 256) attention rows,
+    // R residual rows (r_idx != null: gathered, row i = R[r_idx[i]] or R2[~r_idx[i]]), Woimg = Wo's image (8 slots)
+    const float* A; int lda; const float* R; int ldr; const int* r_idx; const float* R2;
+    const void* Woimg; const float* bo; const float* pg; const float* pb;
 };
 
+#define SP_SB() __builtin_amdgcn_sched_barrier(0)
 #define SP_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
 // the six partial products of one (weight fragment triple, activation triple), small terms first
 #define SP_MM6(acc, wh, wm, wl, xh, xm, xl) \
@@ -88,6 +93,7 @@ struct FfnSplitArgs {
         SP_MFMA(acc, wh, xh);                \
     }
 
+template <bool PROJ>
 __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sp_smem[];
     float* b1s = reinterpret_cast<float*>(sp_smem + SP_NSLOT * SP_SLOT);
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int ff = p.ff, nc = ff >> 5;            // 32-unit hidden chunks
-    const int G = 2 * nc;                         // ring slots per tile
+    constexpr int NP = PROJ ? 8 : 0;              // leading slots of the output projection (32 channels each)
+    const int G = NP + 2 * nc;                    // ring slots per tile
 
     float* prm = b1s + ff;                        // b2, ln_g, ln_b
     for (int i = tid; i < (ff >> 2); i += 512)
@@ -108,6 +115,11 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
         reinterpret_cast<sp_f4*>(prm)[tid] = reinterpret_cast<const sp_f4*>(p.b2)[tid];
         reinterpret_cast<sp_f4*>(prm + 256)[tid] = reinterpret_cast<const sp_f4*>(p.ln_g)[tid];
         reinterpret_cast<sp_f4*>(prm + 512)[tid] = reinterpret_cast<const sp_f4*>(p.ln_b)[tid];
+        if (PROJ) {
+            reinterpret_cast<sp_f4*>(prm + 768)[tid] = reinterpret_cast<const sp_f4*>(p.bo)[tid];
+            reinterpret_cast<sp_f4*>(prm + 1024)[tid] = reinterpret_cast<const sp_f4*>(p.pg)[tid];
+            reinterpret_cast<sp_f4*>(prm + 1280)[tid] = reinterpret_cast<const sp_f4*>(p.pb)[tid];
+        }
     }
 
     // LDS-DMA: piece i of slot g (of the current tile; g >= G: the next tile's first slots, the same weights) = 1 KiB
@@ -115,10 +127,12 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     // (sb + g) % 3.
     int sb = 0;
     const char* wimg = reinterpret_cast<const char*>(p.Wimg);
+    const char* woimg = reinterpret_cast<const char*>(p.Woimg);
     auto stream_piece = [&](int g, int i) {
         const int gg = g < G ? g : g - G;
         char* dstp = sp_smem + ((sb + g) % SP_NSLOT) * SP_SLOT + (wave * SP_NPIECE + i) * 1024;
-        const char* ub = wimg + ((size_t)gg * SP_SLOT + (size_t)(wave * SP_NPIECE + i) * 1024);
+        const char* ub = (PROJ && gg < NP ? woimg + (size_t)gg * SP_SLOT : wimg + (size_t)(gg - NP) * SP_SLOT) +
+                         (size_t)(wave * SP_NPIECE + i) * 1024;
         asm volatile("" : "+s"(ub));
         SP_GLDS16(ub + (unsigned)(lane * 16), dstp);
     };
@@ -142,9 +156,9 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     const int my_row = tile * SP_ROWS + wave * 16 + li;
     // the tile's rows, split once: xh / xm / xl [s] = B operand of GEMM1's step s (channels 32 s + 16 (j / 4) + 4 lg + j % 4)
     sp_s8 xh[8], xm[8], xl[8];
-    {
-        const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
-        const float* xp = p.X + ld_row * p.ldx + 4 * lg;
+    const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
+    {   // PROJ: the attention rows (B operand of the projection), else the block input
+        const float* xp = (PROJ ? p.A + ld_row * p.lda : p.X + ld_row * p.ldx) + 4 * lg;
         sp_f4 xr[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const sp_f4*>(xp + 16 * q);
@@ -156,6 +170,69 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
         __syncthreads();
         first = false;
     }
+    sp_s8 f[2][3];                                  // ping-pong fragment sets (statically indexed: loops are unrolled)
+    if (PROJ) {
+        // ---- attention output projection: slot g = channels [32 g, 32 g + 32) of A Wo^T ([tile 2][step 8][piece 3])
+        sp_f4 x1[16];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const char* sa = SP_SLOT_OF(g);
+            sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            f[0][0] = SP_RD(sa, 0); f[0][1] = SP_RD(sa, 1); f[0][2] = SP_RD(sa, 2);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                SP_SB();
+                asm volatile("" : "+v"(f[u & 1][0]), "+v"(f[u & 1][1]), "+v"(f[u & 1][2]));
+                SP_SB();
+                if (u < 15) {
+                    f[(u + 1) & 1][0] = SP_RD(sa, (u + 1) * 3 + 0); f[(u + 1) & 1][1] = SP_RD(sa, (u + 1) * 3 + 1);
+                    f[(u + 1) & 1][2] = SP_RD(sa, (u + 1) * 3 + 2);
+                }
+                SP_SB();
+                if (u < 8) { SP_MM6(a0, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                else { SP_MM6(a1, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(g + 2, u >> 1);
+            }
+            SP_SB();
+            x1[2 * g] = a0; x1[2 * g + 1] = a1;
+            SP_END_SLOT()
+        }
+        // + bo + residual rows, LayerNorm: the block input, split for GEMM1 (the attention pieces are dead)
+        {
+            const float* rp = p.R + ld_row * p.ldr + 4 * lg;
+            if (p.r_idx) {
+                const int ix = p.r_idx[ld_row];
+                rp = (ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr) + 4 * lg;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                x1[q] += *reinterpret_cast<const sp_f4*>(rp + 16 * q) + *reinterpret_cast<const sp_f4*>(prm + 768 + 16 * q + 4 * lg);
+        }
+        float t1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) t1 += (x1[t][0] + x1[t][1]) + (x1[t][2] + x1[t][3]);
+        t1 += __shfl_xor(t1, 16, 64);
+        t1 += __shfl_xor(t1, 32, 64);
+        const float mu = t1 * (1.0f / 256.0f);
+        float t2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x1[t][r] -= mu; t2 = fmaf(x1[t][r], x1[t][r], t2); }
+        }
+        t2 += __shfl_xor(t2, 16, 64);
+        t2 += __shfl_xor(t2, 32, 64);
+        const float rs = 1.0f / sqrtf(t2 * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const sp_f4 g4 = *reinterpret_cast<const sp_f4*>(prm + 1024 + 16 * t + 4 * lg);
+            const sp_f4 b4 = *reinterpret_cast<const sp_f4*>(prm + 1280 + 16 * t + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x1[t][r] = x1[t][r] * rs * g4[r] + b4[r];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sp_split8(x1[2 * s], x1[2 * s + 1], xh[s], xm[s], xl[s]);
+    }
     sp_f4 y[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) y[t] = sp_f4{0.f, 0.f, 0.f, 0.f};
@@ -165,18 +242,24 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
         // MFMAs of unit u (the empty asm is where the wait for them lands: after those MFMAs, before the next request).
         // ---- GEMM1: the chunk's two 16-unit tiles over the 256 channels (slot 2 c: [tile][step][piece] slabs), tile by
         // tile: bias + ReLU + split of tile 0 run under tile 1's MFMAs
-        const char* sa = SP_SLOT_OF(2 * c);
+        const char* sa = SP_SLOT_OF(NP + 2 * c);
         sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        sp_s8 wh = SP_RD(sa, 0), wm = SP_RD(sa, 1), wl = SP_RD(sa, 2), nh, nm, nl;
+        f[0][0] = SP_RD(sa, 0); f[0][1] = SP_RD(sa, 1); f[0][2] = SP_RD(sa, 2);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            asm volatile("" : "+v"(wh), "+v"(wm), "+v"(wl));
-            if (u < 15) { nh = SP_RD(sa, (u + 1) * 3 + 0); nm = SP_RD(sa, (u + 1) * 3 + 1); nl = SP_RD(sa, (u + 1) * 3 + 2); }
-            if (u < 8) { SP_MM6(a0, wh, wm, wl, xh[u & 7], xm[u & 7], xl[u & 7]) }
-            else { SP_MM6(a1, wh, wm, wl, xh[u & 7], xm[u & 7], xl[u & 7]) }
-            if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(2 * c + 2, u >> 1);
-            if (u < 15) { wh = nh; wm = nm; wl = nl; }
+            SP_SB();
+            asm volatile("" : "+v"(f[u & 1][0]), "+v"(f[u & 1][1]), "+v"(f[u & 1][2]));
+            SP_SB();
+            if (u < 15) {
+                f[(u + 1) & 1][0] = SP_RD(sa, (u + 1) * 3 + 0); f[(u + 1) & 1][1] = SP_RD(sa, (u + 1) * 3 + 1);
+                f[(u + 1) & 1][2] = SP_RD(sa, (u + 1) * 3 + 2);
+            }
+            SP_SB();
+            if (u < 8) { SP_MM6(a0, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+            else { SP_MM6(a1, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+            if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(NP + 2 * c + 2, u >> 1);
         }
+        SP_SB();
         // bias + ReLU, split: the B operand of GEMM2 (k slot (lg, j) <-> unit 16 (j / 4) + 4 lg + j % 4)
         sp_s8 hh, hm, hl;
         {
@@ -189,16 +272,22 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
         }
         SP_END_SLOT()
         // ---- GEMM2: all 256 output channels over the chunk's 32 hidden units (slot 2 c + 1: [channel tile][piece])
-        const char* sw = SP_SLOT_OF(2 * c + 1);
-        wh = SP_RD(sw, 0); wm = SP_RD(sw, 1); wl = SP_RD(sw, 2);
+        const char* sw = SP_SLOT_OF(NP + 2 * c + 1);
+        f[0][0] = SP_RD(sw, 0); f[0][1] = SP_RD(sw, 1); f[0][2] = SP_RD(sw, 2);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            asm volatile("" : "+v"(wh), "+v"(wm), "+v"(wl));
-            if (t < 15) { nh = SP_RD(sw, (t + 1) * 3 + 0); nm = SP_RD(sw, (t + 1) * 3 + 1); nl = SP_RD(sw, (t + 1) * 3 + 2); }
-            SP_MM6(y[t], wh, wm, wl, hh, hm, hl)
-            if ((t & 1) && (t >> 1) < SP_NPIECE) stream_piece(2 * c + 3, t >> 1);
-            if (t < 15) { wh = nh; wm = nm; wl = nl; }
+            SP_SB();
+            asm volatile("" : "+v"(f[t & 1][0]), "+v"(f[t & 1][1]), "+v"(f[t & 1][2]));
+            SP_SB();
+            if (t < 15) {
+                f[(t + 1) & 1][0] = SP_RD(sw, (t + 1) * 3 + 0); f[(t + 1) & 1][1] = SP_RD(sw, (t + 1) * 3 + 1);
+                f[(t + 1) & 1][2] = SP_RD(sw, (t + 1) * 3 + 2);
+            }
+            SP_SB();
+            SP_MM6(y[t], f[t & 1][0], f[t & 1][1], f[t & 1][2], hh, hm, hl)
+            if ((t & 1) && (t >> 1) < SP_NPIECE) stream_piece(NP + 2 * c + 3, t >> 1);
         }
+        SP_SB();
         SP_END_SLOT()
     }
     // ---- epilogue: + b2 + residual (x = xh + xm + xl exactly, in the accumulator layout), LayerNorm, store
@@ -247,15 +336,39 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#undef SP_SB
 #undef SP_MM6
 #undef SP_MFMA
 #undef SP_END_SLOT
 #undef SP_RD
 #undef SP_SLOT_OF
 
-// three 48-KiB ring slots + b1 + three parameter rows within the CU's 160 KiB of LDS
+// three 48-KiB ring slots + b1 + six parameter rows within the CU's 160 KiB of LDS
 bool ffn_split_supported(int ff) { return ff >= 64 && ff % 32 == 0 && ff <= 2048; }
 size_t ffn_split_image_bytes(int ff) { return (size_t)2 * (ff / 32) * SP_SLOT; }
+size_t ffn_split_proj_image_bytes() { return (size_t)8 * SP_SLOT; }
+
+template <bool PROJ>
+static int launch_ffn_split_t(const FfnSplitArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(a.ff + 6 * 256) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    static int n_cu = 0;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SP_NSLOT * SP_SLOT + (2048 + 6 * 256) * (int)sizeof(float));
+        int dev = 0;
+        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
+        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    CONE_CHECK_HIP(attr_rc);
+    const int tiles = (a.M + SP_ROWS - 1) / SP_ROWS;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff, 256, a.M_dev, s);
+    hipLaunchKernelGGL(ffn_split_kernel<PROJ>, dim3((unsigned)grid), dim3(512), lds, s, a);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1, const float* b2, const float* ln_g,
                      const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s) {
@@ -263,48 +376,49 @@ int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1,
     CONE_REQUIRE(X && Wimg && b1 && b2 && ln_g && ln_b && OUT, "split-bf16 fused FFN: null argument");
     CONE_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "split-bf16 fused FFN: row strides must be multiples of 4");
     if (M <= 0) return 0;
-    const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(ff + 3 * 256) * sizeof(float);
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    static int n_cu = 0;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      SP_NSLOT * SP_SLOT + (2048 + 3 * 256) * (int)sizeof(float));
-        int dev = 0;
-        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
-        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    });
-    CONE_CHECK_HIP(attr_rc);
     FfnSplitArgs a{};
     a.X = X; a.ldx = ldx; a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
-    const int tiles = (M + SP_ROWS - 1) / SP_ROWS;
-    const int grid = tiles < n_cu ? tiles : n_cu;
-    ProfScope ps(PK_FFN_FUSED, M, ff, 256, M_dev, s);
-    hipLaunchKernelGGL(ffn_split_kernel, dim3((unsigned)grid), dim3(512), lds, s, a);
-    CONE_LAUNCH_CHECK();
-    return 0;
+    return launch_ffn_split_t<false>(a, s);
 }
 
-// ---- weight image (once per model): W1 (ff, 256), W2 (256, ff) fp32 -> 2 * (ff / 32) slots of 48 KiB.
-// One thread per 16-B fragment (8 bf16 of one piece): slot g, slab sl, lane l.
+int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,
+                          const float* pg, const float* pb, const void* Wimg, const float* b1, const float* b2,
+                          const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
+                          hipStream_t s, const int* r_idx, const float* R2) {
+    CONE_REQUIRE(ffn_split_supported(ff), "split-bf16 fused layer tail: dim_feedforward=%d unsupported", ff);
+    CONE_REQUIRE(A && Woimg && bo && R && pg && pb && Wimg && b1 && b2 && ln_g && ln_b && OUT, "split-bf16 fused layer tail: null argument");
+    CONE_REQUIRE(!r_idx || R2, "split-bf16 fused layer tail: a gathered residual needs both source matrices");
+    CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "split-bf16 fused layer tail: row strides must be multiples of 4");
+    if (M <= 0) return 0;
+    FfnSplitArgs a{};
+    a.A = A; a.lda = lda; a.Woimg = Woimg; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb; a.r_idx = r_idx; a.R2 = R2;
+    a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    return launch_ffn_split_t<true>(a, s);
+}
+
+// ---- weight images (once per model).  One thread per 16-B fragment (8 bf16 of one piece): slot g, slab sl, lane l.
+// W2 != null: W1 (ff, 256) and W2 (256, ff) -> 2 * (ff / 32) slots (slot 2 c: W1 rows of hidden chunk c, slot 2 c + 1: W2
+// columns).  W2 == null: W1 is any (N = ff, 256) weight of a 256-channel product (the attention output projection): N / 32
+// slots in the W1 slab order.
 __global__ __launch_bounds__(256) void ffn_split_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
                                                              int ff, unsigned* __restrict__ img) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)2 * (ff / 32) * 48 * 64;
+    const size_t total = (size_t)(W2 ? 2 : 1) * (ff / 32) * 48 * 64;
     if (idx >= total) return;
     const int l = (int)(idx & 63);
     const int sl = (int)((idx >> 6) % 48);
     const int g = (int)(idx / (48 * 64));
-    const int c = g >> 1, li = l & 15, lg = l >> 4;
+    const int c = W2 ? g >> 1 : g, li = l & 15, lg = l >> 4;
     float v[8];
     int piece;
-    if ((g & 1) == 0) {     // W1 image: slab = tile * 24 + step * 3 + piece
+    if (!W2 || (g & 1) == 0) {      // W1 image: slab = tile * 24 + step * 3 + piece
         const int t = sl / 24, s = (sl % 24) / 3;
         piece = sl % 3;
         const float* row = W1 + (size_t)(32 * c + 16 * t + li) * 256;
         for (int j = 0; j < 8; ++j) v[j] = row[32 * s + 16 * (j >> 2) + 4 * lg + (j & 3)];
-    } else {                // W2 image: slab = channel tile * 3 + piece
+    } else {                        // W2 image: slab = channel tile * 3 + piece
         const int t = sl / 3;
         piece = sl % 3;
         const float* row = W2 + (size_t)(16 * t + li) * ff + 32 * c;
@@ -321,9 +435,9 @@ __global__ __launch_bounds__(256) void ffn_split_pack_kernel(const float* __rest
 }
 
 int launch_ffn_split_pack(const float* W1, const float* W2, int ff, void* img, hipStream_t s) {
-    CONE_REQUIRE(ffn_split_supported(ff), "split-bf16 weight image: dim_feedforward=%d unsupported", ff);
-    CONE_REQUIRE(W1 && W2 && img, "split-bf16 weight image: null argument");
-    const size_t total = (size_t)2 * (ff / 32) * 48 * 64;
+    CONE_REQUIRE(W2 ? ffn_split_supported(ff) : (ff >= 32 && ff % 32 == 0), "split-bf16 weight image: %d rows unsupported", ff);
+    CONE_REQUIRE(W1 && img, "split-bf16 weight image: null argument");
+    const size_t total = (size_t)(W2 ? 2 : 1) * (ff / 32) * 48 * 64;
     hipLaunchKernelGGL(ffn_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W1, W2, ff,
                        reinterpret_cast<unsigned*>(img));
     CONE_LAUNCH_CHECK();

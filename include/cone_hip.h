@@ -348,6 +348,12 @@ int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const f
 size_t cone_test_ffn_split_image_bytes(int ff);
 int cone_test_ffn_split(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* img, int pack, void* stream);
+/* cone_test_proj_ffn on the bf16 matrix cores; wo_img = scratch of cone_test_proj_split_image_bytes() bytes. */
+size_t cone_test_proj_split_image_bytes(void);
+int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,
+                             const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* img, void* wo_img,
+                             int pack, void* stream);
 /* Encoder self-attention core (cone/transformer.py:239, 8 heads x 32) over windows of packed tokens off[b] .. off[b+1]:
  * mode 0: QKV (M, 768) = q | k | v rows that already carry the position term; mode 2: the same without it, the kernel adds
  * pos_qk[(vlen[b], p)] (R, 512) to q | k of clip token p; mode 1: q | k | v gathered from per-clip rows qkv_vid[vrow0[b] + p]

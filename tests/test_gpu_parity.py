@@ -1533,9 +1533,27 @@ def test_split_bf16_fused_ffn_matches_float64(M, ff):
     err_split = maxdiff(out[:M], ref)
     assert err_split < 2e-5
     assert bool(torch.isnan(out[M:]).all())
-    if ff % 16 == 0 and ff >= 32:
-        out32 = torch.empty(M, 256, device=dev)
-        _lib.check(lib.cone_test_ffn(_lib.ptr(Xd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d), _lib.ptr(lgd),
-                                     _lib.ptr(lbd), _lib.ptr(out32), M, ff, _lib.stream()))
-        torch.cuda.synchronize()
-        assert err_split <= 2.0 * maxdiff(out32, ref) + 1e-6, (err_split, maxdiff(out32, ref))
+    out32 = torch.empty(M, 256, device=dev)
+    _lib.check(lib.cone_test_ffn(_lib.ptr(Xd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d), _lib.ptr(lgd),
+                                 _lib.ptr(lbd), _lib.ptr(out32), M, ff, _lib.stream()))
+    torch.cuda.synchronize()
+    assert err_split <= 2.0 * maxdiff(out32, ref) + 1e-6, (err_split, maxdiff(out32, ref))
+    # with the attention output projection + residual + LayerNorm computed in the kernel as well, in place over R
+    A = torch.randn(M, 256, generator=g)
+    Wo = torch.randn(256, 256, generator=g) / 16
+    bo = torch.randn(256, generator=g) * 0.2
+    pg, pb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.3
+    x1 = torch.nn.functional.layer_norm(X.double() + A.double() @ Wo.double().t() + bo.double(), (256,), pg.double(), pb.double(), 1e-5)
+    h = (x1 @ W1.double().t() + b1.double()).clamp(min=0)
+    ref = torch.nn.functional.layer_norm(x1 + h @ W2.double().t() + b2.double(), (256,), lg.double(), lb.double(), 1e-5)
+    Ad, Wod, bod, pgd, pbd = map(d, (A, Wo, bo, pg, pb))
+    R = torch.full((M + 3, 256), float("nan"), device=dev)
+    R[:M] = Xd
+    wo_img = torch.empty(lib.cone_test_proj_split_image_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(lib.cone_test_proj_ffn_split(_lib.ptr(Ad), _lib.ptr(Wod), _lib.ptr(bod), _lib.ptr(R), _lib.ptr(pgd),
+                                            _lib.ptr(pbd), _lib.ptr(W1d), _lib.ptr(b1d), _lib.ptr(W2d), _lib.ptr(b2d),
+                                            _lib.ptr(lgd), _lib.ptr(lbd), _lib.ptr(R), M, ff, _lib.ptr(img), _lib.ptr(wo_img),
+                                            1, _lib.stream()))
+    torch.cuda.synchronize()
+    assert maxdiff(R[:M], ref) < 3e-5
+    assert bool(torch.isnan(R[M:]).all())

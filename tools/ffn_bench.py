@@ -60,6 +60,16 @@ def layer_fused():
                                       P(out), M, ff, s))
 
 
+wo_img = torch.empty(lib.cone_test_proj_split_image_bytes(), dtype=torch.uint8, device=dev)
+_packed2 = [1]
+
+
+def layer_split():
+    _lib.check(lib.cone_test_proj_ffn_split(P(A), P(Wo), P(b2), P(X), P(lg), P(lb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
+                                            P(out3), M, ff, P(img), P(wo_img), _packed2[0], s))
+    _packed2[0] = 0
+
+
 def layer_unfused():
     _lib.check(lib.cone_test_gemm(P(A), None, 0, P(Wo), P(b2), P(X), P(lg), P(lb), P(X1), None, None, M, 256, 256, 2 | 4, s))
     _lib.check(lib.cone_test_gemm(P(X1), None, 0, P(W1), P(b1), None, None, None, P(H), None, None, M, ff, 256, 1, s))
@@ -70,8 +80,9 @@ def layer_unfused():
 flops = 4.0 * M * ff * 256
 for name, fn in (("fused", fused), ("two GEMMs", unfused), ("fused", fused), ("two GEMMs", unfused),
                  ("fused bf16x3", fused_split), ("fused bf16x3", fused_split),
-                 ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused), ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused)):
-    if name == "proj+ffn":
+                 ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused), ("proj+ffn", layer_fused), ("3 GEMMs", layer_unfused),
+                 ("proj+ffn bf16x3", layer_split), ("proj+ffn bf16x3", layer_split)):
+    if name.startswith("proj+ffn"):
         flops = 4.0 * M * ff * 256 + 2.0 * M * 256 * 256
     for _ in range(2):
         fn()
@@ -85,4 +96,4 @@ for name, fn in (("fused", fused), ("two GEMMs", unfused), ("fused", fused), ("t
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:10s} M={M} ff={ff}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
 print("max |fused - two GEMMs| =", float((out - out2).abs().max()))
-print("max |fused bf16x3 - fused| =", float((out3 - out).abs().max()))
+print("max |proj+ffn bf16x3 - proj+ffn| =", float((out3 - out).abs().max()))
