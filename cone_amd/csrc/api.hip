@@ -50,6 +50,12 @@ struct cone_model {
     int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
     int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
     int opt_gemm = 0;         // GEMM tile family forced for every dense layer (GEMM_AUTO = by shape)
+    // derived (d = 256, ff % 32 == 0): the layer tails' weights split into bf16 pieces and laid out for ffn_split.hip
+    char* split_img = nullptr;                          // one allocation: per layer [Wo image | FFN image]
+    const void* enc_wo_img[CONE_MAX_LAYERS] = {}; const void* enc_ffn_img[CONE_MAX_LAYERS] = {};
+    const void* dec_wo_img[CONE_MAX_LAYERS] = {}; const void* dec_ffn_img[CONE_MAX_LAYERS] = {};
+    int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
+                              // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
     int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
     int opt_ffn_fused = 2;    // 1: linear1 + ReLU + linear2 + residual + LayerNorm as one kernel (ffn.hip); 2: the attention
                               // output projection + residual + LayerNorm ahead of it in the same kernel as well; 0: GEMMs
@@ -192,6 +198,31 @@ static int build_model(const cone_weights* w, cone_model** out) {
                 return CONE_E_HIP;
             }
             m->dec_vT[i] = dst;
+        }
+    }
+    if (d == 256 && ffn_split_supported(m->ff)) {   // split-bf16 images of every layer tail (13 MB at ff = 1024; opt-in path)
+        const size_t per = ffn_split_proj_image_bytes() + ffn_split_image_bytes(m->ff);
+        e = hipMalloc((void**)&m->split_img, per * (size_t)(m->n_enc + m->n_dec));
+        char* ip = m->split_img;
+        int rc = 0;
+        for (int i = 0; i < m->n_enc + m->n_dec && e == hipSuccess && rc == 0; ++i) {
+            const bool enc = i < m->n_enc;
+            const int l = enc ? i : i - m->n_enc;
+            const float* wo = enc ? m->enc[l].sa.out.w : m->dec[l].ca.out.w;
+            const Linear& l1 = enc ? m->enc[l].l1 : m->dec[l].l1;
+            const Linear& l2 = enc ? m->enc[l].l2 : m->dec[l].l2;
+            rc = launch_ffn_split_pack(wo, nullptr, 256, ip, nullptr);
+            if (rc == 0) rc = launch_ffn_split_pack(l1.w, l2.w, m->ff, ip + ffn_split_proj_image_bytes(), nullptr);
+            (enc ? m->enc_wo_img : m->dec_wo_img)[l] = ip;
+            (enc ? m->enc_ffn_img : m->dec_ffn_img)[l] = ip + ffn_split_proj_image_bytes();
+            ip += per;
+        }
+        if (e != hipSuccess || rc != 0 || hipDeviceSynchronize() != hipSuccess) {
+            if (m->split_img) (void)hipFree(m->split_img);
+            (void)hipFree(m->arena);
+            delete m;
+            if (rc == 0) set_error("model_create: building the split-bf16 weight images failed");
+            return CONE_E_HIP;
         }
     }
     *out = m;
@@ -370,7 +401,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (fuse_ffn && m->opt_ffn_fused >= 2) {
             // everything behind the attention in ONE launch: norm2(x1 + ffn(x1)), x1 = norm1(x + attn Wo^T + bo); a
             // workgroup reads its 128 rows of x before it writes them, and nobody else touches them: in place
-            if (l == 0 && gather_res)
+            const bool g0 = l == 0 && gather_res;
+            if (m->opt_split_bf16 && m->split_img)
+                RUN(launch_proj_ffn_split(f.ATT, 256, m->enc_wo_img[l], e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b,
+                                          m->enc_ffn_img[l], e.l1.b, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s,
+                                          g0 ? RIDX : nullptr, g0 ? tproj : nullptr));
+            else if (g0)
                 RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, vproj, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
                                           e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s, RIDX, tproj));
             else
@@ -435,7 +471,10 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         else
             RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
                                   m->nq, Lmax, s));
-        if (m->opt_ffn_fused >= 2 && ffn_fused_supported(ff)) {
+        if (m->opt_ffn_fused >= 2 && m->opt_split_bf16 && m->split_img) {
+            RUN(launch_proj_ffn_split(f.DATT, 256, m->dec_wo_img[l], dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b,
+                                      m->dec_ffn_img[l], dl.l1.b, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
+        } else if (m->opt_ffn_fused >= 2 && ffn_fused_supported(ff)) {
             RUN(launch_proj_ffn_fused(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b, dl.l1.w, dl.l1.b,
                                       dl.l2.w, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
         } else {
@@ -502,6 +541,7 @@ extern "C" int cone_model_create(const cone_weights* w, cone_model** out) { retu
 extern "C" void cone_model_destroy(cone_model* m) {
     if (!m) return;
     if (m->arena) (void)hipFree(m->arena);
+    if (m->split_img) (void)hipFree(m->split_img);
     delete m;
 }
 
@@ -677,6 +717,11 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
     if (!strcmp(name, "ffn_fused")) {
         CONE_REQUIRE(value >= 0 && value <= 2, "set_option: ffn_fused %d not in [0, 2]", value);
         m->opt_ffn_fused = value;
+        return 0;
+    }
+    if (!strcmp(name, "split_bf16")) {
+        CONE_REQUIRE(value == 0 || m->split_img, "set_option: split_bf16 needs hidden_dim 256 and dim_feedforward %% 32 == 0 (<= 2048)");
+        m->opt_split_bf16 = value != 0;
         return 0;
     }
     if (!strcmp(name, "res_gather")) { m->opt_res_gather = value != 0; return 0; }

@@ -321,6 +321,10 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  *   that keeps the (M, dim_feedforward) hidden rows on chip (ffn.hip); 2 = the attention output projection + residual +
  *   LayerNorm ahead of it in that kernel too (everything of a layer behind its attention: one launch, the layer's
  *   intermediate rows never leave the CU); 0 = GEMMs through (M, 256) / (M, ff) buffers.
+ * "split_bf16" (default 0, OPT-IN): every transformer layer's tail (ffn_fused 2) on the bf16 matrix cores -- each fp32
+ *   product as six partial products of three-piece bf16 operands (x = xh + xm + xl exactly), fp32 accumulation
+ *   (ffn_split.hip).  Measured against float64: the same error as the exact-fp32 MFMA chain (1.5e-7 .. 2.4e-7 of
+ *   sum |a b| vs 2.0e-7 .. 2.1e-7), at 1.65x its speed.  The default stays exact fp32.
  * "res_gather" (default 1, with ffn_fused 2 + l0_gather + pos_tables): the first encoder layer's residual rows are read
  *   by the fused layer tail straight from the projected clip / text rows through a row index; 0 = from a packed copy of
  *   the layer input written by a packing pass.  Bit-identical.

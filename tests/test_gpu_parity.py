@@ -182,11 +182,25 @@ def _safe_proposals(pred_spans, lens_v, margin=1e-3):
     return ~(near(x1) | near(x2))
 
 
+@pytest.fixture
+def split_bf16(request):
+    """Opt-in layer tails on the bf16 matrix cores (three-piece operands, fp32 accumulation) for the models of the test;
+    restored to the exact-fp32 default afterwards."""
+    on = getattr(request, "param", 0)
+    yield on
+    for m, _, _ in _MODELS.values():
+        m.set_option("split_bf16", 0)
+
+
+@pytest.mark.parametrize("split_bf16", [0, 1], indirect=True)
 @pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad"])
-def test_stage_b_matches_reference_golden(golden_dir, name):
+def test_stage_b_matches_reference_golden(golden_dir, name, split_bf16):
+    """split_bf16 = 1: the same reference fixtures at the same tolerance with every layer tail computed as six bf16
+    partial products per fp32 product (ffn_split.hip)."""
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     preset = str(fx["preset"])
     model, opt, _ = get_model(preset, int(fx["weight_seed"]))
+    model.set_option("split_bf16", split_bf16)
     lens_v, lens_q = fx["lens_v"].tolist(), fx["lens_q"].tolist()
     inp = gi.stage_b_inputs(opt, int(fx["input_seed"]), lens_v, lens_q)
     assert gi.checksum(inp["src_vid"], inp["src_txt"], inp["src_cls_txt"]) == str(fx["input_checksum"])
@@ -302,11 +316,15 @@ def test_position_tables_equal_materialised_pos_path(preset):
         model.set_option("dec_fold", 2)
         model.set_option("res_gather", 0)        # first layer's residual from a packed copy instead of the row index
         outs.append(inf.run_windows(model, store, opt, wt))
+        model.set_option("res_gather", 1)
+        model.set_option("split_bf16", 1)        # layer tails as six bf16 partial products per fp32 product
+        outs.append(inf.run_windows(model, store, opt, wt))
     finally:
         model.set_option("pos_tables", 1)
         model.set_option("ffn_fused", 2)
         model.set_option("dec_fold", 2)
         model.set_option("res_gather", 1)
+        model.set_option("split_bf16", 0)
     assert int((wt["vid_len"] < opt.max_v_l).sum()) > 0          # ragged windows are in the batch
     for k in ("pred_logits", "pred_spans", "saliency_scores"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < 5e-5, k
@@ -314,6 +332,7 @@ def test_position_tables_equal_materialised_pos_path(preset):
         assert maxdiff(outs[0][k], outs[3][k].cpu()) < 5e-5, ("ffn_fused 1", k)
         assert maxdiff(outs[0][k], outs[4][k].cpu()) < 5e-5, ("dec_fold 1", k)
         assert torch.equal(outs[0][k], outs[5][k]), ("res_gather 0", k)         # the same rows, read from another place
+        assert maxdiff(outs[0][k], outs[6][k].cpu()) < 5e-5, ("split_bf16", k)
     safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
     d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
     assert float(d[safe].max()) < 5e-5
@@ -548,13 +567,15 @@ def test_matcher_cost_matches_reference_golden(golden_dir):
 
 
 # ------------------------------------------------------------------------------- end to end
-@pytest.mark.parametrize("name", ["e2e_ego4d", "e2e_ego4d_small_bsz", "e2e_mad"])
-def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path):
+@pytest.mark.parametrize("name,split_bf16", [("e2e_ego4d", 0), ("e2e_ego4d_small_bsz", 0), ("e2e_mad", 0), ("e2e_ego4d", 1),
+                                             ("e2e_mad", 1)], indirect=["split_bf16"])
+def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path, split_bf16):
     from cone_amd import inference as inf
     with open(os.path.join(golden_dir, name + ".json")) as f:
         fx = json.load(f)
     preset = fx["preset"]
     model, _, _ = get_model(preset, fx["weight_seed"])
+    model.set_option("split_bf16", split_bf16)
     opt = make_opt(preset, nms_thd=0.5, eval_split_name="test", save_all=True, results_dir=str(tmp_path),
                    **fx["opt"])
     ann, vf, qf = synth.make_dataset(opt, fx["n_queries"], fx["n_videos"], seed=fx["data_seed"],
