@@ -360,6 +360,28 @@ def main():
     dt, rec, (out, dp) = timed_region(step)
     n_windows = dp["n_windows"]
 
+    split = None
+    if world == 1 and not args.no_extras and not any(kv.startswith("split_bf16") for kv in args.set_option):
+        # OPT-IN path, reported beside the headline (which stays exact fp32): every layer tail on the bf16 matrix cores,
+        # each fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation (ffn_split.hip)
+        try:
+            ref_out = {k: v.clone() for k, v in dp["outputs"].items() if k in ("pred_logits", "pred_spans")}
+            model.set_option("split_bf16", 1)
+            sdt, srec, (_, sdp) = timed_region(step)
+            sroof, _ = roofline_from_profile(srec)
+            split = {"note": "opt-in model option split_bf16=1 (NOT the headline): fp32 products of the fused layer tails as "
+                             "six bf16 MFMA partial products of three-piece operands (x = xh + xm + xl exactly), fp32 "
+                             "accumulation; error against float64 equal to the fp32 MFMA chain's (tools/probe/"
+                             "split_bf16_probe.hip, tests); same reference fixtures, same tolerances",
+                     "ms_per_step": round(sdt / args.steps * 1e3, 2),
+                     "value": round(sdp["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
+                     "queries_per_s": round(args.queries * args.steps / sdt, 1),
+                     "layer_tail_tflops_fp32_equivalent": sroof["achieved"] if sroof else None,
+                     "max_abs_diff_vs_default": {k: float((sdp["outputs"][k] - v).abs().max()) for k, v in ref_out.items()}}
+            del ref_out, sdp
+        finally:
+            model.set_option("split_bf16", 0)
+
     strong = None
     if use_dist and world > 1:
         # BASELINE configs[3]: ONE config-2 split (the same on every rank: features replicated), sharded by window
@@ -403,6 +425,8 @@ def main():
         }
         if strong is not None:
             res["strong_scaling"] = strong
+        if split is not None:
+            res["split_bf16x3"] = split
         wt = dp.get("windows")
         if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
             fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),

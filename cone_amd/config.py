@@ -18,7 +18,7 @@ from types import SimpleNamespace
 CLI_WINS = ("eval_path", "eval_split_name", "results_root", "num_workers", "nms_thd",
             "debug", "save_all", "max_before_nms", "max_after_nms", "max_pred_l",
             "min_pred_l", "eval_bsz", "data_ratio", "topk_window", "resume",
-            "resume_all", "no_sort_results", "packed_features")
+            "resume_all", "no_sort_results", "packed_features", "split_bf16")
 
 MODEL_DEFAULTS = dict(
     hidden_dim=256, nheads=8, dim_feedforward=1024, enc_layers=2, dec_layers=2,
@@ -75,6 +75,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--packed_features", type=str, default=None,
                    help="(cone_amd extension) packed feature arena written by `python -m cone_amd.pack_features`; "
                         "replaces the LMDB readers")
+    p.add_argument("--split_bf16", action="store_true",
+                   help="(cone_amd extension, opt-in) transformer layer tails on the bf16 matrix cores: every fp32 product as "
+                        "six partial products of three-piece bf16 operands, fp32 accumulation -- fp32-MFMA accuracy "
+                        "(measured against float64), ~1.3x the step rate; the default computes them on the fp32 MFMA")
     p.add_argument("--no_norm_vfeat", action="store_true")
     p.add_argument("--no_norm_tfeat", action="store_true")
     p.add_argument("--motion_feat_dir", type=str)

@@ -53,6 +53,7 @@ struct cone_model {
     // derived (d = 256, ff % 32 == 0): the layer tails' weights split into bf16 pieces and laid out for ffn_split.hip
     char* split_img = nullptr;                          // one allocation: per layer [Wo image | FFN image]
     const void* enc_wo_img[CONE_MAX_LAYERS] = {}; const void* enc_ffn_img[CONE_MAX_LAYERS] = {};
+    const void* enc_qkv_img[CONE_MAX_LAYERS] = {};
     const void* dec_wo_img[CONE_MAX_LAYERS] = {}; const void* dec_ffn_img[CONE_MAX_LAYERS] = {};
     int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
                               // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
@@ -202,9 +203,15 @@ static int build_model(const cone_weights* w, cone_model** out) {
     }
     if (d == 256 && ffn_split_supported(m->ff)) {   // split-bf16 images of every layer tail (13 MB at ff = 1024; opt-in path)
         const size_t per = ffn_split_proj_image_bytes() + ffn_split_image_bytes(m->ff);
-        e = hipMalloc((void**)&m->split_img, per * (size_t)(m->n_enc + m->n_dec));
+        const size_t qkv = rows256_split_image_bytes(768);
+        e = hipMalloc((void**)&m->split_img, per * (size_t)(m->n_enc + m->n_dec) + qkv * (size_t)m->n_enc);
         char* ip = m->split_img;
         int rc = 0;
+        for (int l = 0; l < m->n_enc && e == hipSuccess && rc == 0; ++l) {     // q | k | v projections (768 x 256)
+            rc = launch_ffn_split_pack(m->enc[l].sa.in_w, nullptr, 768, ip, nullptr);
+            m->enc_qkv_img[l] = ip;
+            ip += qkv;
+        }
         for (int i = 0; i < m->n_enc + m->n_dec && e == hipSuccess && rc == 0; ++i) {
             const bool enc = i < m->n_enc;
             const int l = enc ? i : i - m->n_enc;
@@ -386,7 +393,10 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         } else if (plan.tables) {
             // q | k | v = x W^T + b in ONE N = 768 GEMM on x; the attention adds pos W_qk^T of this layer from the
             // static table ((x + pos) W^T = x W^T + pos W^T): no x + pos matrix, no second A operand
-            RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
+            if (m->opt_split_bf16 && m->split_img)
+                RUN(launch_rows256_split(f.X, 256, m->enc_qkv_img[l], e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, s));
+            else
+                RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
             mode = ATTN_POSADD;
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + 512; src.ldq = src.ldk = src.ldv = 768;
             src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512; src.vlen = vlen;
@@ -762,6 +772,15 @@ extern "C" int cone_test_ffn_split(const float* X, const float* W1, const float*
         if (rc) return rc;
     }
     return launch_ffn_split(X, 256, img, b1, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff, (hipStream_t)stream);
+}
+extern "C" size_t cone_test_rows_split_image_bytes(int N) { return rows256_split_supported(N) ? rows256_split_image_bytes(N) : 0; }
+extern "C" int cone_test_rows_split(const float* X, const float* W, const float* bias, float* C, int M, int N, void* img,
+                                    int pack, void* stream) {
+    if (pack) {
+        const int rc = launch_ffn_split_pack(W, nullptr, N, img, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return launch_rows256_split(X, 256, img, bias, C, N, M, nullptr, N, (hipStream_t)stream);
 }
 extern "C" size_t cone_test_proj_split_image_bytes(void) { return ffn_split_proj_image_bytes(); }
 extern "C" int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,

@@ -117,6 +117,11 @@ size_t ffn_split_image_bytes(int ff);
 int launch_ffn_split_pack(const float* W1, const float* W2, int ff, void* img, hipStream_t s);
 int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1, const float* b2, const float* ln_g,
                      const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s);
+// C (M, N) = X (M, 256) W^T + bias on the same split operands; Wimg = launch_ffn_split_pack(W, nullptr, N, ...)
+bool rows256_split_supported(int N);
+size_t rows256_split_image_bytes(int N);
+int launch_rows256_split(const float* X, int ldx, const void* Wimg, const float* bias, float* C, int ldc, int M,
+                         const int* M_dev, int N, hipStream_t s);
 // launch_proj_ffn_fused's computation: Woimg = launch_ffn_split_pack(Wo, nullptr, 256, ...) (ffn_split_proj_image_bytes())
 size_t ffn_split_proj_image_bytes();
 int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,

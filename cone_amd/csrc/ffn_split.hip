@@ -336,6 +336,92 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// C = X W^T + bias for K = 256 and any N % 32 == 0 (the q | k | v projection of the later encoder layers) with the same
+// split operands: the projection phase of the kernel above on its own -- a wave's 16 x 256 rows stay in registers as bf16
+// pieces, W streams as N / 32 slots ([tile 2][step 8][piece 3] slabs each), every slot's 32 output channels are stored
+// straight from the accumulators (lane = token, 16 B = 4 consecutive channels).
+struct RowsSplitArgs {
+    const float* X; int ldx; const void* Wimg; const float* bias; float* C; int ldc; int M; const int* M_dev; int N;
+};
+
+__global__ __launch_bounds__(512, 2) void rows256_split_kernel(RowsSplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    float* bs = reinterpret_cast<float*>(sp_smem + SP_NSLOT * SP_SLOT);
+    int M = p.M;
+    if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
+    const int n_tiles = (M + SP_ROWS - 1) / SP_ROWS;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int G = p.N >> 5;                         // ring slots per tile
+    for (int i = tid; i < (p.N >> 2); i += 512)
+        reinterpret_cast<sp_f4*>(bs)[i] = p.bias ? reinterpret_cast<const sp_f4*>(p.bias)[i] : sp_f4{0.f, 0.f, 0.f, 0.f};
+    int sb = 0;
+    const char* wimg = reinterpret_cast<const char*>(p.Wimg);
+    auto stream_piece = [&](int g, int i) {
+        int gg = g;
+        while (gg >= G) gg -= G;                    // the next tile's first slots (G may be 1 or 2)
+        char* dstp = sp_smem + ((sb + g) % SP_NSLOT) * SP_SLOT + (wave * SP_NPIECE + i) * 1024;
+        const char* ub = wimg + (size_t)gg * SP_SLOT + (size_t)(wave * SP_NPIECE + i) * 1024;
+        asm volatile("" : "+s"(ub));
+        SP_GLDS16(ub + (unsigned)(lane * 16), dstp);
+    };
+#pragma unroll
+    for (int i = 0; i < SP_NPIECE; ++i) stream_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < SP_NPIECE; ++i) stream_piece(1, i);
+    bool first = true;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int my_row = tile * SP_ROWS + wave * 16 + li;
+        const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
+        sp_s8 xh[8], xm[8], xl[8];
+        {
+            const float* xp = p.X + ld_row * p.ldx + 4 * lg;
+            sp_f4 xr[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const sp_f4*>(xp + 16 * q);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sp_split8(xr[2 * s], xr[2 * s + 1], xh[s], xm[s], xl[s]);
+        }
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_NPIECE) : "memory");
+            __syncthreads();
+            first = false;
+        }
+        float* crow = p.C + (size_t)my_row * p.ldc + 4 * lg;
+        sp_s8 f[2][3];
+        for (int g = 0; g < G; ++g) {
+            const char* sa = SP_SLOT_OF(g);
+            sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            f[0][0] = SP_RD(sa, 0); f[0][1] = SP_RD(sa, 1); f[0][2] = SP_RD(sa, 2);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                SP_SB();
+                asm volatile("" : "+v"(f[u & 1][0]), "+v"(f[u & 1][1]), "+v"(f[u & 1][2]));
+                SP_SB();
+                if (u < 15) {
+                    f[(u + 1) & 1][0] = SP_RD(sa, (u + 1) * 3 + 0); f[(u + 1) & 1][1] = SP_RD(sa, (u + 1) * 3 + 1);
+                    f[(u + 1) & 1][2] = SP_RD(sa, (u + 1) * 3 + 2);
+                }
+                SP_SB();
+                if (u < 8) { SP_MM6(a0, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                else { SP_MM6(a1, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(g + 2, u >> 1);
+            }
+            SP_SB();
+            if (my_row < M) {
+                *reinterpret_cast<sp_f4*>(crow + 32 * g) = a0 + *reinterpret_cast<const sp_f4*>(bs + 32 * g + 4 * lg);
+                *reinterpret_cast<sp_f4*>(crow + 32 * g + 16) = a1 + *reinterpret_cast<const sp_f4*>(bs + 32 * g + 16 + 4 * lg);
+            }
+            SP_END_SLOT()
+        }
+        sb = (sb + G) % SP_NSLOT;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #undef SP_SB
 #undef SP_MM6
 #undef SP_MFMA
@@ -396,6 +482,35 @@ int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const floa
     a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
     return launch_ffn_split_t<true>(a, s);
+}
+
+bool rows256_split_supported(int N) { return N >= 32 && N % 32 == 0 && N <= 3072; }
+size_t rows256_split_image_bytes(int N) { return (size_t)(N / 32) * SP_SLOT; }
+
+int launch_rows256_split(const float* X, int ldx, const void* Wimg, const float* bias, float* C, int ldc, int M,
+                         const int* M_dev, int N, hipStream_t s) {
+    CONE_REQUIRE(rows256_split_supported(N), "split-bf16 row GEMM: N=%d unsupported", N);
+    CONE_REQUIRE(X && Wimg && C && ldx % 4 == 0 && ldc % 4 == 0, "split-bf16 row GEMM: bad argument");
+    if (M <= 0) return 0;
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    static int n_cu = 0;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)rows256_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SP_NSLOT * SP_SLOT + 3072 * (int)sizeof(float));
+        int dev = 0;
+        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
+        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    CONE_CHECK_HIP(attr_rc);
+    RowsSplitArgs a{X, ldx, Wimg, bias, C, ldc, M, M_dev, N};
+    const int tiles = (M + SP_ROWS - 1) / SP_ROWS;
+    const int grid = tiles < n_cu ? tiles : n_cu;
+    ProfScope ps(PK_GEMM_ROWS16, M, N, 256, M_dev, s);
+    hipLaunchKernelGGL(rows256_split_kernel, dim3((unsigned)grid), dim3(512),
+                       (size_t)SP_NSLOT * SP_SLOT + (size_t)N * sizeof(float), s, a);
+    CONE_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---- weight images (once per model).  One thread per 16-B fragment (8 bf16 of one piece): slot g, slab sl, lane l.

@@ -801,6 +801,8 @@ def setup_model(opt):
         raise ValueError("--resume <ckpt> is required")
     ckpt = torch.load(opt.resume, map_location="cpu", weights_only=False)
     model.load_state_dict(ckpt["model"])
+    if getattr(opt, "split_bf16", False):
+        model.set_option("split_bf16", 1)
     logger.info(f"Loaded model saved at epoch {ckpt.get('epoch')} from checkpoint: {opt.resume}")
     return model, criterion, None, None
 

@@ -352,6 +352,11 @@ int cone_test_proj_ffn(const float* A, const float* Wo, const float* bo, const f
 size_t cone_test_ffn_split_image_bytes(int ff);
 int cone_test_ffn_split(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* img, int pack, void* stream);
+/* C (M, N) = X (M, 256) W^T + bias (W (N, 256), N % 32 == 0) on the same split operands; img = scratch of
+ * cone_test_rows_split_image_bytes(N) bytes. */
+size_t cone_test_rows_split_image_bytes(int N);
+int cone_test_rows_split(const float* X, const float* W, const float* bias, float* C, int M, int N, void* img, int pack,
+                         void* stream);
 /* cone_test_proj_ffn on the bf16 matrix cores; wo_img = scratch of cone_test_proj_split_image_bytes() bytes. */
 size_t cone_test_proj_split_image_bytes(void);
 int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,

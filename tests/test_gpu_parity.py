@@ -1578,3 +1578,32 @@ def test_split_bf16_fused_ffn_matches_float64(M, ff):
     torch.cuda.synchronize()
     assert maxdiff(R[:M], ref) < 3e-5
     assert bool(torch.isnan(R[M:]).all())
+
+
+@pytest.mark.parametrize("M,N", [(1, 32), (127, 768), (1000, 768), (40000, 768), (300, 256), (513, 64)])
+def test_split_bf16_row_gemm_matches_float64(M, N):
+    """rows256_split_kernel (opt-in path's q | k | v projection): C = X W^T + b with three-piece bf16 operands against
+    float64, at the exact-fp32 GEMM's tolerance (test_gemm_matches_torch: 2e-5 of the result scale) and not further from
+    float64 than that GEMM."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(M + 7 * N)
+    X = torch.randn(M, 256, generator=g) * 1.5
+    W = torch.randn(N, 256, generator=g) / 16
+    b = torch.randn(N, generator=g) * 0.2
+    ref = X.double() @ W.double().t() + b.double()
+    Xd, Wd, bd = X.to(dev), W.to(dev), b.to(dev)
+    lib = _lib.load()
+    img = torch.empty(lib.cone_test_rows_split_image_bytes(N), dtype=torch.uint8, device=dev)
+    out = torch.full((M + 2, N), float("nan"), device=dev)
+    _lib.check(lib.cone_test_rows_split(_lib.ptr(Xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(out), M, N, _lib.ptr(img), 1,
+                                        _lib.stream()))
+    torch.cuda.synchronize()
+    err = maxdiff(out[:M], ref)
+    assert err < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool(torch.isnan(out[M:]).all())
+    out32 = torch.empty(M, N, device=dev)
+    _lib.check(lib.cone_test_gemm(_lib.ptr(Xd), None, 0, _lib.ptr(Wd), _lib.ptr(bd), None, None, None, _lib.ptr(out32), None,
+                                  None, M, N, 256, 0, _lib.stream()))
+    torch.cuda.synchronize()
+    assert err <= 2.0 * maxdiff(out32, ref) + 1e-6, (err, maxdiff(out32, ref))
