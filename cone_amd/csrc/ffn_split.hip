@@ -151,20 +151,25 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
 #pragma unroll
     for (int i = 0; i < SP_NPIECE; ++i) stream_piece(1, i);
 
+    // a tile's rows (PROJ: the attention rows = B operand of the projection, else the block input) are requested from
+    // the previous tile's epilogue -- once its operand pieces are dead, ahead of its stores -- and split at the tile's top
+    sp_f4 xr[16];
+    auto load_rows = [&](int tile) {
+        const int row = tile * SP_ROWS + wave * 16 + li;
+        const size_t lr = (size_t)(row < M ? row : M - 1);
+        const float* xp = (PROJ ? p.A + lr * p.lda : p.X + lr * p.ldx) + 4 * lg;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const sp_f4*>(xp + 16 * q);
+    };
+    load_rows(blockIdx.x);
     bool first = true;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int my_row = tile * SP_ROWS + wave * 16 + li;
-    // the tile's rows, split once: xh / xm / xl [s] = B operand of GEMM1's step s (channels 32 s + 16 (j / 4) + 4 lg + j % 4)
+    // split once: xh / xm / xl [s] = B operand of GEMM1's step s (channels 32 s + 16 (j / 4) + 4 lg + j % 4)
     sp_s8 xh[8], xm[8], xl[8];
     const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
-    {   // PROJ: the attention rows (B operand of the projection), else the block input
-        const float* xp = (PROJ ? p.A + ld_row * p.lda : p.X + ld_row * p.ldx) + 4 * lg;
-        sp_f4 xr[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const sp_f4*>(xp + 16 * q);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) sp_split8(xr[2 * s], xr[2 * s + 1], xh[s], xm[s], xl[s]);
-    }
+    for (int s = 0; s < 8; ++s) sp_split8(xr[2 * s], xr[2 * s + 1], xh[s], xm[s], xl[s]);
     if (first) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP_NPIECE) : "memory");
         __syncthreads();
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
         // tile: bias + ReLU + split of tile 0 run under tile 1's MFMAs
         const char* sa = SP_SLOT_OF(NP + 2 * c);
         sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        unsigned p0h[2], p0m[2], p0l[2];
         f[0][0] = SP_RD(sa, 0); f[0][1] = SP_RD(sa, 1); f[0][2] = SP_RD(sa, 2);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -258,22 +264,34 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
             if (u < 8) { SP_MM6(a0, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
             else { SP_MM6(a1, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
             if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(NP + 2 * c + 2, u >> 1);
+            if (u == 9) {       // tile 0 is complete: its bias + ReLU + split run under tile 1's MFMAs
+                a0 += *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 4 * lg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a0[r] = fmaxf(a0[r], 0.f);
+                sp_split2(a0[0], a0[1], p0h[0], p0m[0], p0l[0]);
+                sp_split2(a0[2], a0[3], p0h[1], p0m[1], p0l[1]);
+            }
         }
         SP_SB();
-        // bias + ReLU, split: the B operand of GEMM2 (k slot (lg, j) <-> unit 16 (j / 4) + 4 lg + j % 4)
-        sp_s8 hh, hm, hl;
-        {
-            const sp_f4 bb0 = *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 4 * lg);
-            const sp_f4 bb1 = *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 16 + 4 * lg);
-            a0 += bb0; a1 += bb1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
-            sp_split8(a0, a1, hh, hm, hl);
-        }
         SP_END_SLOT()
-        // ---- GEMM2: all 256 output channels over the chunk's 32 hidden units (slot 2 c + 1: [channel tile][piece])
+        // ---- GEMM2: all 256 output channels over the chunk's 32 hidden units (slot 2 c + 1: [channel tile][piece]); its
+        // first fragments are requested ahead of tile 1's bias + ReLU + split
         const char* sw = SP_SLOT_OF(NP + 2 * c + 1);
         f[0][0] = SP_RD(sw, 0); f[0][1] = SP_RD(sw, 1); f[0][2] = SP_RD(sw, 2);
+        SP_SB();
+        // the B operand of GEMM2 (k slot (lg, j) <-> unit 16 (j / 4) + 4 lg + j % 4): tile 0's pieces, then tile 1's
+        sp_s8 hh, hm, hl;
+        {
+            unsigned p1h[2], p1m[2], p1l[2];
+            a1 += *reinterpret_cast<const sp_f4*>(b1s + 32 * c + 16 + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[r] = fmaxf(a1[r], 0.f);
+            sp_split2(a1[0], a1[1], p1h[0], p1m[0], p1l[0]);
+            sp_split2(a1[2], a1[3], p1h[1], p1m[1], p1l[1]);
+            hh = __builtin_bit_cast(sp_s8, sp_u4{p0h[0], p0h[1], p1h[0], p1h[1]});
+            hm = __builtin_bit_cast(sp_s8, sp_u4{p0m[0], p0m[1], p1m[0], p1m[1]});
+            hl = __builtin_bit_cast(sp_s8, sp_u4{p0l[0], p0l[1], p1l[0], p1l[1]});
+        }
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             SP_SB();
@@ -304,6 +322,11 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) y[t] += *reinterpret_cast<const sp_f4*>(prm + 16 * t + 4 * lg);
+    SP_SB();
+    // the operand pieces are dead: the next tile's rows travel under the LayerNorm and the stores (after the last tile a
+    // valid tile is simply re-read, so that the register tile has one definition per iteration)
+    load_rows(tile + (int)gridDim.x < n_tiles ? tile + (int)gridDim.x : tile);
+    SP_SB();
     float s1 = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) s1 += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
