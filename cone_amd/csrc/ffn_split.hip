@@ -311,6 +311,9 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     // ---- epilogue: + b2 + residual (x = xh + xm + xl exactly, in the accumulator layout), LayerNorm, store
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+        // (opaque here: otherwise the unpacked halves computed by the split at the tile's top are kept alive across the
+        // whole tile -- 80 spilled registers -- instead of being re-derived by two shifts)
+        asm volatile("" : "+v"(xh[s]), "+v"(xm[s]), "+v"(xl[s]));
         const sp_u4 uh = __builtin_bit_cast(sp_u4, xh[s]), um = __builtin_bit_cast(sp_u4, xm[s]), ul = __builtin_bit_cast(sp_u4, xl[s]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {           // pair e: elements 2 e, 2 e + 1 of the step = (tile 2 s + e / 2, r = 2 (e % 2) ..)
