@@ -19,6 +19,12 @@ rocprofv3 --kernel-trace --stats -d $out/prof_${tag}_step -o t -- python3 bench.
 # the timed region only: the last launches of the trace (3 steps), so that per-kernel averages are those of the step
 win=$(python3 -c "import json,sys; print(3 * json.load(open('$out/${tag}_prof_step.json'))['ms_per_step'] + 0.5)")
 python3 tools/rocpd_summary.py $out/prof_${tag}_step/t_results.db $win > $out/${tag}_bench_kernel_stats.csv 2>> $out/prof_$tag.log
+# the opt-in split-bf16 path, same window
+rm -rf $out/prof_${tag}_split
+rocprofv3 --kernel-trace --stats -d $out/prof_${tag}_split -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
+    --no_extras --set_option split_bf16=1 > $out/${tag}_prof_split.json 2>> $out/prof_$tag.log
+win=$(python3 -c "import json,sys; print(3 * json.load(open('$out/${tag}_prof_split.json'))['ms_per_step'] + 0.5)")
+python3 tools/rocpd_summary.py $out/prof_${tag}_split/t_results.db $win > $out/${tag}_bench_kernel_stats_split.csv 2>> $out/prof_$tag.log
 B="python3 bench.py --steps 2 --warmup 1 --cpu_queries 0 --no_extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $B > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $B > $out/pmc_write.log 2>&1
