@@ -8,7 +8,6 @@ tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 rm -rf $out/prof_$tag $out/pmc_fetch $out/pmc_write $out/pmc_mfma
 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
     > $out/${tag}_prof_bench.json 2> $out/prof_$tag.log
@@ -32,4 +31,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_
     -d $out/pmc_mfma -o m -- $B > $out/pmc_mfma.log 2>&1
 python3 tools/pmc_summary.py $out $out/${tag}_pmc > $out/${tag}_pmc.log 2>&1
 tail -3 $out/${tag}_pmc.log
+# the bench line last: roofline.traffic is read from profiles/<tag>_pmc_traffic.json of THIS collection
+cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv profiles/
+python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 cat $out/${tag}_bench_line.json
