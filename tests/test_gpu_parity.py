@@ -1514,15 +1514,15 @@ def test_encoder_attention_kernel_matches_float64(mode):
     assert bool(torch.isnan(out[M:]).all())
 
 
-@pytest.mark.parametrize("preset,seed0", [("ego4d", 100), ("mad", 200)])
-def test_randomised_splits_against_oracle(preset, seed0):
+@pytest.mark.parametrize("preset,seed0,split", [("ego4d", 100, 0), ("mad", 200, 0), ("ego4d", 300, 1)])
+def test_randomised_splits_against_oracle(preset, seed0, split):
     """tools/fuzz_parity.py (a longer soak of the same loop ran 400 + 150 random splits clean): random ragged splits --
     videos from one clip up, 1..13 queries, 1..max text tokens, top-k above and below the window count, eval_bsz 1..32,
     NMS thresholds incl. -1, window batches 1..32768 -- device pipeline against the CPU oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "14", str(seed0), preset],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "14", str(seed0), preset, str(split)],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 

@@ -2,7 +2,7 @@
 """Randomised parity soak: random small splits (ragged videos from 1 clip up, 1..N queries, text lengths 1..max, top-k
 above and below the number of windows, every eval_bsz / NMS threshold / window batch), device pipeline against the CPU
 oracle: rank lists exact, window rows within the logit tolerance, fusion + NMS exact on identical candidates, results
-independent of window_batch.  Test infrastructure (imports oracle/).  usage: fuzz_parity.py [iterations] [seed0] [preset]"""
+independent of window_batch.  Test infrastructure (imports oracle/).  usage: fuzz_parity.py [iterations] [seed0] [preset] [split_bf16 0|1]"""
 import os
 import sys
 import time
@@ -20,11 +20,13 @@ from oracle import cone_oracle as O  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 preset = sys.argv[3] if len(sys.argv) > 3 else "ego4d"
+split_bf16 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 torch.cuda.set_device(0)
 base = make_opt(preset)
 sd = synth.make_state_dict(base, 0)
 model, _ = build_model(base)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+model.set_option("split_bf16", split_bf16)        # 1: the opt-in bf16-split layer tails, same checks, same tolerances
 A = lambda r: np.array(r["pred_relevant_windows"])
 worst = dict(prop=0.0, sec=0.0, match_bad=0.0)
 t_start = time.time()
@@ -64,5 +66,5 @@ for it in range(iters):
                     window_batch=32768 if opt.window_batch != 32768 else 5)
     again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
     assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
-print(f"fuzz ok: {iters} random splits ({preset}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
+print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
       f"worst span diff {worst['sec']:.2e} s, worst share of matching rows beyond 2e-4: {worst['match_bad']:.0%}")
