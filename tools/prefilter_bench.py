@@ -2,7 +2,7 @@
 """BASELINE.json configs[2]: MAD-scale synthetic long video -- CLIP d=512 features, window_len=125,
 ~100k windows (ctx_l = 6.2 M clips = 12.7 GB fp32 resident in HBM) -- HBM-bound pre-filter stress.
 Reports GB/s of the frame-score stream against the 8 TB/s HBM3E peak (algorithmic bytes
-4*ctx_l*dv + Q*4*(dv + ctx_l + num_window))."""
+4*ctx_l*dv + Q*4*(dv + num_window): SURVEY.md 8d, the formula bench.py's prefilter_mad object uses)."""
 import argparse
 import json
 import os
@@ -49,7 +49,7 @@ def main():
     rec = buf[:n]
     fs_ms = rec[np.isin(rec[:, 0], (0, 1, 2, 4, 5))][:, 4]
     per_step_ms = fs_ms.sum() / args.steps
-    alg = 4.0 * args.ctx_l * args.dv + args.queries * 4.0 * (args.dv + args.ctx_l)
+    alg = 4.0 * args.ctx_l * args.dv + args.queries * 4.0 * (args.dv + nw)
     # reference check on a slice
     ref = (vid[:4096] @ txt.t()).t()
     err = float((fs[:, :4096] - ref).abs().max())
