@@ -55,6 +55,7 @@ struct cone_model {
     const void* enc_wo_img[CONE_MAX_LAYERS] = {}; const void* enc_ffn_img[CONE_MAX_LAYERS] = {};
     const void* enc_qkv_img[CONE_MAX_LAYERS] = {};
     const void* dec_wo_img[CONE_MAX_LAYERS] = {}; const void* dec_ffn_img[CONE_MAX_LAYERS] = {};
+    int opt_qkv_fused = 1;    // (split_bf16) the next encoder layer's q | k | v projection inside the fused layer tail
     int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
                               // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
     int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
@@ -378,6 +379,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
     }
 
+    bool qkv_fused = false;               // this layer's q | k | v rows were written by the previous layer's tail
     for (int l = 0; l < m->n_enc; ++l) {  // cone/transformer.py:233-246
         const EncLayer& e = m->enc[l];
         GemmArgs g;
@@ -393,7 +395,9 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         } else if (plan.tables) {
             // q | k | v = x W^T + b in ONE N = 768 GEMM on x; the attention adds pos W_qk^T of this layer from the
             // static table ((x + pos) W^T = x W^T + pos W^T): no x + pos matrix, no second A operand
-            if (m->opt_split_bf16 && m->split_img)
+            if (qkv_fused) {
+                // written by the previous layer's fused tail from the registers that held its output rows
+            } else if (m->opt_split_bf16 && m->split_img)
                 RUN(launch_rows256_split(f.X, 256, m->enc_qkv_img[l], e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, s));
             else
                 RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
@@ -412,11 +416,17 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             // everything behind the attention in ONE launch: norm2(x1 + ffn(x1)), x1 = norm1(x + attn Wo^T + bo); a
             // workgroup reads its 128 rows of x before it writes them, and nobody else touches them: in place
             const bool g0 = l == 0 && gather_res;
-            if (m->opt_split_bf16 && m->split_img)
+            if (m->opt_split_bf16 && m->split_img) {
+                // the next encoder layer's q | k | v projection rides in the same launch (its input rows are this kernel's
+                // output: no second pass over them); ATT and QKV are disjoint parts of the H region
+                const bool next_qkv = m->opt_qkv_fused && l + 1 < m->n_enc && plan.tables;
                 RUN(launch_proj_ffn_split(f.ATT, 256, m->enc_wo_img[l], e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b,
                                           m->enc_ffn_img[l], e.l1.b, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s,
-                                          g0 ? RIDX : nullptr, g0 ? tproj : nullptr));
-            else if (g0)
+                                          g0 ? RIDX : nullptr, g0 ? tproj : nullptr,
+                                          next_qkv ? m->enc_qkv_img[l + 1] : nullptr, next_qkv ? m->enc[l + 1].sa.in_b : nullptr,
+                                          next_qkv ? f.QKV : nullptr, 768, next_qkv ? 768 : 0));
+                qkv_fused = next_qkv;
+            } else if (g0)
                 RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, vproj, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
                                           e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s, RIDX, tproj));
             else
@@ -729,6 +739,7 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
         m->opt_ffn_fused = value;
         return 0;
     }
+    if (!strcmp(name, "qkv_fused")) { m->opt_qkv_fused = value != 0; return 0; }
     if (!strcmp(name, "split_bf16")) {
         CONE_REQUIRE(value == 0 || m->split_img, "set_option: split_bf16 needs hidden_dim 256 and dim_feedforward %% 32 == 0 (<= 2048)");
         m->opt_split_bf16 = value != 0;

@@ -127,7 +127,11 @@ size_t ffn_split_proj_image_bytes();
 int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const void* Wimg, const float* b1, const float* b2,
                           const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
-                          hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
+                          hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr,
+                          const void* Qimg = nullptr, const float* qb = nullptr, float* QKV = nullptr, int ldq = 0,
+                          int n_qkv = 0);
+// Qimg != null: the kernel also writes QKV (M, n_qkv) = OUT Wq^T + qb (the next layer's q | k | v projection; Qimg =
+// launch_ffn_split_pack(Wq, nullptr, n_qkv, ...)) from the registers that hold OUT
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,

@@ -78,6 +78,9 @@ struct FfnSplitArgs {
     // R residual rows (r_idx != null: gathered, row i = R[r_idx[i]] or R2[~r_idx[i]]), Woimg = Wo's image (8 slots)
     const float* A; int lda; const float* R; int ldr; const int* r_idx; const float* R2;
     const void* Woimg; const float* bo; const float* pg; const float* pb;
+    // QKV: the NEXT layer's q | k | v projection of the rows this kernel produces, computed from the registers that hold
+    // them: Qimg = its weight image (NQ = n_qkv / 32 slots), qb its bias, QKV (M, n_qkv) its output
+    const void* Qimg; const float* qb; float* QKV; int ldq; int n_qkv;
 };
 
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
@@ -93,7 +96,7 @@ struct FfnSplitArgs {
         SP_MFMA(acc, wh, xh);                \
     }
 
-template <bool PROJ>
+template <bool PROJ, bool QKV>
 __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sp_smem[];
     float* b1s = reinterpret_cast<float*>(sp_smem + SP_NSLOT * SP_SLOT);
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     const int ff = p.ff, nc = ff >> 5;            // 32-unit hidden chunks
     constexpr int NP = PROJ ? 8 : 0;              // leading slots of the output projection (32 channels each)
-    const int G = NP + 2 * nc;                    // ring slots per tile
+    const int NQ = QKV ? p.n_qkv >> 5 : 0;        // trailing slots of the next layer's q | k | v projection
+    const int G = NP + 2 * nc + NQ;               // ring slots per tile
 
     float* prm = b1s + ff;                        // b2, ln_g, ln_b
     for (int i = tid; i < (ff >> 2); i += 512)
@@ -121,6 +125,10 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
             reinterpret_cast<sp_f4*>(prm + 1280)[tid] = reinterpret_cast<const sp_f4*>(p.pb)[tid];
         }
     }
+    float* qbs = prm + 1536;                      // q | k | v bias
+    if (QKV)
+        for (int i = tid; i < (p.n_qkv >> 2); i += 512)
+            reinterpret_cast<sp_f4*>(qbs)[i] = reinterpret_cast<const sp_f4*>(p.qb)[i];
 
     // LDS-DMA: piece i of slot g (of the current tile; g >= G: the next tile's first slots, the same weights) = 1 KiB
     // at image offset g * 48 KiB + (6 wave + i) KiB, lane * 16 B inside it; destination = the same offset in ring slot
@@ -128,10 +136,13 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
     int sb = 0;
     const char* wimg = reinterpret_cast<const char*>(p.Wimg);
     const char* woimg = reinterpret_cast<const char*>(p.Woimg);
+    const char* qimg = reinterpret_cast<const char*>(p.Qimg);
     auto stream_piece = [&](int g, int i) {
         const int gg = g < G ? g : g - G;
         char* dstp = sp_smem + ((sb + g) % SP_NSLOT) * SP_SLOT + (wave * SP_NPIECE + i) * 1024;
-        const char* ub = (PROJ && gg < NP ? woimg + (size_t)gg * SP_SLOT : wimg + (size_t)(gg - NP) * SP_SLOT) +
+        const char* ub = (PROJ && gg < NP ? woimg + (size_t)gg * SP_SLOT
+                          : (QKV && gg >= NP + 2 * nc ? qimg + (size_t)(gg - NP - 2 * nc) * SP_SLOT
+                                                       : wimg + (size_t)(gg - NP) * SP_SLOT)) +
                          (size_t)(wave * SP_NPIECE + i) * 1024;
         asm volatile("" : "+s"(ub));
         SP_GLDS16(ub + (unsigned)(lane * 16), dstp);
@@ -355,6 +366,42 @@ __global__ __launch_bounds__(512, 2) void ffn_split_kernel(FfnSplitArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * g[r] + be[r];
             *reinterpret_cast<sp_f4*>(op + 16 * t) = o;
+            if (QKV) y[t] = o;
+        }
+    } else if (QKV) {       // rows past M feed unstored outputs: any finite values
+#pragma unroll
+        for (int t = 0; t < 16; ++t) y[t] = sp_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (QKV) {
+        // ---- the next layer's q | k | v projection of these rows, straight from the registers: split once more, then
+        // NQ slots of 32 output channels each ([tile 2][step 8][piece 3] slabs), stored from the accumulators
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sp_split8(y[2 * s], y[2 * s + 1], xh[s], xm[s], xl[s]);
+        float* qrow = p.QKV + (size_t)my_row * p.ldq + 4 * lg;
+        for (int g = 0; g < NQ; ++g) {
+            const char* sa = SP_SLOT_OF(NP + 2 * nc + g);
+            sp_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            f[0][0] = SP_RD(sa, 0); f[0][1] = SP_RD(sa, 1); f[0][2] = SP_RD(sa, 2);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                SP_SB();
+                asm volatile("" : "+v"(f[u & 1][0]), "+v"(f[u & 1][1]), "+v"(f[u & 1][2]));
+                SP_SB();
+                if (u < 15) {
+                    f[(u + 1) & 1][0] = SP_RD(sa, (u + 1) * 3 + 0); f[(u + 1) & 1][1] = SP_RD(sa, (u + 1) * 3 + 1);
+                    f[(u + 1) & 1][2] = SP_RD(sa, (u + 1) * 3 + 2);
+                }
+                SP_SB();
+                if (u < 8) { SP_MM6(a0, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                else { SP_MM6(a1, f[u & 1][0], f[u & 1][1], f[u & 1][2], xh[u & 7], xm[u & 7], xl[u & 7]) }
+                if ((u & 1) && (u >> 1) < SP_NPIECE) stream_piece(NP + 2 * nc + g + 2, u >> 1);
+            }
+            SP_SB();
+            if (my_row < M) {
+                *reinterpret_cast<sp_f4*>(qrow + 32 * g) = a0 + *reinterpret_cast<const sp_f4*>(qbs + 32 * g + 4 * lg);
+                *reinterpret_cast<sp_f4*>(qrow + 32 * g + 16) = a1 + *reinterpret_cast<const sp_f4*>(qbs + 32 * g + 16 + 4 * lg);
+            }
+            SP_END_SLOT()
         }
     }
     sb = (sb + G) % SP_NSLOT;
@@ -460,15 +507,17 @@ bool ffn_split_supported(int ff) { return ff >= 64 && ff % 32 == 0 && ff <= 2048
 size_t ffn_split_image_bytes(int ff) { return (size_t)2 * (ff / 32) * SP_SLOT; }
 size_t ffn_split_proj_image_bytes() { return (size_t)8 * SP_SLOT; }
 
-template <bool PROJ>
+template <bool PROJ, bool QKV>
 static int launch_ffn_split_t(const FfnSplitArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(a.ff + 6 * 256) * sizeof(float);
+    const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
+    CONE_REQUIRE(lds <= 160 * 1024, "split-bf16 fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff,
+                 a.n_qkv);
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     static int n_cu = 0;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      SP_NSLOT * SP_SLOT + (2048 + 6 * 256) * (int)sizeof(float));
+        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel<PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
         int dev = 0;
         if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
         if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -476,8 +525,10 @@ static int launch_ffn_split_t(const FfnSplitArgs& a, hipStream_t s) {
     CONE_CHECK_HIP(attr_rc);
     const int tiles = (a.M + SP_ROWS - 1) / SP_ROWS;
     const int grid = tiles < n_cu ? tiles : n_cu;
-    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff, 256, a.M_dev, s);
-    hipLaunchKernelGGL(ffn_split_kernel<PROJ>, dim3((unsigned)grid), dim3(512), lds, s, a);
+    // FLOPs of a record = 4 M ff 256 (+ 2 M 256 256 with the projection); the fused q | k | v projection adds
+    // 2 M n_qkv 256 = 4 M (n_qkv / 2) 256: it is booked as n_qkv / 2 extra hidden units
+    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
+    hipLaunchKernelGGL((ffn_split_kernel<PROJ, QKV>), dim3((unsigned)grid), dim3(512), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -491,13 +542,14 @@ int launch_ffn_split(const float* X, int ldx, const void* Wimg, const float* b1,
     FfnSplitArgs a{};
     a.X = X; a.ldx = ldx; a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
-    return launch_ffn_split_t<false>(a, s);
+    return launch_ffn_split_t<false, false>(a, s);
 }
 
 int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const void* Wimg, const float* b1, const float* b2,
                           const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
-                          hipStream_t s, const int* r_idx, const float* R2) {
+                          hipStream_t s, const int* r_idx, const float* R2, const void* Qimg, const float* qb, float* QKV,
+                          int ldq, int n_qkv) {
     CONE_REQUIRE(ffn_split_supported(ff), "split-bf16 fused layer tail: dim_feedforward=%d unsupported", ff);
     CONE_REQUIRE(A && Woimg && bo && R && pg && pb && Wimg && b1 && b2 && ln_g && ln_b && OUT, "split-bf16 fused layer tail: null argument");
     CONE_REQUIRE(!r_idx || R2, "split-bf16 fused layer tail: a gathered residual needs both source matrices");
@@ -507,7 +559,12 @@ int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const floa
     a.A = A; a.lda = lda; a.Woimg = Woimg; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb; a.r_idx = r_idx; a.R2 = R2;
     a.Wimg = Wimg; a.b1 = b1; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
-    return launch_ffn_split_t<true>(a, s);
+    if (Qimg) {
+        CONE_REQUIRE(qb && QKV && n_qkv >= 32 && n_qkv % 32 == 0 && ldq % 4 == 0, "split-bf16 fused layer tail: bad q|k|v arguments");
+        a.Qimg = Qimg; a.qb = qb; a.QKV = QKV; a.ldq = ldq; a.n_qkv = n_qkv;
+        return launch_ffn_split_t<true, true>(a, s);
+    }
+    return launch_ffn_split_t<true, false>(a, s);
 }
 
 bool rows256_split_supported(int N) { return N >= 32 && N % 32 == 0 && N <= 3072; }

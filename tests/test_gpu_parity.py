@@ -319,12 +319,15 @@ def test_position_tables_equal_materialised_pos_path(preset):
         model.set_option("res_gather", 1)
         model.set_option("split_bf16", 1)        # layer tails as six bf16 partial products per fp32 product
         outs.append(inf.run_windows(model, store, opt, wt))
+        model.set_option("qkv_fused", 0)         # ... with the next layer's q|k|v projection as its own launch
+        outs.append(inf.run_windows(model, store, opt, wt))
     finally:
         model.set_option("pos_tables", 1)
         model.set_option("ffn_fused", 2)
         model.set_option("dec_fold", 2)
         model.set_option("res_gather", 1)
         model.set_option("split_bf16", 0)
+        model.set_option("qkv_fused", 1)
     assert int((wt["vid_len"] < opt.max_v_l).sum()) > 0          # ragged windows are in the batch
     for k in ("pred_logits", "pred_spans", "saliency_scores"):
         assert maxdiff(outs[0][k], outs[1][k].cpu()) < 5e-5, k
@@ -333,6 +336,7 @@ def test_position_tables_equal_materialised_pos_path(preset):
         assert maxdiff(outs[0][k], outs[4][k].cpu()) < 5e-5, ("dec_fold 1", k)
         assert torch.equal(outs[0][k], outs[5][k]), ("res_gather 0", k)         # the same rows, read from another place
         assert maxdiff(outs[0][k], outs[6][k].cpu()) < 5e-5, ("split_bf16", k)
+        assert torch.equal(outs[6][k], outs[7][k]), ("qkv_fused 0", k)          # the same products in the same order
     safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
     d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
     assert float(d[safe].max()) < 5e-5
