@@ -419,7 +419,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             if (m->opt_split_bf16 && m->split_img) {
                 // the next encoder layer's q | k | v projection rides in the same launch (its input rows are this kernel's
                 // output: no second pass over them); ATT and QKV are disjoint parts of the H region
-                const bool next_qkv = m->opt_qkv_fused && l + 1 < m->n_enc && plan.tables;
+                const bool next_qkv = m->opt_qkv_fused && l + 1 < m->n_enc && plan.tables && ffn_split_qkv_fits(ff, 768);
                 RUN(launch_proj_ffn_split(f.ATT, 256, m->enc_wo_img[l], e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b,
                                           m->enc_ffn_img[l], e.l1.b, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s,
                                           g0 ? RIDX : nullptr, g0 ? tproj : nullptr,

@@ -124,6 +124,7 @@ int launch_rows256_split(const float* X, int ldx, const void* Wimg, const float*
                          const int* M_dev, int N, hipStream_t s);
 // launch_proj_ffn_fused's computation: Woimg = launch_ffn_split_pack(Wo, nullptr, 256, ...) (ffn_split_proj_image_bytes())
 size_t ffn_split_proj_image_bytes();
+bool ffn_split_qkv_fits(int ff, int n_qkv);
 int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const void* Wimg, const float* b1, const float* b2,
                           const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,

@@ -506,6 +506,11 @@ __global__ __launch_bounds__(512, 2) void rows256_split_kernel(RowsSplitArgs p) 
 bool ffn_split_supported(int ff) { return ff >= 64 && ff % 32 == 0 && ff <= 2048; }
 size_t ffn_split_image_bytes(int ff) { return (size_t)2 * (ff / 32) * SP_SLOT; }
 size_t ffn_split_proj_image_bytes() { return (size_t)8 * SP_SLOT; }
+// does the fused tail + a q | k | v projection of n_qkv outputs fit the CU's LDS (ring + b1 + parameter rows + its bias)?
+bool ffn_split_qkv_fits(int ff, int n_qkv) {
+    return ffn_split_supported(ff) && n_qkv >= 32 && n_qkv % 32 == 0 &&
+           (size_t)SP_NSLOT * SP_SLOT + (size_t)(ff + 6 * 256 + n_qkv) * sizeof(float) <= 160 * 1024;
+}
 
 template <bool PROJ, bool QKV>
 static int launch_ffn_split_t(const FfnSplitArgs& a, hipStream_t s) {
