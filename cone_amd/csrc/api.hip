@@ -55,7 +55,8 @@ struct cone_model {
     const void* enc_wo_img[CONE_MAX_LAYERS] = {}; const void* enc_ffn_img[CONE_MAX_LAYERS] = {};
     const void* enc_qkv_img[CONE_MAX_LAYERS] = {};
     const void* dec_wo_img[CONE_MAX_LAYERS] = {}; const void* dec_ffn_img[CONE_MAX_LAYERS] = {};
-    int opt_qkv_fused = 1;    // (split_bf16) the next encoder layer's q | k | v projection inside the fused layer tail
+    int opt_qkv_fused = 1;    // the next encoder layer's q | k | v projection inside the fused layer tail (same launch): 1 = on
+                              // the split_bf16 path (-0.3 ms), 2 = on the exact-fp32 path too (neutral), 0 = own launch
     int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
                               // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
     int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
@@ -426,12 +427,17 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                                           next_qkv ? m->enc_qkv_img[l + 1] : nullptr, next_qkv ? m->enc[l + 1].sa.in_b : nullptr,
                                           next_qkv ? f.QKV : nullptr, 768, next_qkv ? 768 : 0));
                 qkv_fused = next_qkv;
-            } else if (g0)
-                RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, vproj, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
-                                          e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s, RIDX, tproj));
-            else
-                RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, f.X, 256, e.n1.g, e.n1.b, e.l1.w, e.l1.b,
-                                          e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s));
+            } else {
+                // (exact-fp32 kernel: measured neutral against the separate GEMM launch -- 44.3 vs 44.1 ms of kernel time per
+                // step -- so only on request: qkv_fused = 2)
+                const bool next_qkv = m->opt_qkv_fused >= 2 && l + 1 < m->n_enc && plan.tables && ffn_fused_qkv_fits(ff, 768);
+                RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b, e.l1.w,
+                                          e.l1.b, e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s,
+                                          g0 ? RIDX : nullptr, g0 ? tproj : nullptr,
+                                          next_qkv ? m->enc[l + 1].sa.in_w : nullptr, next_qkv ? m->enc[l + 1].sa.in_b : nullptr,
+                                          next_qkv ? f.QKV : nullptr, 768, next_qkv ? 768 : 0));
+                qkv_fused = next_qkv;
+            }
             continue;
         }
         g = G(m, f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X1, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL | EPI_LN);
@@ -739,7 +745,11 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
         m->opt_ffn_fused = value;
         return 0;
     }
-    if (!strcmp(name, "qkv_fused")) { m->opt_qkv_fused = value != 0; return 0; }
+    if (!strcmp(name, "qkv_fused")) {
+        CONE_REQUIRE(value >= 0 && value <= 2, "set_option: qkv_fused %d not in [0, 2]", value);
+        m->opt_qkv_fused = value;
+        return 0;
+    }
     if (!strcmp(name, "split_bf16")) {
         CONE_REQUIRE(value == 0 || m->split_img, "set_option: split_bf16 needs hidden_dim 256 and dim_feedforward %% 32 == 0 (<= 2048)");
         m->opt_split_bf16 = value != 0;

@@ -105,7 +105,12 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
 int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
-                          const int* M_dev, int ff, hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
+                          const int* M_dev, int ff, hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr,
+                          const float* Wq = nullptr, const float* qb = nullptr, float* QKV = nullptr, int ldq = 0,
+                          int n_qkv = 0);
+// Wq != null: the kernel also writes QKV (M, n_qkv) = OUT Wq^T + qb (the next layer's q | k | v projection) from the
+// registers that hold OUT
+bool ffn_fused_qkv_fits(int ff, int n_qkv);
 // r_idx != null: residual row i is gathered -- r_idx[i] >= 0: row r_idx[i] of R, else row ~r_idx[i] of R2 (launch_row_index)
 
 // ---------------------------------------------------------------- the same on the bf16 matrix cores (ffn_split.hip)

@@ -69,6 +69,9 @@ struct FfnArgs {
     const float* Wo; const float* bo; const float* pg; const float* pb;
     // r_idx != null: the residual rows are gathered: row i = R[r_idx[i]] (r_idx[i] >= 0) or R2[~r_idx[i]]
     const int* r_idx; const float* R2;
+    // QKV: the NEXT layer's q | k | v projection of the rows this kernel produces (Wq (n_qkv, 256), qb), computed from the
+    // registers that hold them and written to QKV (M, n_qkv): no second pass over the rows, no extra launch
+    const float* Wq; const float* qb; float* QKV; int ldq; int n_qkv;
 };
 
 // LayerNorm over a token's 256 channels held as v[16] (channel 16 t + 4 lg + r in v[t][r]): 4 lanes x 64 registers.
@@ -90,7 +93,7 @@ __device__ __forceinline__ void ffn_layernorm_regs(f32x4f (&v)[16], float& rstd)
     rstd = 1.0f / sqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
 }
 
-template <bool PROJ>
+template <bool PROJ, bool QKV>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* b1s = smem + FFN_NST * FFN_STAGE;
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     const int li = lane & 15, lg = lane >> 4;
     const int ff = p.ff, nc = ff >> 4;
     constexpr int NP = PROJ ? 8 : 0;              // leading chunks of the output projection (32 channels each)
-    const int G = NP + nc;                        // weight chunks per tile; the ring runs on across tiles
+    const int NQ = QKV ? p.n_qkv >> 5 : 0;        // trailing chunks of the next layer's q | k | v projection (32 channels each)
+    const int G = NP + nc + NQ;                   // weight chunks per tile; the ring runs on across tiles
 
     // every per-channel parameter vector goes to LDS once per workgroup: b1 (ff), then 6 x 256: b2, ln_g, ln_b and
     // (PROJ) bo, pg, pb -- no ordinary global load remains inside the tile loop besides the tile's own rows
@@ -120,6 +124,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
             reinterpret_cast<f32x4f*>(prm + 1280)[tid] = reinterpret_cast<const f32x4f*>(p.pb)[tid];
         }
     }
+    float* qbs = prm + 1536;
+    if (QKV)
+        for (int i = tid; i < (p.n_qkv >> 2); i += 512)
+            reinterpret_cast<f32x4f*>(qbs)[i] = reinterpret_cast<const f32x4f*>(p.qb)[i];
 
     // ---- LDS-DMA pieces.  A feed-forward chunk = 32 slabs of [16 rows][16 floats]; wave w issues slabs 4w .. 4w+3
     // (0-15 = W1, 16-31 = W2); lane -> (row = lane / 4, physical chunk = lane % 4), the source chunk is XOR-swizzled.
@@ -150,9 +158,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
         // ONE scalar base (selected, not branched on) + ONE 32-bit lane offset; the empty asm pins the base in SGPRs at
         // this point: hoisted out of the tile loop, base + lane offset becomes a 64-bit VGPR pair per piece, spilled,
         // and every reload drains the DMA queue with a vmcnt(0)
-        const bool pj = PROJ && gg < NP;
+        const bool qk = QKV && gg >= NP + nc;         // a q | k | v chunk: 32 rows of Wq in the projection's slab format
+        const bool pj = (PROJ && gg < NP) || qk;
         const char* ub = reinterpret_cast<const char*>(
-            pj ? p.Wo + ((size_t)gg * (32 * 256) + 16 * i) : fbase + ((size_t)(gg - NP) * fchunk + (size_t)i * fpiece));
+            qk ? p.Wq + ((size_t)(gg - NP - nc) * (32 * 256) + 16 * i)
+               : (pj ? p.Wo + ((size_t)gg * (32 * 256) + 16 * i) : fbase + ((size_t)(gg - NP) * fchunk + (size_t)i * fpiece)));
         const unsigned vo = (unsigned)((pj ? poff : foff) * 4);
         asm volatile("" : "+s"(ub));
         FFN_GLDS16(ub + vo, dstp);
@@ -426,6 +436,51 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * g[r] + be[r];
             *reinterpret_cast<f32x4f*>(op + 16 * t) = o;
+            if (QKV) y[t] = o;
+        }
+    } else if (QKV) {       // rows past M feed unstored outputs: any finite values
+#pragma unroll
+        for (int t = 0; t < 16; ++t) y[t] = f32x4f{0.f, 0.f, 0.f, 0.f};
+    }
+    if (QKV) {
+        // ---- the next layer's q | k | v projection of the tile's output rows (still in registers, in the B-operand
+        // layout): NQ chunks of 32 output channels in the projection phase's format, stored from the accumulators
+        float* qrow = p.QKV + (size_t)my_row * p.ldq + 4 * lg;
+        for (int g = 0; g < NQ; ++g) {
+            const float* st = FFN_STAGE_OF(NP + nc + g);
+            f32x4f ha[2], hb[2];
+            ha[0] = f32x4f{0.f, 0.f, 0.f, 0.f}; hb[0] = ha[0];
+            ha[1] = ha[0]; hb[1] = ha[0];
+            wa = FFN_RD(st, 0); wb = FFN_RD(st, 256); va = FFN_RD(st, 4096); vb = FFN_RD(st, 4096 + 256);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                FFN_SB();
+                asm volatile("" : "+v"(wa), "+v"(wb), "+v"(va), "+v"(vb));
+                FFN_SB();
+                if (u < 7) {
+                    na = FFN_RD(st, (2 * u + 2) * 256); nb = FFN_RD(st, (2 * u + 3) * 256);
+                    nva = FFN_RD(st, 4096 + (2 * u + 2) * 256); nvb = FFN_RD(st, 4096 + (2 * u + 3) * 256);
+                }
+                FFN_SB();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    FFN_MFMA(ha[r & 1], wa[r], y[2 * u][r])
+                    FFN_MFMA(hb[r & 1], va[r], y[2 * u][r])
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    FFN_MFMA(ha[r & 1], wb[r], y[2 * u + 1][r])
+                    FFN_MFMA(hb[r & 1], vb[r], y[2 * u + 1][r])
+                }
+                if (u & 1) stream_piece(NP + nc + g + 2, u >> 1);
+                if (u < 7) { wa = na; wb = nb; va = nva; vb = nvb; }
+            }
+            FFN_SB();
+            if (my_row < M) {
+                *reinterpret_cast<f32x4f*>(qrow + 32 * g) = (ha[0] + ha[1]) + *reinterpret_cast<const f32x4f*>(qbs + 32 * g + 4 * lg);
+                *reinterpret_cast<f32x4f*>(qrow + 32 * g + 16) = (hb[0] + hb[1]) + *reinterpret_cast<const f32x4f*>(qbs + 32 * g + 16 + 4 * lg);
+            }
+            FFN_END_CHUNK()
         }
     }
     sb = (sb + G) % FFN_NST;
@@ -443,18 +498,23 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
 #undef FFN_RD
 
 bool ffn_fused_supported(int ff) { return ff >= 32 && ff % 16 == 0 && ff <= 4096; }
+bool ffn_fused_qkv_fits(int ff, int n_qkv) {
+    return ffn_fused_supported(ff) && n_qkv >= 32 && n_qkv % 32 == 0 &&
+           (size_t)(FFN_NST * FFN_STAGE + ff + 6 * 256 + n_qkv) * sizeof(float) <= 160 * 1024;
+}
 
-template <bool PROJ>
+template <bool PROJ, bool QKV>
 static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256) * sizeof(float);
+    const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
+    CONE_REQUIRE(lds <= 160 * 1024, "fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff, a.n_qkv);
     // once per process: the opt-in to > 64 KiB of LDS (a property of the code object) and the CU count that sizes
     // the persistent grid (one workgroup per CU: 132 KiB of LDS, 512 threads at <= 256 VGPRs)
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     static int n_cu = 0;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (FFN_NST * FFN_STAGE + 4096 + 6 * 256) * (int)sizeof(float));
+        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
         int dev = 0;
         if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
         if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -463,8 +523,9 @@ static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     const int tiles = (a.M + FFN_ROWS - 1) / FFN_ROWS;
     const int grid = tiles < n_cu ? tiles : n_cu;
     // FLOPs of a record: 4 * M * ff * 256 for the block, + 2 * M * 256 * 256 with the projection
-    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff, 256, a.M_dev, s);
-    hipLaunchKernelGGL(ffn_fused_kernel<PROJ>, dim3((unsigned)grid), dim3(512), lds, s, a);
+    // (+ 2 * M * n_qkv * 256 with the fused q | k | v projection: booked as n_qkv / 2 extra hidden units)
+    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
+    hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV>), dim3((unsigned)grid), dim3(512), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -479,13 +540,14 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
     FfnArgs a{};
     a.X = X; a.ldx = ldx; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
-    return launch_ffn_t<false>(a, s);
+    return launch_ffn_t<false, false>(a, s);
 }
 
 int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
                           const float* pg, const float* pb, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* ln_g, const float* ln_b, float* OUT, int ldo, int M,
-                          const int* M_dev, int ff, hipStream_t s, const int* r_idx, const float* R2) {
+                          const int* M_dev, int ff, hipStream_t s, const int* r_idx, const float* R2, const float* Wq,
+                          const float* qb, float* QKV, int ldq, int n_qkv) {
     CONE_REQUIRE(!r_idx || R2, "fused layer tail: a gathered residual needs both source matrices");
     CONE_REQUIRE(ffn_fused_supported(ff), "fused layer tail: dim_feedforward=%d unsupported", ff);
     CONE_REQUIRE(A && Wo && bo && R && pg && pb && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused layer tail: null argument");
@@ -495,7 +557,12 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
     a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff; a.r_idx = r_idx; a.R2 = R2;
-    return launch_ffn_t<true>(a, s);
+    if (Wq) {
+        CONE_REQUIRE(qb && QKV && n_qkv >= 32 && n_qkv % 32 == 0 && ldq % 4 == 0, "fused layer tail: bad q|k|v arguments");
+        a.Wq = Wq; a.qb = qb; a.QKV = QKV; a.ldq = ldq; a.n_qkv = n_qkv;
+        return launch_ffn_t<true, true>(a, s);
+    }
+    return launch_ffn_t<true, false>(a, s);
 }
 
 }  // namespace cone

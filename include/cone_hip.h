@@ -325,8 +325,9 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  *   product as six partial products of three-piece bf16 operands (x = xh + xm + xl exactly), fp32 accumulation
  *   (ffn_split.hip).  Measured against float64: the same error as the exact-fp32 MFMA chain (1.5e-7 .. 2.4e-7 of
  *   sum |a b| vs 2.0e-7 .. 2.1e-7), at 1.65x its speed.  The default stays exact fp32.
- * "qkv_fused" (default 1; with split_bf16): the next encoder layer's q | k | v projection is computed by the fused layer
- *   tail from the registers that hold its output rows; 0 = as its own launch.  Bit-identical.
+ * "qkv_fused" (default 1): the next encoder layer's q | k | v projection is computed by the fused layer tail from the
+ *   registers that hold its output rows: 1 = on the split_bf16 path (bit-identical to the separate launch), 2 = on the
+ *   exact-fp32 path as well (measured neutral; another summation order than the GEMM launch), 0 = always its own launch.
  * "res_gather" (default 1, with ffn_fused 2 + l0_gather + pos_tables): the first encoder layer's residual rows are read
  *   by the fused layer tail straight from the projected clip / text rows through a row index; 0 = from a packed copy of
  *   the layer input written by a packing pass.  Bit-identical.

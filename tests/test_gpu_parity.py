@@ -321,6 +321,9 @@ def test_position_tables_equal_materialised_pos_path(preset):
         outs.append(inf.run_windows(model, store, opt, wt))
         model.set_option("qkv_fused", 0)         # ... with the next layer's q|k|v projection as its own launch
         outs.append(inf.run_windows(model, store, opt, wt))
+        model.set_option("split_bf16", 0)
+        model.set_option("qkv_fused", 2)         # the exact-fp32 path with q|k|v inside the fused tail as well
+        outs.append(inf.run_windows(model, store, opt, wt))
     finally:
         model.set_option("pos_tables", 1)
         model.set_option("ffn_fused", 2)
@@ -337,6 +340,7 @@ def test_position_tables_equal_materialised_pos_path(preset):
         assert torch.equal(outs[0][k], outs[5][k]), ("res_gather 0", k)         # the same rows, read from another place
         assert maxdiff(outs[0][k], outs[6][k].cpu()) < 5e-5, ("split_bf16", k)
         assert torch.equal(outs[6][k], outs[7][k]), ("qkv_fused 0", k)          # the same products in the same order
+        assert maxdiff(outs[0][k], outs[8][k].cpu()) < 5e-5, ("qkv_fused 2, fp32", k)
     safe = _safe_proposals(outs[1]["pred_spans"].cpu(), wt["vid_len"].cpu().numpy())
     d = (outs[0]["matching"] - outs[1]["matching"]).abs().cpu()
     assert float(d[safe].max()) < 5e-5
