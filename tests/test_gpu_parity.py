@@ -1121,6 +1121,26 @@ def test_cli_start_inference_on_packed_store(tmp_path):
     assert json.loads(json.dumps(fusion)) == sub["results"]
     ref, ref_miou = O.evaluate_nlq_performance_ego4d(sub["results"], gt, [0.3, 0.5], [1, 5, 10, 50, 100])
     assert np.array_equal(res, ref * 100) and float(miou) == float(ref_miou)
+    # --split_bf16 (cone_amd extension, opt-in): the same command line drives the bf16-split layer tails; same answer as
+    # the API with the option set, and every kept moment within the span / score tolerance of the default run
+    out2 = tmp_path / "out_split"
+    out2.mkdir()
+    argv2 = [a if a != str(out_dir) else str(out2) for a in argv] + ["--split_bf16"]
+    mod.EGO4D_VAL_GT = str(gt_path)
+    try:
+        inf.start_inference(argv2)
+    finally:
+        mod.EGO4D_VAL_GT = old
+    sub2 = json.loads((out2 / "inference_ego4d_val_t1_preds.json").read_text())
+    model.set_option("split_bf16", 1)
+    (fusion2, _, _), _ = inf.predict_split(model, inf.FeatureStore(eff, ann, vf, qf), eff)
+    assert json.loads(json.dumps(fusion2)) == sub2["results"]
+    same = 0
+    for a, b in zip(sub["results"], sub2["results"]):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * eff.max_v_l * eff.clip_length + 2e-4:
+            same += 1
+    assert same >= 0.9 * len(sub["results"]), same      # the rest: 4-dp rounding flips upstream of the NMS
 
 
 def test_pipeline_ignores_stale_memory():
