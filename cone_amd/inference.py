@@ -600,7 +600,8 @@ _EGO4D_KEYS = {}        # id(annotation list) -> (the list, parsed keys): the ke
 
 def _ego4d_keys(ann):
     hit = _EGO4D_KEYS.get(id(ann))
-    if hit is not None and hit[0] is ann and len(hit[1]) == len(ann):
+    if (hit is not None and hit[0] is ann and len(hit[1]) == len(ann) and len(ann)
+            and hit[2] == (ann[0]["query_id"], ann[-1]["query_id"])):       # the same list object, not edited since
         return hit[1]
     keys = []
     for meta in ann:                                                # cone/inference.py:133-140
@@ -609,7 +610,7 @@ def _ego4d_keys(ann):
         keys.append((int(parts[1]), parts[0], meta["clip_id"]))
     if len(_EGO4D_KEYS) > 64:
         _EGO4D_KEYS.clear()
-    _EGO4D_KEYS[id(ann)] = (ann, keys)
+    _EGO4D_KEYS[id(ann)] = (ann, keys, (ann[0]["query_id"], ann[-1]["query_id"]) if len(ann) else None)
     return keys
 
 
