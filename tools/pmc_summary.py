@@ -33,7 +33,8 @@ def load(path):
 # pattern").  ffn_fused_kernel reads its row tiles as 64-B row segments (4 lanes x 16 B per row and instruction): its
 # fabric requests are 64 B and FETCH_SIZE is exact -- calibrated on the encoder launches, whose algorithmic read is the
 # two (M, 256) fp32 inputs = 4.14 GB at M = 2.02 M rows against 2 x 1.8 GB counted (weights are served by the L2).
-READ_FACTOR = {"cone::ffn_fused_kernel<true>": 1.0, "cone::ffn_fused_kernel<false>": 1.0}
+READ_FACTOR = {"cone::ffn_fused_kernel<true, false>": 1.0, "cone::ffn_fused_kernel<false, false>": 1.0,
+               "cone::ffn_fused_kernel<true, true>": 1.0}
 
 src, dst = sys.argv[1], sys.argv[2]
 f = load(f"{src}/pmc_fetch/f_counter_collection.csv")
