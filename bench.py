@@ -98,9 +98,16 @@ def pmc_traffic(kernel):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
-                t = json.load(f)["cone::" + kernel]
-        except (OSError, KeyError, ValueError):
+                tab = json.load(f)
+        except (OSError, ValueError):
             continue
+        t = tab.get("cone::" + kernel)
+        if t is None:       # template arguments may have been added since: same kernel name and first argument
+            stem = "cone::" + kernel.split(",")[0].rstrip(">")
+            cands = [v for k, v in tab.items() if k.startswith(stem)]
+            if not cands:
+                continue
+            t = max(cands, key=lambda v: v.get("launches", 0))
         return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                 "traffic_source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
     return {"traffic": None}
