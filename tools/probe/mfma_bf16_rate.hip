@@ -1,5 +1,6 @@
 // What does a bare v_mfma_f32_16x16x32_bf16 stream reach when issued the way ffn_split.hip issues it: groups of six
 // dependent MFMAs on one accumulator, 16 groups per "phase", 1 / 2 waves per SIMD, zero or random-ish operands?
+// Build: hipcc --offload-arch=gfx950 -O3 mfma_bf16_rate.hip -o mfma_bf16_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f4 __attribute__((ext_vector_type(4)));
