@@ -241,3 +241,31 @@ def test_debug_and_results_dir_options(tmp_path):
     opt = parse_test_options(base + ["--eval_results_dir", str(tmp_path), "--debug", "--results_root", "a/b"])
     assert opt.results_dir == str(tmp_path) and opt.debug and opt.num_workers == 0
     assert opt.results_root == os.path.join("a", "debug_results")             # cone/config.py:179-181
+
+
+def test_three_piece_bf16_split_is_exact_and_six_products_carry_fp32():
+    """The arithmetic claim behind the opt-in split_bf16 path (cone_amd/csrc/ffn_split.hip), checked on the CPU with torch's
+    bfloat16 (round to nearest even, like v_cvt_pk_bf16_f32): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) reconstruct
+    every normal fp32 value exactly, and the six kept piece products differ from the fp32 product by <= 2^-22 of it."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(200000, generator=g) * 3, torch.randn(50000, generator=g) * 1e-3,
+                   torch.randn(50000, generator=g) * 1e4, torch.tensor([1.0, -1.0, 0.0, 3.14159274, 1e-30, 65504.0, 1 + 2 ** -23])])
+    w = torch.randn(x.numel(), generator=g) / 16
+
+    def split(t):
+        h = t.to(torch.bfloat16).float()
+        m = (t - h).to(torch.bfloat16).float()
+        lo = (t - h - m).to(torch.bfloat16).float()
+        return h, m, lo
+    xh, xm, xl = split(x)
+    assert torch.equal((xh.double() + xm.double() + xl.double()).float(), x)          # exact: 8 + 8 + 8 significant bits
+    wh, wm, wl = split(w)
+    assert torch.equal((wh.double() + wm.double() + wl.double()).float(), w)
+    six = (xl.double() * wh + xh.double() * wl + xm.double() * wm + xh.double() * wm + xm.double() * wh + xh.double() * wh)
+    exact = x.double() * w.double()
+    rel = ((six - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0]
+    assert float(rel.max()) <= 2.0 ** -22, float(rel.max())
+    # two pieces / three products would not do: ~2^-16
+    three = xh.double() * wm + xm.double() * wh + xh.double() * wh
+    assert float(((three - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0].max()) > 2.0 ** -18
