@@ -589,10 +589,10 @@ def _gc_paused():
             gc.enable()
 
 
-def format_results(ann, opt, rows, n):
+def format_results(ann, opt, rows, n, skeletons=None):
     """A16 (cone/inference.py:130-202): the three submission lists from the kept rows."""
     with _gc_paused():
-        return _format_results(ann, opt, rows, n)
+        return _format_results(ann, opt, rows, n, skeletons)
 
 
 _EGO4D_KEYS = {}        # id(annotation list) -> (the list, parsed keys): the keys depend on the annotation file only
@@ -614,14 +614,25 @@ def _ego4d_keys(ann):
     return keys
 
 
-def _format_results(ann, opt, rows, n):
+def result_skeletons(ann, opt):
+    """The three submission lists with every field but ``predicted_times`` -- they depend on the annotations only, so the
+    host builds them while the GPU is still working on the split (predict_split)."""
+    with _gc_paused():
+        if opt.dset_name == "ego4d":
+            keys = _ego4d_keys(ann)
+            return tuple([{"query_idx": k[0], "annotation_uid": k[1], "predicted_times": None, "clip_uid": k[2]}
+                          for k in keys] for _ in range(3))
+        return tuple([{"query_id": m["query_id"], "predicted_times": None, "video_id": m["video_id"]} for m in ann]
+                     for _ in range(3))
+
+
+def _format_results(ann, opt, rows, n, skeletons=None):
     lists = _rows_to_lists(rows, n)
-    if opt.dset_name == "ego4d":
-        keys = _ego4d_keys(ann)
-        return tuple([{"query_idx": k[0], "annotation_uid": k[1], "predicted_times": pt, "clip_uid": k[2]}
-                      for k, pt in zip(keys, lists[t])] for t in range(3))
-    return tuple([{"query_id": m["query_id"], "predicted_times": pt, "video_id": m["video_id"]}
-                  for m, pt in zip(ann, lists[t])] for t in range(3))
+    out = skeletons if skeletons is not None else result_skeletons(ann, opt)
+    for t in range(3):
+        for item, pt in zip(out[t], lists[t]):
+            item["predicted_times"] = pt
+    return out
 
 
 def query_chunks(nq: int, opt):
@@ -666,10 +677,11 @@ def predict_split(model, store: FeatureStore, opt):
         return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
     chunks = query_chunks(len(store.ann), opt)
     if len(chunks) == 1:
-        dp = device_pipeline(model, store, opt)
+        dp = device_pipeline(model, store, opt)         # enqueued; nothing in it waits for the GPU
+        skel = result_skeletons(store.ann, opt)         # host work that needs no result: under the GPU's time
         torch.cuda.synchronize()
         dp["model_seconds"] = time.time() - t0
-        return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
+        return format_results(store.ann, opt, dp["rows"], dp["n"], skel), dp
     # clip-side work once for the split, shared by the chunks (they are views of one arena)
     store.index_tensors()
     win_idx = prefilter(model, store, opt)
