@@ -57,7 +57,10 @@ def rec_flops(kind, a, b, c):
     if kind == 9:
         f += 2.0 * a * 256 * 256
     return f
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_PREFILTER_FILES = ("r03_pmc_prefilter.json",)
 
 
 def collect_profile():
@@ -89,12 +92,12 @@ def reference_window_flops(lv, lq, dv, dt, d=256, ff=1024, nq=5, enc=2, dec=2):
     return proj + enc_f + dec_f + rest
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, files=PMC_FILES):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/
-    rNN_pmc_traffic.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc
-    runs; counters cannot be read from inside the process).  Same averaging as `achieved`: over all launches of
-    the kernel in a step."""
-    for name in PMC_FILES:
+    rNN_pmc_*.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE -- the guide's gfx950 read
+    correction -- from separate rocprofv3 --pmc runs; counters cannot be read from inside the process).  Same
+    averaging as `achieved`: over all launches of the kernel in the profiled command."""
+    for name in files:
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -109,7 +112,9 @@ def pmc_traffic(kernel):
                 continue
             t = max(cands, key=lambda v: v.get("launches", 0))
         return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
-                "traffic_source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+                "traffic_read": round(t["read_bytes_per_launch"]), "traffic_write": round(t["write_bytes_per_launch"]),
+                "traffic_source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; reads = 2 x "
+                                  "FETCH_SIZE, the guide's gfx950 correction)"}
     return {"traffic": None}
 
 
@@ -137,6 +142,14 @@ def roofline_from_profile(rec):
             "flops_per_launch": round(d["flops"] / d["launches"]),
             "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
     roof.update(pmc_traffic(KERNEL_NAMES[dom]))
+    if dom in (8, 9):
+        # algorithmic HBM bytes of a fused layer tail over M rows: its (M, 256) fp32 input rows (kind 9: attention rows +
+        # residual rows), the (M, 256) output rows; the weights (<= 1.3 MB) are served by the L2 / Infinity Cache
+        rows_io = 3 if dom == 9 else 2
+        alg = rows_io * 1024.0 * sum(a for kind, a, b, c, ms in rec if int(kind) == dom) / d["launches"]
+        roof["algorithmic_bytes"] = round(alg)
+        if roof.get("traffic"):
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 3)
     shapes = {}
     for kind, a, b, c, ms in rec:       # the dominant kernel by (N, K): which layers pull the average down
         if int(kind) == dom and a >= 65536:
@@ -195,10 +208,12 @@ def _timed(fn, steps, warmup):
 
 def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
     """BASELINE configs[2]: MAD-scale long video (ctx_l x 512 fp32 = 12.7 GB resident in HBM, ~100 k windows of 125
-    clips), frame scores + window max + stable top-30 for 1 query (streaming kernel) and for 64 queries at once
-    (fp32-MFMA tiles with the queries as LDS operand slabs, frames read once).  Roofline: SURVEY 8d's algorithmic bytes 4*ctx_l*dv + Q*4*(dv + num_window)
-    over the hipEvent time of the frame-score kernel(s) of one query batch (the dominant kernel, > 75 % of the
-    path) and, as `path_frac`, over the wall time of the whole pre-filter call sequence."""
+    clips), window scores (frame scores with the window max fused into the stream: no (nq, ctx_l) matrix is written)
+    + stable top-30 for 1 query (streaming kernel) and for 64 queries at once (fp32-MFMA tiles with the queries as LDS
+    operand slabs, frames read once).  Roofline: SURVEY 8d's algorithmic bytes 4*ctx_l*dv + Q*4*(dv + num_window)
+    over the hipEvent time of the frame-score kernel(s) of one query batch (the dominant kernel, > 85 % of the
+    path) and, as `path_frac`, over the wall time of the whole pre-filter call sequence; `traffic` = HBM bytes per
+    launch from the committed rocprofv3 PMC passes over tools/prefilter_bench.py (profiles/r03_pmc_prefilter.json)."""
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev).manual_seed(0)
@@ -211,7 +226,7 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
         txt = ops.l2_normalize(torch.randn(nq, dv, device=dev, generator=g), 0.0)
 
         def call():
-            fs, ws = ops.prefilter_scores(vid, txt, W)
+            _, ws = ops.prefilter_scores(vid, txt, W, frame_scores=False)
             return ops.topk_windows(ws, topk)
         _timed(call, 1, 2)
         lib.cone_prof_enable(1)
@@ -221,12 +236,14 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
         k_ms = float(rec[np.isin(rec[:, 0], (0, 4))][:, 4].sum()) / steps        # frame-score launches of one call
         alg = 4.0 * ctx_l * dv + nq * 4.0 * (dv + nw)
         ach = alg / (k_ms * 1e-3) / 1e9
+        kernel = f"frame_score_kernel<{dv // 256}, 1, 4, 1>" if nq < 8 else "frame_score_mq_kernel<4, false>"
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg)}
+        roof.update(pmc_traffic(kernel, PMC_PREFILTER_FILES))
+        if roof.get("traffic"):
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 3)
         out[f"q{nq}"] = {"queries": nq, "ms_per_call": round(dt * 1e3, 3), "windows_per_s": round(nw * nq / dt, 1),
-                         "frame_score_kernel_ms": round(k_ms, 3),
-                         "kernel": KERNEL_NAMES[4] if nq < 8 else "frame_score_mq_kernel",
-                         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                      "algorithmic_bytes": int(alg)},
+                         "frame_score_kernel_ms": round(k_ms, 3), "kernel": kernel, "roofline": roof,
                          "path_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}
         del txt
     del vid
@@ -262,7 +279,7 @@ def bench_config5(ctx_l=33_000, queries=64, steps=10):
     try:
         model.set_option("split_bf16", 1)       # the opt-in path on the same workload (not the config's figure)
         dts, _ = _timed(lambda: inf.predict_split(model, store, opt), steps, 3)
-    except _lib.ConeHipError:
+    except Exception:
         dts = None
     return {"workload": f"BASELINE.json configs[4] on 1 GPU: {queries} queries x one MAD-length video (ctx_l {ctx_l}, "
                         f"d 512, window_len 125), top-30 => {dp['n_windows']} windows, stages A-C + JSON rows",
@@ -285,11 +302,15 @@ def main():
                     help="diagnostics: flip an A/B switch of the model handle (cone_model_set_option), e.g. pos_tables=0")
     ap.add_argument("--window_batch", type=int, default=32768)
     ap.add_argument("--pipeline_tail", type=float, default=None,
-                    help="fraction of the queries in the tail chunk of the host/GPU pipeline (default 1/8; 0 = one chunk)")
+                    help="fraction of the queries in the tail chunk of the host/GPU pipeline (default: none = one chunk)")
     ap.add_argument("--need_saliency", action="store_true",
-                    help="A/B: also run the saliency head (the reference computes it and never reads it)")
+                    help="A/B: the headline step also runs the saliency head and the intermediate decoder layers' heads "
+                         "(the reference computes them and never reads them); the default line reports that figure as "
+                         "ms_per_step_full_forward next to the headline")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_extras", action="store_true", help="skip the configs[0]/[2]/[4] figures (N = 1)")
+    ap.add_argument("--no_extras", action="store_true",
+                    help="only the headline timed region (profiling runs): skip the full-forward region, the split_bf16 "
+                         "region and the configs[0]/[2]/[4] figures")
     ap.add_argument("--cpu_queries", type=int, default=400)
     args = ap.parse_args()
 
@@ -318,7 +339,7 @@ def main():
 
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
                    window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks, pipeline_tail=args.pipeline_tail,
-                   need_saliency=args.need_saliency)
+                   need_saliency=args.need_saliency, need_aux=args.need_saliency)
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -373,48 +394,8 @@ def main():
     dt, rec, (out, dp) = timed_region(step)
     n_windows = dp["n_windows"]
 
-    split = None
-    if world == 1 and not args.no_extras and not any(kv.startswith("split_bf16") for kv in args.set_option):
-        # OPT-IN path, reported beside the headline (which stays exact fp32): every layer tail on the bf16 matrix cores,
-        # each fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation (ffn_split.hip)
-        try:
-            ref_out = {k: v.clone() for k, v in dp["outputs"].items() if k in ("pred_logits", "pred_spans")}
-            model.set_option("split_bf16", 1)
-            sdt, srec, (_, sdp) = timed_region(step)
-            sroof, _ = roofline_from_profile(srec)
-            split = {"note": "opt-in model option split_bf16=1 (NOT the headline): fp32 products of the fused layer tails as "
-                             "six bf16 MFMA partial products of three-piece operands (x = xh + xm + xl exactly), fp32 "
-                             "accumulation; error against float64 equal to the fp32 MFMA chain's (tools/probe/"
-                             "split_bf16_probe.hip, tests); same reference fixtures, same tolerances",
-                     "ms_per_step": round(sdt / args.steps * 1e3, 2),
-                     "value": round(sdp["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
-                     "queries_per_s": round(args.queries * args.steps / sdt, 1),
-                     "layer_tail_tflops_fp32_equivalent": sroof["achieved"] if sroof else None,
-                     "max_abs_diff_vs_default": {k: float((sdp["outputs"][k] - v).abs().max()) for k, v in ref_out.items()}}
-            del ref_out, sdp
-        except _lib.ConeHipError as e:          # a model shape the split kernels do not cover: the headline is unaffected
-            split = {"note": f"split_bf16 not available for this model: {e}"}
-        finally:
-            model.set_option("split_bf16", 0)
-
-    strong = None
-    if use_dist and world > 1:
-        # BASELINE configs[3]: ONE config-2 split (the same on every rank: features replicated), sharded by window
-        from cone_amd import parallel as par
-        ann0, vf0, qf0 = (ann, vf, qf) if rank == 0 else synth.make_dataset(opt, args.queries, args.videos, seed=0)
-        store0 = store if rank == 0 else inf.FeatureStore(opt, ann0, vf0, qf0)
-
-        def strong_step():
-            return par.predict_split_distributed(model, store0, opt, mode="window", format_shard=True)
-        sdt, _, (_, sinfo) = timed_region(strong_step)
-        strong = {"config": "BASELINE.json configs[3]: ONE Ego4D-NLQ val-scale split sharded by window over the ranks, "
-                            "one RCCL all_gather of the per-window proposal rows, fusion + NMS of all queries on every "
-                            "rank, JSON rows of its own query shard on every rank",
-                  "scaling": "strong", "value": round(sinfo["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
-                  "queries_per_s": round(args.queries * args.steps / sdt, 1),
-                  "ms_per_step": round(sdt / args.steps * 1e3, 2), "n_windows": sinfo["n_windows"],
-                  "ranks_seen": dist.get_world_size(), "collectives_per_step": 1}
-
+    # ---- the headline object first: nothing below can take it down (every extra is guarded on its own)
+    res = None
     if rank == 0:
         roof, kern = roofline_from_profile(rec)
         res = {
@@ -432,16 +413,14 @@ def main():
                        "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture",
                        "outputs": "per window pred_logits, pred_spans, matching scores -> rows [st, ed, proposal, "
                                   "matching]; per query fused / proposal / matching top-5 after NMS as JSON rows"
-                                  + ("; saliency head computed too" if args.need_saliency else
-                                     "; saliency and aux (intermediate-layer) heads not computed -- the reference "
-                                     "computes them and never reads them (cone/inference.py:54-59)"),
+                                  + ("; saliency head and the intermediate decoder layer's heads (aux_outputs) computed too"
+                                     if args.need_saliency else
+                                     "; saliency and aux (intermediate-layer) heads not computed in the headline step -- the "
+                                     "reference computes them and never reads them (cone/inference.py:54-59); "
+                                     "ms_per_step_full_forward is the same step with both computed, as CONE.forward does"),
                        "ranks_seen": dist.get_world_size() if use_dist else 1},
             "roofline": roof, "kernels": kern,
         }
-        if strong is not None:
-            res["strong_scaling"] = strong
-        if split is not None:
-            res["split_bf16x3"] = split
         wt = dp.get("windows")
         if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
             fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),
@@ -452,15 +431,92 @@ def main():
                                    "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
                                    "note": "reference FLOPs (padding excluded) over the whole step time; the build "
                                            "executes fewer (de-duplicated projections, folded decoder K/V)"}
-        if world == 1 and not args.no_extras:
-            del store, dp, out
-            model._ws.buf = None
-            torch.cuda.empty_cache()
-            res["latency_config1"] = bench_latency_config1()
-            res["config5"] = bench_config5()
-            res["prefilter_mad"] = bench_prefilter_mad()
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_queries, max(1, args.cpu_queries * args.videos // args.queries))
+
+    def note(name, value):
+        if res is not None:
+            res[name] = value
+
+    def guarded(name, fn):
+        """Run one extra; a failure becomes {"error": ...} under its name instead of taking the line down."""
+        try:
+            v = fn()
+        except Exception as e:              # noqa: BLE001 -- torch OOM / RuntimeError / KeyError alike
+            v = {"error": repr(e)[:500]}
+            try:
+                torch.cuda.synchronize()
+            except Exception:               # noqa: BLE001
+                pass
+        if v is not None:
+            note(name, v)
+
+    # ---- the reference's full CONE.forward in the eval path (cone/model.py:112-127): saliency_scores + aux_outputs too
+    if not args.need_saliency and not args.no_extras:
+        def full_forward():
+            opt.need_saliency = opt.need_aux = True
+            try:
+                fdt, _, (_, fdp) = timed_region(step)
+            finally:
+                opt.need_saliency = opt.need_aux = False
+            note("ms_per_step_full_forward", round(fdt / args.steps * 1e3, 2))
+            note("value_full_forward", round(world * fdp["n_windows"] * args.steps / fdt, 1))
+        guarded("full_forward_error", full_forward)
+
+    if world == 1 and not args.no_extras and not any(kv.startswith("split_bf16") for kv in args.set_option):
+        # OPT-IN path, reported beside the headline (which stays exact fp32): every layer tail on the bf16 matrix cores,
+        # each fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation (ffn_split.hip)
+        def split_path():
+            try:
+                outs = dp.get("outputs")        # (absent when the step ran as several pipeline chunks)
+                ref_out = {k: v.clone() for k, v in outs.items() if k in ("pred_logits", "pred_spans")} if outs else {}
+                model.set_option("split_bf16", 1)
+                sdt, srec, (_, sdp) = timed_region(step)
+                sroof, _ = roofline_from_profile(srec)
+                diffs = {k: float((sdp["outputs"][k] - v).abs().max()) for k, v in ref_out.items()} if sdp.get("outputs") else None
+                return {"note": "opt-in model option split_bf16=1 (NOT the headline): fp32 products of the fused layer tails as "
+                                "six bf16 MFMA partial products of three-piece operands (x = xh + xm + xl exactly), fp32 "
+                                "accumulation; error against float64 equal to the fp32 MFMA chain's (tools/probe/"
+                                "split_bf16_probe.hip, tests); same reference fixtures, same tolerances",
+                        "ms_per_step": round(sdt / args.steps * 1e3, 2),
+                        "value": round(sdp["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
+                        "queries_per_s": round(args.queries * args.steps / sdt, 1),
+                        "layer_tail_tflops_fp32_equivalent": sroof["achieved"] if sroof else None,
+                        "max_abs_diff_vs_default": diffs}
+            except _lib.ConeHipError as e:      # a model shape the split kernels do not cover
+                return {"note": f"split_bf16 not available for this model: {e}"}
+            finally:
+                model.set_option("split_bf16", 0)
+        guarded("split_bf16x3", split_path)
+
+    if use_dist and world > 1:
+        # BASELINE configs[3]: ONE config-2 split (the same on every rank: features replicated), sharded by window
+        from cone_amd import parallel as par
+        ann0, vf0, qf0 = (ann, vf, qf) if rank == 0 else synth.make_dataset(opt, args.queries, args.videos, seed=0)
+        store0 = store if rank == 0 else inf.FeatureStore(opt, ann0, vf0, qf0)
+
+        def strong_step():
+            return par.predict_split_distributed(model, store0, opt, mode="window", format_shard=True)
+        sdt, _, (_, sinfo) = timed_region(strong_step)
+        note("strong_scaling", {
+            "config": "BASELINE.json configs[3]: ONE Ego4D-NLQ val-scale split sharded by window over the ranks, "
+                      "one RCCL all_gather of the per-window proposal rows, fusion + NMS of all queries on every "
+                      "rank, JSON rows of its own query shard on every rank",
+            "scaling": "strong", "value": round(sinfo["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
+            "queries_per_s": round(args.queries * args.steps / sdt, 1),
+            "ms_per_step": round(sdt / args.steps * 1e3, 2), "n_windows": sinfo["n_windows"],
+            "ranks_seen": dist.get_world_size(), "collectives_per_step": 1})
+        del store0
+
+    if world == 1 and not args.no_extras:
+        del store, dp, out
+        model._ws.buf = None
+        torch.cuda.empty_cache()
+        guarded("latency_config1", bench_latency_config1)
+        guarded("config5", bench_config5)
+        guarded("prefilter_mad", bench_prefilter_mad)
+    if world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
+        guarded("cpu_baseline", lambda: cpu_baseline(opt, sd, args.cpu_queries,
+                                                     max(1, args.cpu_queries * args.videos // args.queries)))
+    if rank == 0:
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -74,8 +74,9 @@ _SIGNATURES = {
     "cone_l2_normalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                          C.c_void_p]),
     "cone_num_windows": (C.c_int64, [C.c_int64, C.c_int]),
+    "cone_prefilter_scores_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "cone_prefilter_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_prefilter_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -171,7 +172,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 2:
+    if lib.cone_abi_version() != 3:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -33,6 +33,7 @@ def _compile(src):
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
         return obj
     extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
+    extra += os.environ.get("CONE_HIPCC_FLAGS", "").split()     # A/B builds on the GPU box (tools/ab_variants.sh)
     cmd = ["hipcc", *FLAGS, *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

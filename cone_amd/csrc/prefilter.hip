@@ -5,7 +5,8 @@
 //                        One wavefront streams whole rows with coalesced 16-B lane loads (1 KiB per
 //                        wave-instruction), RPW rows in flight per wave, QG query vectors held in
 //                        registers; per-(row,query) partial sums are combined with wave shuffles.
-//   window_max_kernel  : win[q][i] = max(frame_scores[q][max((i-1)S,0) : min((i-1)S+W, ctx_l)])
+//                        The wave keeps the running max of each half-block (S frames) it streams: the window max is
+//                        fused (window_combine_kernel), the frame scores are written only on request.
 //   topk_kernel        : first k entries of the stable descending sort of each score row.
 #include <mutex>
 
@@ -13,14 +14,22 @@
 
 namespace cone {
 
-template <int VPL /* float4 per lane per row: dv = 256*VPL */, int QG, int RPW>
-__global__ __launch_bounds__(256) void frame_score_kernel(const float* __restrict__ vid, int64_t ctx_l,
+// Fused frame scores + window max.  S = int(W/2), so window i = half-blocks i-1 and i (block h = frames [hS, (h+1)S)) plus,
+// when W is odd, the first frame of block i+1: a wave keeps the running max of the half-block it streams in registers and
+// writes ONE value per (query, half-block) -- hm -- and the block's first frame score -- fr; window_combine_kernel takes
+// win[i] = max(hm[i-1], hm[i], fr[i+1]) from those (max is order-free: bit-identical to the max over the stored frame
+// scores).  The (nq, ctx_l) frame-score matrix is written only when the caller asks for it (fs != nullptr): the
+// reference needs it for nothing but this max (cone/inference.py:284-295).
+//   WPH = 1: one wave per half-block, grid-stride (long videos: every wave streams contiguous 4-row groups of its blocks);
+//   WPH = 4: the four waves of a workgroup share one half-block and combine through LDS (short videos: 4x the waves).
+template <int VPL /* float4 per lane per row: dv = 256*VPL */, int QG, int RPW, int WPH>
+__global__ __launch_bounds__(256) void frame_score_kernel(const float* __restrict__ vid, int64_t ctx_l, int S, int64_t nh,
                                                           const float* __restrict__ txt, int q0, int nq,
-                                                          float* __restrict__ fs) {
-    constexpr int DV = 256 * VPL;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
+                                                          float* __restrict__ fs, float* __restrict__ hm,
+                                                          float* __restrict__ fr) {
+    constexpr int DV = 256 * VPL, UPB = 4 / WPH;
+    __shared__ float red[4][QG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % WPH;
     float4 q[QG][VPL];
 #pragma unroll
     for (int g = 0; g < QG; ++g)
@@ -29,69 +38,73 @@ __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restric
             const int qi = min(q0 + g, nq - 1);
             q[g][v] = reinterpret_cast<const float4*>(txt + (size_t)qi * DV)[lane + 64 * v];
         }
-    for (int64_t r0 = wave_id * RPW; r0 < ctx_l; r0 += n_waves * RPW) {
-        float4 x[RPW][VPL];
+    for (int64_t h = (int64_t)blockIdx.x * UPB + wave / WPH; h < nh; h += (int64_t)gridDim.x * UPB) {
+        const int64_t r_lo = h * S;
+        const int n = (int)min((int64_t)S, ctx_l - r_lo);            // frames of this half-block
+        const float* base = vid + r_lo * DV;
+        float m[QG];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int64_t row = min(r0 + r, ctx_l - 1);
+        for (int g = 0; g < QG; ++g) m[g] = -INFINITY;
+        for (int j0 = sub * RPW; j0 < n; j0 += WPH * RPW) {
+            float4 x[RPW][VPL];
 #pragma unroll
-            for (int v = 0; v < VPL; ++v)
-                x[r][v] = reinterpret_cast<const float4*>(vid + row * DV)[lane + 64 * v];
-        }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                float s = 0.f;
+            for (int r = 0; r < RPW; ++r) {
+                const int row = min(j0 + r, n - 1);
 #pragma unroll
                 for (int v = 0; v < VPL; ++v)
-                    s += (x[r][v].x * q[g][v].x + x[r][v].y * q[g][v].y) +
-                         (x[r][v].z * q[g][v].z + x[r][v].w * q[g][v].w);
-                s = wave_sum(s);
-                if (lane == 0 && r0 + r < ctx_l && q0 + g < nq) fs[(size_t)(q0 + g) * ctx_l + r0 + r] = s;
+                    x[r][v] = reinterpret_cast<const float4*>(base + (size_t)row * DV)[lane + 64 * v];
             }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v)
+                        s += (x[r][v].x * q[g][v].x + x[r][v].y * q[g][v].y) +
+                             (x[r][v].z * q[g][v].z + x[r][v].w * q[g][v].w);
+                    s = wave_sum(s);
+                    if (j0 + r < n) {
+                        m[g] = fmaxf(m[g], s);
+                        if (lane == 0 && q0 + g < nq) {
+                            if (fs) fs[(size_t)(q0 + g) * ctx_l + r_lo + j0 + r] = s;
+                            if (r == 0 && j0 == 0) fr[(size_t)(q0 + g) * nh + h] = s;      // the block's first frame
+                        }
+                    }
+                }
+        }
+        if (WPH == 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    if (q0 + g < nq) hm[(size_t)(q0 + g) * nh + h] = m[g];
+            }
+        } else {                                    // h is uniform over the workgroup: the barriers are too
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) red[wave][g] = m[g];
+            }
+            __syncthreads();
+            if (wave == 0 && lane < QG && q0 + lane < nq)
+                hm[(size_t)(q0 + lane) * nh + h] = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+            __syncthreads();
+        }
     }
 }
 
-// One wave per window: coalesced reads of its <= W frame scores, wave max (exact, order-free).
-__global__ __launch_bounds__(256) void window_max_kernel(const float* __restrict__ fs, int64_t ctx_l, int W,
-                                                         int S, int64_t num_window, float* __restrict__ win) {
-    const int q = blockIdx.y, lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= num_window) return;
-    const int64_t s = max((i - 1) * S, (int64_t)0);
-    const int64_t e = min((i - 1) * S + W, ctx_l);
-    const float* f = fs + (size_t)q * ctx_l;
+// win[q][i] = max(hm[q][i-1], hm[q][i], W odd ? fr[q][i+1] : -inf) over the half-blocks that exist (0 <= h < nh):
+// window i covers frames [max((i-1)S, 0), min((i-1)S + W, ctx_l)), cone/inference.py:286-292.
+__global__ __launch_bounds__(256) void window_combine_kernel(const float* __restrict__ hm, const float* __restrict__ fr,
+                                                             int64_t nh, int odd, float* __restrict__ win) {
+    const int q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > nh) return;                                                  // num_window = nh + 1
+    const float* a = hm + (size_t)q * nh;
     float m = -INFINITY;
-    for (int64_t t = s + lane; t < e; t += 64) m = fmaxf(m, f[t]);
-    m = wave_max(m);
-    if (lane == 0) win[(size_t)q * num_window + i] = m;
-}
-
-// Long score rows (MAD scale: 100 k windows x up to 64 queries): one workgroup per 64 consecutive windows of one query
-// stages the (64 + 1) S + 1 frame scores they cover in LDS with coalesced loads (every frame score is read once from
-// memory instead of once per window it belongs to) and each wave takes its windows' maxima from there.
-constexpr int WM_WPB = 64;
-__global__ __launch_bounds__(256) void window_max_tiled_kernel(const float* __restrict__ fs, int64_t ctx_l, int W, int S,
-                                                               int64_t num_window, float* __restrict__ win) {
-    extern __shared__ float wm_s[];
-    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t w0 = (int64_t)blockIdx.x * WM_WPB;
-    const int64_t f_lo = max((w0 - 1) * S, (int64_t)0);
-    const int64_t w_hi = min(w0 + WM_WPB, num_window);                  // exclusive
-    const int64_t f_hi = min((w_hi - 2) * S + W, ctx_l);                // end of the last window's range
-    const float* f = fs + (size_t)q * ctx_l;
-    const int n = (int)(f_hi - f_lo);
-    for (int i = tid; i < n; i += 256) wm_s[i] = f[f_lo + i];
-    __syncthreads();
-    for (int64_t i = w0 + wave; i < w_hi; i += 4) {
-        const int s = (int)(max((i - 1) * S, (int64_t)0) - f_lo);
-        const int e = (int)(min((i - 1) * S + W, ctx_l) - f_lo);
-        float m = -INFINITY;
-        for (int t = s + lane; t < e; t += 64) m = fmaxf(m, wm_s[t]);
-        m = wave_max(m);
-        if (lane == 0) win[(size_t)q * num_window + i] = m;
-    }
+    if (i >= 1) m = a[i - 1];
+    if (i < nh) m = fmaxf(m, a[i]);
+    if (odd && i + 1 < nh) m = fmaxf(m, fr[(size_t)q * nh + i + 1]);
+    win[(size_t)q * (nh + 1) + i] = m;
 }
 
 // Two-level stable top-k for long rows: level 1 -- one workgroup per chunk of TK_CH scores keeps the chunk in LDS and
@@ -268,10 +281,11 @@ __device__ __forceinline__ int pf_swz16(int row) { return (0x1230 >> (((row >> 2
 
 constexpr int MQ_NT = 768;     // 12 waves: the one workgroup a CU holds (128 KiB of LDS) runs three waves per SIMD
 
-template <int QT /* query tiles of 16 */>
+template <int QT /* query tiles of 16 */, bool FS /* also write the frame scores */>
 __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* __restrict__ vid, int64_t ctx_l, int dv,
-                                                                const float* __restrict__ txt, int q0, int nq,
-                                                                float* __restrict__ fs) {
+                                                                int S, int64_t nh, const float* __restrict__ txt, int q0,
+                                                                int nq, float* __restrict__ fs, float* __restrict__ hm,
+                                                                float* __restrict__ fr) {
     extern __shared__ __attribute__((aligned(16))) float qs[];          // [QT][dv / 16] slabs of [16 queries][16 floats]
     const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
@@ -286,81 +300,124 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* _
     }
     __syncthreads();
     const int rd = li * 16 + ((lg ^ pf_swz16(li)) << 2);
-    const int64_t n_tiles = (ctx_l + 15) >> 4;
-    const int64_t wave_id = (int64_t)blockIdx.x * (MQ_NT / 64) + (tid >> 6), n_waves = (int64_t)gridDim.x * (MQ_NT / 64);
     const int nchunk = dv >> 7;                                          // 128-channel chunks (8 slabs)
-    for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
-        const int64_t f0 = t * 16;
-        const int64_t frame = min(f0 + li, ctx_l - 1);
-        const float* fp = vid + frame * dv + 4 * lg;
+    constexpr int NW = MQ_NT / 64;
+    // A wave owns whole half-blocks (frames [hS, (h+1)S)): ceil(S / 16) tiles of 16 frames, the last one partial (its spare
+    // lanes re-read the block's last frame and are masked), running max per (query, lane) in registers, one value per
+    // (query, half-block) out.  The waves of a workgroup take consecutive half-blocks, so their 4-B results of one query
+    // fall into one cache line.  The stream is software-pipelined across tiles AND half-blocks: the first 128 channels of
+    // the next tile are in flight under the last chunk of this one.
+    const int64_t h_step = (int64_t)gridDim.x * NW;
+    int64_t h = (int64_t)blockIdx.x * NW + (tid >> 6);
+    if (h >= nh) return;
+    int64_t r_lo = h * S, r_hi = min(r_lo + S, ctx_l);
+    int64_t f0 = r_lo;
+    const float* fp = vid + min(f0 + li, r_hi - 1) * dv + 4 * lg;
+    pf4 cur[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+    pf4 mx[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mx[qt] = pf4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    while (true) {
+        // where the stream goes after this tile
+        int64_t h2 = h, f2 = f0 + 16, lo2 = r_lo, hi2 = r_hi;
+        if (f2 >= r_hi) { h2 = h + h_step; lo2 = h2 * S; hi2 = min(lo2 + S, ctx_l); f2 = lo2; }
+        const bool more = h2 < nh;
+        const float* fp2 = more ? vid + min(f2 + li, hi2 - 1) * dv + 4 * lg : fp;
         pf4 acc[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) acc[qt] = pf4{0.f, 0.f, 0.f, 0.f};
-        pf4 cur[8], nxt[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+        // Burst loads (the 8 x 64 B of a row's next 128 channels back to back: whole 128-B lines), compiler-scheduled MFMAs.
+        // Measured on one box at 64 queries (round 3, tools/ab_variants.sh): this loop 3.76 - 3.79 ms; the same with the query
+        // fragments software-pipelined and the MFMA order pinned 3.97; with a rolling per-slab prefetch instead of the bursts
+        // 4.07 - 4.10.  PMC: 84 % MFMA-busy at an effective 1.85 GHz -- the exact-fp32 matrix pipe under a 3.4 TB/s stream
+        // is power-limited, three waves per SIMD already cover each other's LDS and memory waits.
         for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) {
+            const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
+            pf4 nxt[8];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(fp + 128 * (c + 1) + 16 * s);
-            }
+            for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
-                    const pf4 a = *reinterpret_cast<const pf4*>(qs + (qt * ns + c * 8 + s) * 256 + rd);
+                    const pf4 aa = *reinterpret_cast<const pf4*>(qs + (qt * ns + c * 8 + s) * 256 + rd);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], cur[s][r], acc[qt], 0, 0, 0);
+                        acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[r], cur[s][r], acc[qt], 0, 0, 0);
                 }
             }
-            if (c + 1 < nchunk) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+            for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+        }
+        const bool valid = f0 + li < r_hi;
+        const bool first = f0 == r_lo && li == 0;       // lane li = 0 of the block's first tile = frame hS
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (valid) mx[qt][r] = fmaxf(mx[qt][r], acc[qt][r]);
+                const int qg = q0 + qt * 16 + 4 * lg + r;
+                if (FS && valid && qg < nq) fs[(size_t)qg * ctx_l + f0 + li] = acc[qt][r];
+                if (first && qg < nq) fr[(size_t)qg * nh + h] = acc[qt][r];
             }
         }
-        if (f0 + li < ctx_l) {
+        if (f0 + 16 >= r_hi) {                          // half-block done: max over its 16 frame lanes, one store per query
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    float v = mx[qt][r];
+                    v = fmaxf(v, __shfl_xor(v, 1, 64));
+                    v = fmaxf(v, __shfl_xor(v, 2, 64));
+                    v = fmaxf(v, __shfl_xor(v, 4, 64));
+                    v = fmaxf(v, __shfl_xor(v, 8, 64));
                     const int qg = q0 + qt * 16 + 4 * lg + r;
-                    if (qg < nq) fs[(size_t)qg * ctx_l + f0 + li] = acc[qt][r];
+                    if (li == 0 && qg < nq) hm[(size_t)qg * nh + h] = v;
+                    mx[qt][r] = -INFINITY;
                 }
         }
+        if (!more) break;
+        h = h2; f0 = f2; r_lo = lo2; r_hi = hi2; fp = fp2;
     }
 }
 
-static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, float* fs,
-                                  hipStream_t s) {
-    // 64 queries per launch while their vectors fit the LDS next to nothing else (64 x 512 x 4 B = 128 KiB), else 32
-    const int qpl = dv <= 512 ? 64 : 32;
+static int prefilter_grid_setup(int* n_cu_out) {
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     static int n_cu = 0;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)frame_score_mq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      128 * 1024);
-        if (attr_rc == hipSuccess)
-            attr_rc = hipFuncSetAttribute((const void*)frame_score_mq_kernel<2>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        const void* fns[4] = {(const void*)frame_score_mq_kernel<4, false>, (const void*)frame_score_mq_kernel<4, true>,
+                              (const void*)frame_score_mq_kernel<2, false>, (const void*)frame_score_mq_kernel<2, true>};
+        for (int i = 0; i < 4 && attr_rc == hipSuccess; ++i)
+            attr_rc = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         int dev = 0;
         if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
         if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     });
-    CONE_CHECK_HIP(attr_rc);
-    int64_t blocks = ((ctx_l + 15) / 16 + MQ_NT / 64 - 1) / (MQ_NT / 64);
-    if (blocks > n_cu) blocks = n_cu;                                  // one workgroup per CU, grid-stride over 16-frame tiles
+    *n_cu_out = n_cu;
+    return attr_rc == hipSuccess ? 0 : -1;
+}
+
+static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, int S, int64_t nh, const float* txt, int nq,
+                                  float* fs, float* hm, float* fr, hipStream_t s) {
+    // 64 queries per launch while their vectors fit the LDS next to nothing else (64 x 512 x 4 B = 128 KiB), else 32
+    const int qpl = dv <= 512 ? 64 : 32;
+    int n_cu = 0;
+    if (prefilter_grid_setup(&n_cu)) { set_error("prefilter: raising the LDS limit of the many-query kernel failed"); return CONE_E_HIP; }
+    int64_t blocks = (nh + MQ_NT / 64 - 1) / (MQ_NT / 64);
+    if (blocks > n_cu) blocks = n_cu;                                  // one workgroup per CU, grid-stride over half-blocks
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
         const bool wide = qpl == 64 && rem > 32;                           // 4 query tiles, else 2
         ProfScope ps(PK_FRAME_SCORE, ctx_l, dv, rem < (wide ? 64 : 32) ? rem : (wide ? 64 : 32), nullptr, s);
-        if (wide)
-            hipLaunchKernelGGL(frame_score_mq_kernel<4>, dim3((unsigned)blocks), dim3(MQ_NT), (size_t)64 * dv * 4, s, vid,
-                               ctx_l, dv, txt, q0, nq, fs);
-        else
-            hipLaunchKernelGGL(frame_score_mq_kernel<2>, dim3((unsigned)blocks), dim3(MQ_NT), (size_t)32 * dv * 4, s, vid,
-                               ctx_l, dv, txt, q0, nq, fs);
+#define CONE_MQ_LAUNCH(QT, FS, QN)                                                                                      \
+    hipLaunchKernelGGL((frame_score_mq_kernel<QT, FS>), dim3((unsigned)blocks), dim3(MQ_NT), (size_t)(QN) * dv * 4, s, vid, \
+                       ctx_l, dv, S, nh, txt, q0, nq, fs, hm, fr)
+        if (wide) { if (fs) CONE_MQ_LAUNCH(4, true, 64); else CONE_MQ_LAUNCH(4, false, 64); }
+        else { if (fs) CONE_MQ_LAUNCH(2, true, 32); else CONE_MQ_LAUNCH(2, false, 32); }
+#undef CONE_MQ_LAUNCH
         CONE_LAUNCH_CHECK();
         q0 += wide ? 64 : 32;
     }
@@ -482,42 +539,27 @@ __global__ __launch_bounds__(256) void topk_seg_kernel(const float* __restrict__
 }
 
 template <int VPL>
-static int launch_frame_scores(const float* vid, int64_t ctx_l, const float* txt, int nq, float* fs,
-                               hipStream_t s) {
+static int launch_frame_scores(const float* vid, int64_t ctx_l, int S, int64_t nh, const float* txt, int nq, float* fs,
+                               float* hm, float* fr, hipStream_t s) {
     constexpr int RPW = 4;
-    int64_t blocks = (ctx_l + 4 * RPW - 1) / (4 * RPW);
-    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: 8 workgroups per CU
+    // long videos: one wave per half-block, 8 workgroups per CU grid-striding; short ones: a workgroup per half-block
+    const bool wide = nh < 4096;
+    int64_t blocks = wide ? nh : (nh + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
-        ProfScope ps(PK_FRAME_SCORE, ctx_l, 256 * VPL, rem >= 4 ? 4 : (rem >= 2 ? 2 : 1), nullptr, s);
-        if (rem >= 4) {
-            hipLaunchKernelGGL((frame_score_kernel<VPL, 4, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
-                               ctx_l, txt, q0, nq, fs);
-            q0 += 4;
-        } else if (rem >= 2) {
-            hipLaunchKernelGGL((frame_score_kernel<VPL, 2, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
-                               ctx_l, txt, q0, nq, fs);
-            q0 += 2;
-        } else {
-            hipLaunchKernelGGL((frame_score_kernel<VPL, 1, RPW>), dim3((unsigned)blocks), dim3(256), 0, s, vid,
-                               ctx_l, txt, q0, nq, fs);
-            q0 += 1;
-        }
+        const int qg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+        ProfScope ps(PK_FRAME_SCORE, ctx_l, 256 * VPL, qg, nullptr, s);
+#define CONE_FS_LAUNCH(QG, WPH)                                                                                        \
+    hipLaunchKernelGGL((frame_score_kernel<VPL, QG, RPW, WPH>), dim3((unsigned)blocks), dim3(256), 0, s, vid, ctx_l, S, \
+                       nh, txt, q0, nq, fs, hm, fr)
+        if (qg == 4) { if (wide) CONE_FS_LAUNCH(4, 4); else CONE_FS_LAUNCH(4, 1); }
+        else if (qg == 2) { if (wide) CONE_FS_LAUNCH(2, 4); else CONE_FS_LAUNCH(2, 1); }
+        else { if (wide) CONE_FS_LAUNCH(1, 4); else CONE_FS_LAUNCH(1, 1); }
+#undef CONE_FS_LAUNCH
+        q0 += qg;
         CONE_LAUNCH_CHECK();
     }
-    return 0;
-}
-
-int launch_window_max(const float* fs, int64_t ctx_l, int W, int S, int nq, float* win, hipStream_t s) {
-    const int64_t nw = (ctx_l + S - 1) / S + 1;
-    const size_t lds = (size_t)((WM_WPB + 1) * S + W + 1) * sizeof(float);
-    if (nw >= 4 * WM_WPB && lds <= 48 * 1024) {
-        hipLaunchKernelGGL(window_max_tiled_kernel, dim3((unsigned)((nw + WM_WPB - 1) / WM_WPB), nq), dim3(256), lds, s,
-                           fs, ctx_l, W, S, nw, win);
-    } else {
-        hipLaunchKernelGGL(window_max_kernel, dim3((unsigned)((nw + 3) / 4), nq), dim3(256), 0, s, fs, ctx_l, W, S, nw, win);
-    }
-    CONE_LAUNCH_CHECK();
     return 0;
 }
 
@@ -529,29 +571,45 @@ extern "C" int64_t cone_num_windows(int64_t ctx_l, int W) {
     return (ctx_l + S - 1) / S + 1;
 }
 
+extern "C" size_t cone_prefilter_scores_workspace(int64_t ctx_l, int nq, int W) {
+    const int S = W / 2;
+    if (S <= 0 || ctx_l <= 0 || nq <= 0) return 0;
+    const size_t nh = (size_t)((ctx_l + S - 1) / S);
+    return 2 * cone::align_up((size_t)nq * nh * sizeof(float), 256);
+}
+
 extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W,
-                                     int S, float* frame_scores, float* win_scores, void* stream) {
-    CONE_REQUIRE(ctx_l > 0 && nq > 0 && W > 0 && S > 0, "prefilter: bad sizes ctx_l=%lld nq=%d W=%d S=%d",
+                                     int S, float* frame_scores, float* win_scores, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    CONE_REQUIRE(vid && txt && win_scores, "prefilter: null argument");
+    CONE_REQUIRE(ctx_l > 0 && nq > 0 && W > 0 && S > 0 && S == W / 2, "prefilter: bad sizes ctx_l=%lld nq=%d W=%d S=%d",
                  (long long)ctx_l, nq, W, S);
     CONE_REQUIRE(dv == 256 || dv == 512 || dv == 768 || dv == 1024,
                  "prefilter: feature dim %d not in {256,512,768,1024}", dv);
+    const size_t need = cone_prefilter_scores_workspace(ctx_l, nq, W);
+    CONE_REQUIRE(ws && ws_bytes >= need, "prefilter: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
+    const int64_t nh = (ctx_l + S - 1) / S;
+    float* hm = (float*)ws;
+    float* fr = (float*)((char*)ws + need / 2);
     int rc;
     if (nq >= 8) {
         // Many queries over one video: the clip arena is read once for up to 64 queries by the fp32-MFMA kernel
         // (BASELINE configs 3 / 5) instead of nq / 4 VALU passes over the features.
-        rc = cone::launch_frame_scores_mq(vid, ctx_l, dv, txt, nq, frame_scores, s);
-        if (rc) return rc;
-        return cone::launch_window_max(frame_scores, ctx_l, W, S, nq, win_scores, s);
-    }
-    switch (dv / 256) {
-        case 1: rc = cone::launch_frame_scores<1>(vid, ctx_l, txt, nq, frame_scores, s); break;
-        case 2: rc = cone::launch_frame_scores<2>(vid, ctx_l, txt, nq, frame_scores, s); break;
-        case 3: rc = cone::launch_frame_scores<3>(vid, ctx_l, txt, nq, frame_scores, s); break;
-        default: rc = cone::launch_frame_scores<4>(vid, ctx_l, txt, nq, frame_scores, s); break;
+        rc = cone::launch_frame_scores_mq(vid, ctx_l, dv, S, nh, txt, nq, frame_scores, hm, fr, s);
+    } else {
+        switch (dv / 256) {
+            case 1: rc = cone::launch_frame_scores<1>(vid, ctx_l, S, nh, txt, nq, frame_scores, hm, fr, s); break;
+            case 2: rc = cone::launch_frame_scores<2>(vid, ctx_l, S, nh, txt, nq, frame_scores, hm, fr, s); break;
+            case 3: rc = cone::launch_frame_scores<3>(vid, ctx_l, S, nh, txt, nq, frame_scores, hm, fr, s); break;
+            default: rc = cone::launch_frame_scores<4>(vid, ctx_l, S, nh, txt, nq, frame_scores, hm, fr, s); break;
+        }
     }
     if (rc) return rc;
-    return cone::launch_window_max(frame_scores, ctx_l, W, S, nq, win_scores, s);
+    hipLaunchKernelGGL(cone::window_combine_kernel, dim3((unsigned)((nh + 1 + 255) / 256), nq), dim3(256), 0, s, hm, fr, nh,
+                       W & 1, win_scores);
+    CONE_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cone_prefilter_batched(const float* arena, int dv, const float* cls, const int64_t* g_row0,

@@ -422,7 +422,8 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
         prow0 = g("vid_row0") - base if base else g("vid_row0")
         out = model.forward_packed(feats["vproj"], prow0, g("vid_len"), feats["tproj"], g("txt_row0"),
                                    g("txt_len"), opt.max_v_l, Lq_max, l0=feats.get("l0"),
-                                   saliency=bool(getattr(opt, "need_saliency", False)))
+                                   saliency=bool(getattr(opt, "need_saliency", False)),
+                                   aux=bool(getattr(opt, "need_aux", False)))
         match = model.clip_matching_gathered(feats["cls_norm"], g("cls_row"), store.vid_raw, g("vid_row0"),
                                              g("vid_len"), g("pad_len"), out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, g("vid_len"), g("video_start"),
@@ -431,6 +432,9 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
         outs["matching"].append(match); outs["rows"].append(rows)
         if "saliency_scores" in out:
             outs.setdefault("saliency_scores", []).append(out["saliency_scores"])
+        if "aux_outputs" in out:        # (n_dec - 1, B, Nq, 2) each, stacked over the intermediate decoder layers
+            outs.setdefault("aux_logits", []).append(torch.stack([a["pred_logits"] for a in out["aux_outputs"]], 1))
+            outs.setdefault("aux_spans", []).append(torch.stack([a["pred_spans"] for a in out["aux_outputs"]], 1))
     return {k: torch.cat(v, 0) for k, v in outs.items()}
 
 

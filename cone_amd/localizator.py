@@ -41,7 +41,8 @@ class CONELocalizator:
     @torch.no_grad()
     def compute_window_ranklist(self, video_feats, text_cls_feat):
         """run_on_video/cone_localizator.py:83-100 (stable tie order)."""
-        _, ws = ops.prefilter_scores(video_feats.contiguous(), text_cls_feat.reshape(1, -1).contiguous(), self.max_v_l)
+        _, ws = ops.prefilter_scores(video_feats.contiguous(), text_cls_feat.reshape(1, -1).contiguous(), self.max_v_l,
+                                      frame_scores=False)
         idx, _ = ops.topk_windows(ws, ws.shape[1])
         return idx[0].tolist()
 

@@ -284,9 +284,11 @@ class CONE:
                     **self.pos_tables(max_v_l))
 
     def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None,
-                       saliency: bool = True):
+                       saliency: bool = True, aux: bool = False):
         """CONE.forward on windows given by index into projected token arenas.  ``saliency=False`` skips the
-        saliency head (cone/inference.py computes and never reads it, :54-59)."""
+        saliency head (cone/inference.py computes and never reads it, :54-59); ``aux=True`` also runs decoder.norm +
+        the class / span heads of the intermediate decoder layers (``aux_outputs``, cone/model.py:123-127 -- equally
+        unread at inference)."""
         lib, h = _lib.load(), self._h()
         l0s = l0p = None
         if l0 is not None:
@@ -295,20 +297,30 @@ class CONE:
             l0p = C.byref(l0s)
         B = vid_row0.shape[0]
         dev = vproj.device
-        nq = self.num_queries
+        nq, nd = self.num_queries, self.args.dec_layers
         logits = torch.empty(B, nq, 2, device=dev)
         spans = torch.empty(B, nq, 2, device=dev)
         sal = torch.empty(B, Lv_max, device=dev) if saliency else None
+        tp = None
+        want_aux = aux and nd > 1
+        if want_aux:
+            t = _lib.Taps()
+            aux_l = torch.empty(nd - 1, B, nq, 2, device=dev)
+            aux_s = torch.empty(nd - 1, B, nq, 2, device=dev)
+            t.aux_logits, t.aux_spans = aux_l.data_ptr(), aux_s.data_ptr()
+            tp = C.byref(t)
         nbytes = lib.cone_forward_packed_workspace(h, B, Lv_max, Lq_max, l0p)
         ws = self._ws.get(nbytes, dev)
         i32 = torch.int32
         _lib.check(lib.cone_forward_packed(h, _lib.ptr(vproj), _lib.ptr(vid_row0, i32), _lib.ptr(vid_len, i32),
                                            _lib.ptr(tproj), _lib.ptr(txt_row0, i32), _lib.ptr(txt_len, i32), B,
-                                           Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), None,
+                                           Lv_max, Lq_max, _lib.ptr(logits), _lib.ptr(spans), _lib.ptr(sal), tp,
                                            l0p, _lib.ptr(ws), ws.numel(), _lib.stream()))
         out = {"pred_logits": logits, "pred_spans": spans}
         if saliency:
             out["saliency_scores"] = sal
+        if want_aux:
+            out["aux_outputs"] = [{"pred_logits": aux_l[i], "pred_spans": aux_s[i]} for i in range(nd - 1)]
         return out
 
     def clip_matching_gathered(self, cls, cls_row, vid, vid_row0, vid_len, pad_len, spans):

@@ -33,21 +33,25 @@ def num_windows(ctx_l: int, max_v_l: int) -> int:
     return math.ceil(ctx_l / int(max_v_l / 2)) + 1
 
 
-def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int):
+def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int, frame_scores: bool = True):
     """cone/inference.py:284-296 for all queries of one video.
 
     vid_ctx (ctx_l, dv) adapted+normalised clip features, cls_txt (nq, dv).
-    Returns (frame_scores (nq, ctx_l), window_scores (nq, num_window))."""
+    Returns (frame_scores (nq, ctx_l), window_scores (nq, num_window)).  The window max is fused into the
+    frame-score stream; ``frame_scores=False`` skips writing the (nq, ctx_l) matrix (returned as None) -- the
+    reference only computes it to take the window max, and so does every caller in this package."""
     lib = _lib.load()
     ctx_l, dv = vid_ctx.shape
     nq = cls_txt.shape[0]
     W, S = max_v_l, int(max_v_l / 2)
     nw = num_windows(ctx_l, max_v_l)
-    fs = torch.empty(nq, ctx_l, device=vid_ctx.device)
+    fs = torch.empty(nq, ctx_l, device=vid_ctx.device) if frame_scores else None
     ws = torch.empty(nq, nw, device=vid_ctx.device)
+    nbytes = lib.cone_prefilter_scores_workspace(ctx_l, nq, W)
+    scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=vid_ctx.device)
     _lib.check(lib.cone_prefilter_scores(_lib.ptr(vid_ctx, torch.float32), ctx_l, dv,
                                          _lib.ptr(cls_txt, torch.float32), nq, W, S, _lib.ptr(fs), _lib.ptr(ws),
-                                         _lib.stream()))
+                                         _lib.ptr(scratch), scratch.numel(), _lib.stream()))
     return fs, ws
 
 

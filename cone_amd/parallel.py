@@ -198,7 +198,7 @@ def prefilter_ctx_sharded(ctx_local: torch.Tensor, ctx_l: int, cls_norm: torch.T
     fp32 bit patterns next to the scores) -- no feature row ever moves."""
     if window_scores_fn is None or topk_fn is None:
         from . import ops
-        window_scores_fn = window_scores_fn or (lambda v, c, w: ops.prefilter_scores(v, c, w)[1])
+        window_scores_fn = window_scores_fn or (lambda v, c, w: ops.prefilter_scores(v, c, w, frame_scores=False)[1])
         topk_fn = topk_fn or ops.topk_windows
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     shard = ctx_shard(ctx_l, max_v_l, rank, world)

@@ -12,7 +12,9 @@
  *     caller (torch tensors), row-major, densely packed unless a stride is given;
  *     cone_weights pointers may be host or device (copied once at cone_model_create);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on
- *     it, nothing synchronises, nothing allocates (scratch comes in through `ws`);
+ *     it, nothing synchronises, nothing allocates (scratch comes in through `ws`) -- except
+ *     cone_model_create / cone_model_destroy, which allocate / free the handle's weight arena
+ *     (hipMalloc + blocking copies) and therefore synchronise with the device;
  *   - return value 0 = success, negative = error (CONE_E_*), text in cone_last_error();
  *     nothing throws across the ABI;
  *   - a cone_model is immutable after creation (cone_model_set_option, a parity-test hook, is the
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 2
+#define CONE_HIP_ABI_VERSION 3
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -94,11 +96,16 @@ int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, i
 
 /* A3+A4, cone/inference.py:284-296: frame_scores[q][f] = <vid[f], txt[q]>;
  * win_scores[q][i] = max(frame_scores[q][max((i-1)S,0) : min((i-1)S+W, ctx_l)]),
- * num_window = ceil(ctx_l/S)+1.  vid (ctx_l,dv), txt (nq,dv), frame_scores (nq,ctx_l) scratch+output,
- * win_scores (nq,num_window). */
+ * num_window = ceil(ctx_l/S)+1, S = W/2.  vid (ctx_l,dv), txt (nq,dv), win_scores (nq,num_window).
+ * The window max is fused into the frame-score stream (a running max per half window of S frames; each frame belongs
+ * to two windows), so the (nq,ctx_l) frame-score matrix -- which the reference computes only to take this max -- is
+ * OPTIONAL: frame_scores may be NULL (nothing of that size is written), or receives the scores as before.
+ * ws >= cone_prefilter_scores_workspace(ctx_l, nq, W) bytes (two floats per query and half window). */
 int64_t cone_num_windows(int64_t ctx_l, int W);
+size_t cone_prefilter_scores_workspace(int64_t ctx_l, int nq, int W);
 int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq,
-                          int W, int S, float* frame_scores, float* win_scores, void* stream);
+                          int W, int S, float* frame_scores, float* win_scores, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* A4, cone/inference.py:297-299 (+ [:topk], cone/ego4d_mad_dataloader.py:146): the first k entries
  * of the descending sort of each row of win_scores (nq,num_window); ties -> lower window index

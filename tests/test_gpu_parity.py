@@ -405,7 +405,11 @@ def test_stage_a_matches_reference_golden(golden_dir, name):
 
 @pytest.mark.parametrize("ctx_l,W,dv,nq", [(1, 90, 256, 1), (44, 90, 256, 3), (45, 90, 256, 2), (91, 90, 256, 5),
                                            (1000, 125, 512, 7), (5000, 125, 512, 1), (333, 90, 768, 2),
-                                           (3000, 125, 512, 64), (777, 90, 256, 9), (4096, 125, 512, 33)])
+                                           (3000, 125, 512, 64), (777, 90, 256, 9), (4096, 125, 512, 33),
+                                           # half-window seams of an odd window length (W = 2 S + 1: the extra frame)
+                                           (61, 125, 512, 2), (62, 125, 512, 1), (63, 125, 512, 4), (124, 125, 512, 3),
+                                           (125, 125, 512, 9), (186, 125, 512, 2), (187, 125, 512, 17), (90, 90, 256, 8),
+                                           (89, 91, 256, 3), (2, 3, 256, 2), (7, 2, 256, 1), (1025, 90, 1024, 6)])
 def test_prefilter_edge_shapes(ctx_l, W, dv, nq):
     from cone_amd import ops
     dev = _gpu()
@@ -416,11 +420,40 @@ def test_prefilter_edge_shapes(ctx_l, W, dv, nq):
     ref_fs = vid @ txt.t()
     assert maxdiff(fs.t(), ref_fs) < 1e-5
     assert ws.shape[1] == O.num_windows(ctx_l, W)
+    # the product form: the window max fused into the stream, no frame-score matrix written -- same bits
+    none, ws_fused = ops.prefilter_scores(vid.to(dev), txt.to(dev), W, frame_scores=False)
+    assert none is None and torch.equal(ws_fused, ws)
     for q in range(nq):
         assert torch.equal(O.window_scores(fs[q].cpu(), W), ws[q].cpu())
         k = min(7, ws.shape[1])
         idx, val = ops.topk_windows(ws, k)
         assert idx[q].cpu().tolist() == O.rank_windows(ws[q].cpu())[:k]
+
+
+@pytest.mark.parametrize("ctx_l,W,dv,nq", [(62 * 4100 + 17, 125, 512, 1), (62 * 4100 + 17, 125, 512, 3),
+                                           (45 * 5000, 90, 256, 4), (300_001, 125, 512, 9), (280_000, 125, 512, 40)])
+def test_prefilter_long_rows_fused_window_max(ctx_l, W, dv, nq):
+    """Long videos (>= 4 096 half windows: one wave per half window, grid-stride; many queries: MFMA tiles over whole
+    half windows): window scores == max over the stored frame scores, with and without the frame-score matrix."""
+    from cone_amd import ops
+    dev = _gpu()
+    g = torch.Generator(device=dev).manual_seed(ctx_l % 1000 + nq)
+    vid = ops.l2_normalize(torch.randn(ctx_l, dv, device=dev, generator=g), 1e-5)
+    txt = ops.l2_normalize(torch.randn(nq, dv, device=dev, generator=g), 1e-5)
+    fs, ws = ops.prefilter_scores(vid, txt, W)
+    _, ws_fused = ops.prefilter_scores(vid, txt, W, frame_scores=False)
+    assert torch.equal(ws, ws_fused)
+    S, nw = W // 2, ops.num_windows(ctx_l, W)
+    rows = torch.randint(0, ctx_l, (3000,), device=dev)
+    ref = (vid[rows].double() @ txt.double().t()).t()
+    assert float((fs[:, rows].double() - ref).abs().max()) < 1e-6
+    for q in range(nq):
+        f = fs[q]
+        inner = f[:(nw - 3) * S + W].unfold(0, W, S).max(dim=1).values          # windows 1 .. nw-2 start at (i-1)*S
+        assert torch.equal(ws[q, 1:1 + inner.shape[0]], inner)
+        assert float(ws[q, 0]) == float(f[:min(W - S, ctx_l)].max())
+        for i in (nw - 2, nw - 1):
+            assert float(ws[q, i]) == float(f[(i - 1) * S:min((i - 1) * S + W, ctx_l)].max())
 
 
 def test_prefilter_batched_equals_per_video_path():
@@ -1292,13 +1325,17 @@ def test_mad_scale_prefilter_full_size(nq):
         f = fs[q]
         inner = f[:(nw - 3) * S + W].unfold(0, W, S).max(dim=1).values          # windows 1 .. nw-2 start at (i-1)*S
         assert torch.equal(ws[q, 1:1 + inner.shape[0]], inner)
-        assert float(ws[q, 0]) == float(f[:S].max())
+        assert float(ws[q, 0]) == float(f[:W - S].max())
         last = nw - 1
         assert float(ws[q, last]) == float(f[(last - 1) * S:min((last - 1) * S + W, ctx_l)].max())
     idx, val = ops.topk_windows(ws, k)
     sv, si = torch.sort(ws, dim=1, descending=True, stable=True)
     assert torch.equal(idx.long(), si[:, :k]) and torch.equal(val, sv[:, :k])
-    del vid, fs, ws
+    del fs, sv, si
+    # the product form (what bench.py times): no (nq, ctx_l) matrix is written -- identical window scores
+    none, ws_fused = ops.prefilter_scores(vid, txt, W, frame_scores=False)
+    assert none is None and torch.equal(ws_fused, ws)
+    del vid, ws, ws_fused
     torch.cuda.empty_cache()
 
 

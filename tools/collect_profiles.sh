@@ -1,29 +1,32 @@
 #!/bin/bash
 # Collect the per-round rocprofv3 evidence on the GPU box (run from the repo root through gpurun):
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 # writes gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards.  Counters are collected in their own
-# passes (never together with API traces), each a separate run of the same bench command.
+# passes (never together with API traces), each a separate run of the same command, the program directly after `--`.
 set -u
 tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-rm -rf $out/prof_$tag $out/pmc_fetch $out/pmc_write $out/pmc_mfma
+rm -rf $out/prof_$tag $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf
+# (1) per-kernel time of the whole default command (extras included: the pre-filter / config-5 / latency kernels)
 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
     > $out/${tag}_prof_bench.json 2> $out/prof_$tag.log
 python3 tools/rocpd_summary.py $out/prof_$tag/t_results.db > $out/${tag}_bench_kernel_stats_all.csv 2>> $out/prof_$tag.log
+# (2) the timed region only: the last launches of the trace (3 steps), so that per-kernel averages are those of the step
 rm -rf $out/prof_${tag}_step
 rocprofv3 --kernel-trace --stats -d $out/prof_${tag}_step -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
     --no_extras > $out/${tag}_prof_step.json 2>> $out/prof_$tag.log
-# the timed region only: the last launches of the trace (3 steps), so that per-kernel averages are those of the step
 win=$(python3 -c "import json,sys; print(3 * json.load(open('$out/${tag}_prof_step.json'))['ms_per_step'] + 0.5)")
 python3 tools/rocpd_summary.py $out/prof_${tag}_step/t_results.db $win > $out/${tag}_bench_kernel_stats.csv 2>> $out/prof_$tag.log
-# the opt-in split-bf16 path, same window
+python3 tools/rocpd_summary.py $out/prof_${tag}_step/t_results.db $win --gaps > $out/${tag}_step_gaps.txt 2>> $out/prof_$tag.log
+# (3) the opt-in split-bf16 path, same window
 rm -rf $out/prof_${tag}_split
 rocprofv3 --kernel-trace --stats -d $out/prof_${tag}_split -o t -- python3 bench.py --steps 3 --warmup 1 --cpu_queries 0 \
     --no_extras --set_option split_bf16=1 > $out/${tag}_prof_split.json 2>> $out/prof_$tag.log
 win=$(python3 -c "import json,sys; print(3 * json.load(open('$out/${tag}_prof_split.json'))['ms_per_step'] + 0.5)")
 python3 tools/rocpd_summary.py $out/prof_${tag}_split/t_results.db $win > $out/${tag}_bench_kernel_stats_split.csv 2>> $out/prof_$tag.log
+# (4) PMC passes over the step
 B="python3 bench.py --steps 2 --warmup 1 --cpu_queries 0 --no_extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- $B > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- $B > $out/pmc_write.log 2>&1
@@ -31,7 +34,15 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_
     -d $out/pmc_mfma -o m -- $B > $out/pmc_mfma.log 2>&1
 python3 tools/pmc_summary.py $out $out/${tag}_pmc > $out/${tag}_pmc.log 2>&1
 tail -3 $out/${tag}_pmc.log
-# the bench line last: roofline.traffic is read from profiles/<tag>_pmc_traffic.json of THIS collection
-cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv profiles/
+# (5) PMC passes over the MAD-scale pre-filter (BASELINE configs[2]; 1 and 64 queries in one process)
+P="python3 tools/prefilter_bench.py --queries 1,64 --steps 3"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_pf -o f -- $P > $out/pmc_fetch_pf.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_pf -o w -- $P > $out/pmc_write_pf.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv \
+    -d $out/pmc_mfma_pf -o m -- $P > $out/pmc_mfma_pf.log 2>&1
+python3 tools/pmc_summary.py $out $out/${tag}_pmc_prefilter _pf > $out/${tag}_pmc_prefilter.log 2>&1
+tail -8 $out/${tag}_pmc_prefilter.log
+# the bench line last: roofline.traffic is read from profiles/<tag>_pmc_*.json of THIS collection
+cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv $out/${tag}_pmc_prefilter.json $out/${tag}_pmc_prefilter_counters.csv profiles/
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 cat $out/${tag}_bench_line.json

@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (default output of ROCm 7.2's `rocprofv3 --kernel-trace --stats`):
 per-kernel total / average / count over the last WINDOW ms of the trace, GPU-busy vs wall, as CSV on stdout.
-usage: rocpd_summary.py results.db [window_ms]"""
+usage: rocpd_summary.py results.db [window_ms] [--gaps]
+--gaps: instead of the per-kernel table, list the GPU-idle gaps > 0.2 ms inside the window (start offset, length, the
+kernels on either side) -- where the device waits for the host (between steps: D2H + list building)."""
 import sqlite3
 import sys
 from collections import defaultdict
 
+gaps = "--gaps" in sys.argv
+if gaps:
+    sys.argv.remove("--gaps")
 db = sqlite3.connect(sys.argv[1])
 ev = sorted(db.execute("select start, end, name from kernels").fetchall())
 t_end = max(e[1] for e in ev)
@@ -21,6 +26,18 @@ for s, e, _ in sel[1:]:
 busy += ce - cs
 wall = max(e[1] for e in sel) - sel[0][0]
 print(f"# window {wall / 1e6:.2f} ms, GPU busy {busy / 1e6:.2f} ms ({100 * busy / wall:.1f}%), {len(sel)} launches")
+if gaps:
+    print("offset_ms,gap_ms,after_kernel,before_kernel")
+    end, last = sel[0][1], sel[0][2]
+    tot = 0.0
+    for s0, e0, n0 in sel[1:]:
+        if s0 - end > 0.2e6:
+            print(f"{(end - sel[0][0]) / 1e6:.3f},{(s0 - end) / 1e6:.3f},\"{last.split('(')[0]}\",\"{n0.split('(')[0]}\"")
+            tot += (s0 - end) / 1e6
+        if e0 > end:
+            end, last = e0, n0
+    print(f"# total of listed gaps {tot:.3f} ms")
+    sys.exit(0)
 per = defaultdict(lambda: [0, 0])
 for s, e, n in sel:
     per[n.split("(")[0]][0] += e - s
