@@ -282,6 +282,60 @@ def clip_matching(sd, opt, src_cls_txt, src_vid_appear, src_vid_appear_mask, pro
     return torch.einsum("bld,bd->bl", pf, txt)
 
 
+def matching_alternatives(sd, opt, cls_txt, vid_padded, duration, span_cxw, margin=1e-3):
+    """Test support for hazard "floor / ceil next to an integer" (SURVEY.md 7): the matching scores the reference's
+    ``forward_clip_matching`` (cone/model.py:130-152, 178-210) can produce for ONE proposal when a clip boundary
+    ``x * duration`` lies within ``margin`` of an integer -- a 1-ulp difference in the predicted span then moves the slice
+    end by one clip.  Returns the list of scores over the poolings ``feat[s:e]`` with s in {floor(x1)} (+ its neighbour when
+    x1 is near an integer) and e in {ceil(x2)} (+ neighbour); a proposal away from every boundary has exactly one.
+    ``vid_padded`` (Lv_pad, dv) is the zero-padded window of the reference batch (hazard H3), ``cls_txt`` (dv,)."""
+    sp = torch.as_tensor(span_cxw, dtype=torch.float32).reshape(1, 1, 2)
+    xx = span_cxw_to_xx(sp)[0, 0] * float(duration)                         # fp32, as cone/model.py:188
+    x1, x2 = float(xx[0]), float(xx[1])
+    starts = {max(int(math.floor(x1)), 0)}
+    ends = {int(math.ceil(x2))}
+    if abs(x1 - round(x1)) < margin:
+        starts |= {max(int(round(x1)) - 1, 0), max(int(round(x1)), 0)}
+    if abs(x2 - round(x2)) < margin:
+        ends |= {int(round(x2)), int(round(x2)) + 1}
+    txt = cls_txt / cls_txt.norm()
+    out = []
+    for s_ in sorted(starts):
+        for e_ in sorted(ends):
+            pf = vid_padded[s_:e_].mean(dim=0)[None]
+            if opt.adapter_module == "linear":
+                pf = mlp(pf, sd, "adapter_layer", 2) + pf
+            pf = pf / pf.norm(dim=1, keepdim=True)
+            out.append(float((pf[0] * txt).sum()))
+    return out
+
+
+def check_matching_column(sd, opt, cls_norm, vid_raw, vid_row0, vid_len, pad_len, cls_row, pred_spans, matching, tol=1e-4):
+    """Every (window, slot) matching score of a device run against ``matching_alternatives`` of ITS OWN predicted span on
+    the same zero-padded window: returns (n_checked, n_boundary, worst) where worst = the largest distance to the nearest
+    admissible pooling.  Inputs are CPU tensors / arrays: the store's raw clip arena, the window table columns, the
+    normalised cls vectors."""
+    n_chk = n_bnd = 0
+    worst = 0.0
+    B, Nq = matching.shape
+    for b in range(B):
+        r0, L, P = int(vid_row0[b]), int(vid_len[b]), int(pad_len[b])
+        win = torch.zeros(max(P, L), vid_raw.shape[1])
+        win[:L] = vid_raw[r0:r0 + L]
+        win = win[:P] if P >= L else win
+        cls = cls_norm[int(cls_row[b])]
+        for n in range(Nq):
+            alts = matching_alternatives(sd, opt, cls, win, L, pred_spans[b, n])
+            got = float(matching[b, n])
+            dist = lambda a: 0.0 if (math.isnan(a) and math.isnan(got)) else (
+                float("inf") if (math.isnan(a) or math.isnan(got)) else abs(got - a))
+            d = min(dist(a) for a in alts)
+            worst = max(worst, d)
+            n_chk += 1
+            n_bnd += len(alts) > 1
+    return n_chk, n_bnd, worst
+
+
 def compose_rows(opt, pred_logits, pred_spans, matching, durations, video_starts):
     """A13: cone/inference.py:47-91 -- per window (Nq,4) fp32 rows [st, ed, prop, match]
     sorted by proposal score (stable, descending) unless --no_sort_results; rounding to

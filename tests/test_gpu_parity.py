@@ -20,6 +20,13 @@ from oracle import cone_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# floor on (query, file) pairs of the device pipeline's written files that equal the reference's files (identical rows, or
+# kept moments within the span tolerance where a candidate row differs in its last printed digit upstream of the min-max
+# fusion): raised to the measured figure (gpurun_out/parity_measured.jsonl, profiles/r03_parity_measured.jsonl)
+E2E_FILE_FLOOR = 0.97       # measured 36/36, 27/27, 18/18 (both arithmetic paths): one flipped query of 36 would still pass
+PIPELINE_FLOOR = 0.975      # queries whose kept moments equal the oracle's (device pipeline vs oracle): measured 40/40
+CONFIG5_FLOOR = 15 / 16     # measured 15/16 (one query's candidate row rounds the other way at the 4th decimal)
+CONFIG2_FLOOR = 0.96        # measured 32/32 and 40/40
 
 
 def _gpu():
@@ -44,6 +51,32 @@ def get_model(preset, seed):
 
 def maxdiff(a, b):
     return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def record_measured(test, **vals):
+    """Measured agreement figures of the envelope checks: printed (pytest -s / -rP) and appended to
+    gpurun_out/parity_measured.jsonl so that the floors asserted below can be held against what is measured."""
+    line = json.dumps(dict(test=test, **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in vals.items()}))
+    print("[parity]", line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def check_matching_vs_own_spans(sd, opt, store, wt, raw, feats_cls=None):
+    """Matching column of a device run, EVERY (window, slot): against the oracle's pooling of the run's own predicted
+    span on the same zero-padded window -- where a clip boundary lies within 1e-3 of an integer either neighbouring
+    pooling is admissible (O.matching_alternatives) instead of the row being skipped."""
+    from cone_amd import ops
+    cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)
+    c = lambda t: t.detach().cpu()
+    return O.check_matching_column(sd, opt, c(cls_norm), c(store.vid_raw), c(wt["vid_row0"]).numpy(),
+                                   c(wt["vid_len"]).numpy(), c(wt["pad_len"]).numpy(), c(wt["cls_row"]).numpy(),
+                                   c(raw["pred_spans"]), c(raw["matching"]))
 
 
 # ------------------------------------------------------------------------------- kernels
@@ -651,17 +684,28 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path, split_b
     unsorted = ops.compose_rows(raw["pred_logits"], raw["pred_spans"], raw["matching"], wt["vid_len"],
                                 wt["video_start"], opt.clip_length, False).cpu().tolist()
     sec_tol = 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
-    n_cmp, worst_match = 0, 0.0
+    n_cmp, worst_match, n_misaligned = 0, 0.0, 0
     for w, (a, b) in enumerate(zip(mr, fx["mr_res"])):
         ra, rb = np.array(a["pred_relevant_windows"]), np.array(b["pred_relevant_windows"])
         if np.abs(ra[:, 2] - rb[:, 2]).max() > 2e-4 or np.abs(ra[:, :2] - rb[:, :2]).max() > sec_tol:
+            n_misaligned += 1
             continue
         slot_rows = [[float(f"{e:.4f}") for e in row] for row in unsorted[w]]
         ok = np.array([safe[w][slot_rows.index(list(r))] for r in ra.tolist()])
         if ok.any():
             worst_match = max(worst_match, np.abs(ra[ok, 3] - rb[ok, 3]).max())
             n_cmp += int(ok.sum())
-    assert n_cmp >= 0.9 * safe.size, (n_cmp, safe.size)
+    # ... and the proposals next to a clip boundary are not skipped: every (window, slot) matching score must equal the
+    # oracle's pooling of OUR span on the same padded window, either neighbouring pooling being admissible at a boundary
+    _, _, sd_t = get_model(preset, fx["weight_seed"])
+    n_chk, n_bnd, worst_alt = check_matching_vs_own_spans(sd_t, opt, store, wt, raw)
+    assert n_chk == safe.size and worst_alt <= 1e-4, (n_chk, safe.size, worst_alt)
+    record_measured(f"e2e[{name},split={split_bf16}]", rows=int(safe.size), safe_share=float(safe.mean()),
+                    compared_vs_reference_share=n_cmp / safe.size, misaligned_windows=n_misaligned,
+                    worst_match_vs_reference=float(worst_match), boundary_proposals=n_bnd,
+                    worst_match_vs_own_span_pooling=float(worst_alt), worst_prop=float(worst), worst_sec=float(worst_sec))
+    assert n_misaligned == 0, n_misaligned             # measured: no window's rows sort differently from the reference's
+    assert n_cmp == int(safe.sum()), (n_cmp, int(safe.sum()))      # every safe proposal was compared with the reference
     assert worst_match <= 2e-4, worst_match            # matching score, after 4-dp rounding
     # stage C on the REFERENCE's own window rows reproduces its files exactly
     f2, p2, m2 = (inf.postprocessing_format_mad if preset == "mad" else inf.postprocessing_format_ego4d)(fx["mr_res"], opt)
@@ -699,7 +743,9 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path, split_b
                 ga, rb_ = np.array(g_["predicted_times"]), np.array(r_["predicted_times"])
                 if ga.shape == rb_.shape and np.abs(ga[:, :2] - rb_[:, :2]).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
                     n_close += 1
-    assert n_same + n_close >= 0.9 * 3 * len(ann), (n_same, n_close, len(ann))
+    record_measured(f"e2e_files[{name},split={split_bf16}]", files_x_queries=3 * len(ann), identical=n_same, close=n_close,
+                    share=(n_same + n_close) / (3 * len(ann)))
+    assert n_same + n_close >= E2E_FILE_FLOOR * 3 * len(ann), (n_same, n_close, len(ann))
     if preset == "mad":     # the reference scores the MAD test split too (cone/inference.py:332): .txt + tables
         assert paths[0].endswith(".txt") and paths[1] == written[0] and len(strs) == 4 and res.shape == (5, 3)
     else:                   # Ego4D test: files only (the reference exits there, :476-477)
@@ -731,7 +777,8 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
         ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
         if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
             agree += 1
-    assert agree >= 0.9 * len(f1), agree      # the rest differ only through 4-dp rounding flips upstream of NMS
+    record_measured("pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, share=agree / len(f1))
+    assert agree >= PIPELINE_FLOOR * len(f1), agree      # the rest differ only through 4-dp rounding flips upstream of NMS
     # NMS invariants on our own output
     for item in f1:
         pt = item["predicted_times"]
@@ -1339,6 +1386,68 @@ def test_mad_scale_prefilter_full_size(nq):
     torch.cuda.empty_cache()
 
 
+def test_config2_full_size():
+    """BASELINE configs[1] at the size the headline is quoted on (bench.py's split: 1 000 queries x 50 videos, top-20 =>
+    20 000 windows, eval_bsz 32): rank lists of ALL queries against the oracle's pre-filter; window rows and kept moments
+    of the first reference batch and of a range cut MID-batch in the middle of the split (queries 490 .. 529, with the
+    split's padding table: hazard H3) against the oracle run on the reference batches that contain them
+    (cone/inference.py:30-100, 205-217)."""
+    from cone_amd import inference as inf
+    model, _, sd = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32)
+    ann, vf, qf = synth.make_dataset(opt, 1000, 50, seed=0)
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    (fusion, prop, match), info = inf.predict_split(model, store, opt)
+    assert info["n_windows"] == 20_000 and len(fusion) == 1000
+    with torch.no_grad():
+        ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+    win_idx = info["win_idx"]
+    got = win_idx.cpu().tolist()
+    for qi, row in enumerate(ann):
+        assert got[qi] == ranks[row["query_id"]][:20], qi
+    bp = inf.reference_batch_pad(store, opt, win_idx)
+    A = lambda r: np.array(r["pred_relevant_windows"])
+    sec_tol = 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
+    stats = {}
+    # (oracle range = whole reference batches, device range, label)
+    for (o_lo, o_hi), (lo, hi), label in (((0, 32), (0, 32), "first_batch"), ((480, 544), (490, 530), "mid_batch_cut")):
+        with torch.no_grad():
+            mr = O.compute_mr_results(sd, opt, ann[o_lo:o_hi], vf, qf, ranks)
+        assert len(mr) == (o_hi - o_lo) * 20                     # dense: every video has more than 20 windows
+        mr = mr[(lo - o_lo) * 20:(hi - o_lo) * 20]               # rows of the queries the device range holds
+        sub = inf.FeatureStore.subset(store, lo, hi)
+        wi = win_idx[lo:hi].contiguous()
+        wt = inf.window_table(sub, opt, wi, bp)
+        raw = inf.run_windows(model, sub, opt, wt)
+        rows = raw["rows"].cpu().tolist()
+        assert len(rows) == len(mr) == (hi - lo) * 20
+        q_of = wt["q_of"].cpu().tolist()
+        mine = [[[float(f"{e:.4f}") for e in r] for r in w] for w in rows]
+        dp_, ds_, dm_bad = 0.0, 0.0, 0
+        for w, (a, b) in enumerate(zip(mine, mr)):
+            assert sub.ann[q_of[w]]["query_id"] == b["query_id"]
+            ra, rb = np.array(a), A(b)
+            dp_ = max(dp_, np.abs(ra[:, 2] - rb[:, 2]).max())
+            ds_ = max(ds_, np.abs(ra[:, :2] - rb[:, :2]).max())
+            dm_bad += int((np.abs(ra[:, 3] - rb[:, 3]) > 2e-4).sum())
+        assert dp_ <= 2e-4 and ds_ <= sec_tol, (label, dp_, ds_)
+        n_chk, n_bnd, worst_alt = check_matching_vs_own_spans(sd, opt, sub, wt, raw)
+        assert n_chk == (hi - lo) * 100 and worst_alt <= 1e-4, (label, n_chk, worst_alt)
+        assert dm_bad <= n_bnd, (label, dm_bad, n_bnd)      # only proposals next to a clip boundary may pool differently
+        # kept moments of those queries: the device pipeline's lists against the oracle's stage C on ITS rows
+        fo, po, mo = O.postprocess(mr, opt)
+        agree = 0
+        for a, b in zip(fusion[lo:hi], fo):
+            ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+            agree += bool(ra.shape == rb.shape and np.abs(ra - rb).max() <= sec_tol + 1e-4)
+        stats[label] = dict(worst_prop=float(dp_), worst_sec=float(ds_), matching_rows_beyond_2e4=dm_bad, boundary_proposals=n_bnd,
+                            worst_match_vs_own_span_pooling=float(worst_alt), kept_moments_agree=agree, queries=hi - lo)
+        assert agree >= CONFIG2_FLOOR * (hi - lo), (label, agree)
+        # and stage C is exact on identical candidates
+        assert inf.postprocessing_format_ego4d(mr, opt) == (fo, po, mo)
+    record_measured("config2_full_size", **{f"{k}.{kk}": vv for k, v in stats.items() for kk, vv in v.items()})
+
+
 def test_config5_64_queries_one_mad_length_video():
     """BASELINE configs[4] on one GPU: 64 concurrent queries over ONE MAD-length video (ctx_l 33 000, d 512,
     window_len 125, top-30 => 1 920 windows) end to end; rank lists of all queries and the full pipeline of a sample
@@ -1369,7 +1478,14 @@ def test_config5_64_queries_one_mad_length_video():
     for a, b in zip(fusion[:16], fo):
         ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
         agree += ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4
-    assert agree >= 14, agree
+    record_measured("config5_first_batch", queries=16, kept_moments_agree=int(agree), share=agree / 16)
+    assert agree >= CONFIG5_FLOOR * 16, agree
+    # matching column of that batch, every proposal (boundary proposals: either neighbouring pooling)
+    sub = inf.FeatureStore.subset(store, 0, 16)
+    wt = inf.window_table(sub, opt, info["win_idx"][:16].contiguous())
+    raw = inf.run_windows(model, sub, opt, wt)
+    n_chk, n_bnd, worst_alt = check_matching_vs_own_spans(sd, opt, sub, wt, raw)
+    assert n_chk == 480 * 5 and worst_alt <= 1e-4, (n_chk, worst_alt)
 
 
 def test_criterion_forward_matches_reference_golden(golden_dir):

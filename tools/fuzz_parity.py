@@ -12,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from cone_amd import inference as inf, synth  # noqa: E402
+from cone_amd import inference as inf, ops, synth  # noqa: E402
 from cone_amd.config import make_opt  # noqa: E402
 from cone_amd.model import build_model  # noqa: E402
 from oracle import cone_oracle as O  # noqa: E402
@@ -29,6 +29,9 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 model.set_option("split_bf16", split_bf16)        # 1: the opt-in bf16-split layer tails, same checks, same tolerances
 A = lambda r: np.array(r["pred_relevant_windows"])
 worst = dict(prop=0.0, sec=0.0, match_bad=0.0)
+tot = dict(rows=0, bad=0, bnd=0)
+sd_t = O.as_torch_sd(sd)
+cpu = lambda t: t.detach().cpu()
 t_start = time.time()
 for it in range(iters):
     rng = np.random.default_rng(seed0 + it)
@@ -58,6 +61,17 @@ for it in range(iters):
     assert dp <= 2e-4, f"{tag}: proposal scores off by {dp}"
     assert ds <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4, f"{tag}: spans off by {ds} s"
     bad = float((dm > 2e-4).mean())
+    # matching column, every proposal: the oracle's pooling of the run's own span (either neighbour at a clip boundary)
+    wt = inf.window_table(store, opt, info["win_idx"])
+    raw = inf.run_windows(model, store, opt, wt)
+    n_chk, n_bnd, worst_alt = O.check_matching_column(
+        sd_t, opt, cpu(ops.l2_normalize(store.cls_raw, 1e-5)), cpu(store.vid_raw), cpu(wt["vid_row0"]).numpy(),
+        cpu(wt["vid_len"]).numpy(), cpu(wt["pad_len"]).numpy(), cpu(wt["cls_row"]).numpy(), cpu(raw["pred_spans"]),
+        cpu(raw["matching"]))
+    assert worst_alt <= 1e-4, f"{tag}: matching differs from the oracle's pooling of the same span by {worst_alt}"
+    assert int((dm > 2e-4).sum()) <= n_bnd, f"{tag}: {int((dm > 2e-4).sum())} matching rows off, {n_bnd} boundary proposals"
+    worst["match_alt"] = max(worst.get("match_alt", 0.0), worst_alt)
+    tot["rows"] += dm.size; tot["bad"] += int((dm > 2e-4).sum()); tot["bnd"] += n_bnd
     worst["prop"], worst["sec"], worst["match_bad"] = max(worst["prop"], dp), max(worst["sec"], ds), max(worst["match_bad"], bad)
     fmt = inf.postprocessing_format_ego4d if opt.dset_name == "ego4d" else inf.postprocessing_format_mad
     assert fmt(mr, opt) == (fo, po, mo), f"{tag}: fusion / NMS differ on identical candidates"
@@ -67,4 +81,6 @@ for it in range(iters):
     again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
     assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
 print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
-      f"worst span diff {worst['sec']:.2e} s, worst share of matching rows beyond 2e-4: {worst['match_bad']:.0%}")
+      f"worst span diff {worst['sec']:.2e} s; matching: every proposal within {worst['match_alt']:.1e} of the oracle's pooling of its "
+      f"own span, {tot['bad']} of {tot['rows']} rows ({tot['bad'] / max(tot['rows'], 1):.2%}) beyond 2e-4 of the oracle's rows "
+      f"({tot['bnd']} proposals next to a clip boundary; worst split {worst['match_bad']:.0%})")
