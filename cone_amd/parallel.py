@@ -45,12 +45,39 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_fixed(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+_KEEP_IDX = {}       # (n_total, world, device) -> int64 row indices of the real rows inside the padded gather buffer
+
+
+def _keep_index(n_total: int, world: int, device) -> torch.Tensor:
+    """Rows of the (world * cap) gather buffer that are real: rank r holds shard_range(n_total, r, world) rows at
+    r * cap.  Pure host arithmetic, uploaded once per (n_total, world, device) and reused by every later step."""
+    key = (n_total, world, str(device))
+    idx = _KEEP_IDX.get(key)
+    if idx is None:
+        cap = -(-n_total // world)
+        rows = []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            rows.append(np.arange(r * cap, r * cap + (hi - lo), dtype=np.int64))
+        if len(_KEEP_IDX) > 64:
+            _KEEP_IDX.clear()
+        idx = _KEEP_IDX[key] = torch.from_numpy(np.concatenate(rows)).to(device)
+    return idx
+
+
+def all_gather_fixed(local: torch.Tensor, n_total: int, group=None, virtual=None) -> torch.Tensor:
     """Concatenate, in rank order, per-rank tensors whose dim-0 sizes are ``shard_range(n_total, r, world)``
     -- known on every rank, so there is no size exchange and no host sync: ONE ``all_gather_into_tensor`` on
-    a buffer padded to the largest shard (ceil(n_total / world) rows)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    a buffer padded to the largest shard (ceil(n_total / world) rows); the padding rows of the short ranks are dropped
+    by an ``index_select`` with a cached device index (no boolean mask, no ``nonzero``).
+
+    ``virtual=(rank, world)``: no process group -- the other ranks' shards are filled with copies of the local rows
+    (the one-GPU proxy of bench.py's ``shard_proxy_8``: same buffers, same follow-up work, no collective)."""
+    if virtual is not None:
+        rank, world = virtual
+    else:
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
     lo, hi = shard_range(n_total, rank, world)
     assert local.shape[0] == hi - lo, (local.shape, lo, hi)
     if world == 1:
@@ -61,15 +88,15 @@ def all_gather_fixed(local: torch.Tensor, n_total: int, group=None) -> torch.Ten
     if local.shape[0] != cap:
         send = torch.zeros((cap,) + tail, dtype=local.dtype, device=local.device)
         send[:local.shape[0]] = local
-    recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if virtual is not None:
+        recv = send.contiguous().repeat((world,) + (1,) * len(tail))
+    else:
+        recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     if n_total == world * cap:
         return recv
     # ranks < n_total % world hold `cap` rows, the others cap - 1: drop each short rank's one padding row
-    extra = n_total % world
-    keep = torch.ones(world, cap, dtype=torch.bool)
-    keep[extra:, cap - 1] = False
-    return recv[keep.reshape(-1).to(recv.device)]
+    return recv.index_select(0, _keep_index(n_total, world, recv.device))
 
 
 def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
@@ -91,14 +118,18 @@ def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([recv[r * nmax:r * nmax + s] for r, s in enumerate(sizes)], dim=0)
 
 
-def run_window_sharded(n_windows: int, compute_rows: Callable[[int, int], torch.Tensor], group=None):
+def _rank_world(group, virtual):
+    return virtual if virtual is not None else (dist.get_rank(group), dist.get_world_size(group))
+
+
+def run_window_sharded(n_windows: int, compute_rows: Callable[[int, int], torch.Tensor], group=None, virtual=None):
     """Each rank computes rows for its contiguous slice of the window list; returns the rows of ALL
     windows on every rank (the RCCL gather of per-window proposals ahead of the global NMS)."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = _rank_world(group, virtual)
     lo, hi = shard_range(n_windows, rank, world)
     local = compute_rows(lo, hi)
     assert local.shape[0] == hi - lo
-    return all_gather_fixed(local, n_windows, group)
+    return all_gather_fixed(local, n_windows, group, virtual)
 
 
 def pack_kept(rows: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
@@ -120,13 +151,13 @@ def unpack_kept(msg: torch.Tensor):
 
 
 def run_query_sharded(n_queries: int, compute_kept: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]],
-                      group=None):
+                      group=None, virtual=None):
     """Each rank runs its contiguous query shard; returns (rows, n) of all queries in annotation order on
     every rank.  rows (3, nq, max_after, 5), n (3, nq): ONE fixed-size all_gather."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = _rank_world(group, virtual)
     lo, hi = shard_range(n_queries, rank, world)
     rows, n = compute_kept(lo, hi)
-    return unpack_kept(all_gather_fixed(pack_kept(rows, n), n_queries, group))
+    return unpack_kept(all_gather_fixed(pack_kept(rows, n), n_queries, group, virtual))
 
 
 def assemble_candidates(rows_all: torch.Tensor, q_of: torch.Tensor, slot: torch.Tensor, nq: int, K: int):
@@ -226,6 +257,19 @@ class HipHooks:
         from . import inference as inf
         return inf.prefilter(self.model, store, opt)
 
+    def ctx_rows(self, store, f_lo: int, f_hi: int):
+        """Adapted + normalised clip rows [f_lo, f_hi) of the (single) video of ``store`` -- what the pre-filter scores
+        (cone/inference.py:250-260) -- computed for that range only."""
+        from . import ops
+        return self.model.adapter_norm(ops.l2_normalize(store.vid_raw[f_lo:f_hi], 1e-5))
+
+    def cls_norm(self, store):
+        from . import ops
+        return store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)
+
+    window_scores_fn = None     # defaults of prefilter_ctx_sharded: the fused HIP window scores / stable top-k
+    topk_fn = None
+
     def project_video(self, store, row_range=None):
         from . import inference as inf
         return inf.project_video(self.model, store, row_range)
@@ -251,11 +295,36 @@ def _slice_table(wt, lo, hi, q_lo, tok_base):
     return sl
 
 
+def prefilter_one_video_ctx_sharded(store, opt, hooks, group=None):
+    """Stage A of a split that holds ONE long video (BASELINE configs 3 / 5), sharded along ctx_l: this rank adapts,
+    normalises and scores only the clip rows its window range covers (``ctx_shard``: 1 / world of the video + a W - S
+    halo), keeps a local stable top-k, and ONE all_gather of k (score, window) pairs per query yields the same
+    (nq, topk) window table on every rank -- bit-identical to the single-GPU pre-filter, ties included."""
+    if len(store.ctx_l) != 1:
+        raise ValueError("the ctx-sharded pre-filter takes a split over ONE video; several videos shard by query / window")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ctx_l = int(store.ctx_l[0])
+    _, _, f_lo, f_hi = ctx_shard(ctx_l, opt.max_v_l, rank, world)
+    ctx_local = hooks.ctx_rows(store, f_lo, f_hi)
+    idx, _ = prefilter_ctx_sharded(ctx_local, ctx_l, hooks.cls_norm(store), opt.max_v_l, opt.topk_window, group,
+                                   window_scores_fn=getattr(hooks, "window_scores_fn", None),
+                                   topk_fn=getattr(hooks, "topk_fn", None))
+    return idx.contiguous()
+
+
 @torch.no_grad()
 def predict_split_distributed(model, store, opt, mode: str = "window", group=None, hooks=None,
-                              format_shard: bool = False):
+                              format_shard: bool = False, prefilter: str = "replicated", virtual=None):
     """Stages A->C across the ranks of `group`.  Every rank holds the same FeatureStore (features replicated:
     an Ego4D split is < 1 GB, the MAD-scale stress video 12.7 GB of the 288 GB per GPU).
+
+    ``prefilter="replicated"``: stage A runs on every rank (HBM-bound and cheap for a split of short videos);
+    ``prefilter="ctx"``: ONE long video -- stage A is sharded along ctx_l (``prefilter_one_video_ctx_sharded``: one small
+    all_gather), then the window model is sharded by window as below: two collectives per step in all (BASELINE
+    configs[4]: 64 queries x one MAD-length video).
+
+    ``virtual=(rank, world)``: replay what that rank of a `world`-rank run computes, on one GPU and without a process
+    group -- the gathers are filled with copies of the local shard (bench.py's ``shard_proxy_8``; replicated stage A only).
 
     Returns ``(lists, info)``: ``info['rows'] / info['n']`` = the kept rows of ALL queries, on every rank (tensors);
     ``lists`` = the three submission lists -- of all queries on rank 0 and ``None`` elsewhere, or, with
@@ -263,10 +332,17 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     shards with the queries; a caller that wants one file concatenates the shards in rank order)."""
     from . import inference as inf
     hooks = hooks or HipHooks(model)
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = _rank_world(group, virtual)
     nq = len(store.ann)
     Nq = hooks.num_queries
-    win_idx = hooks.prefilter(store, opt)               # replicated: HBM-bound and cheap (SURVEY 8e)
+    if prefilter == "ctx":
+        if virtual is not None:
+            raise ValueError("virtual ranks replay the replicated pre-filter only")
+        win_idx = prefilter_one_video_ctx_sharded(store, opt, hooks, group)
+    elif prefilter == "replicated":
+        win_idx = hooks.prefilter(store, opt)           # replicated: HBM-bound and cheap (SURVEY 8e)
+    else:
+        raise ValueError(f"unknown pre-filter mode {prefilter!r}")
     batch_pad = inf.reference_batch_pad(store, opt, win_idx)
     q_lo, q_hi = shard_range(nq, rank, world)
     if mode == "query":
@@ -282,7 +358,7 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
             rows = hooks.window_rows(sub, opt, wt, hooks.project_video(store, vid_rows))
             cand, n_valid = inf.candidate_lists(rows, wt, wi, Nq)
             return hooks.fuse_nms(cand, n_valid, opt)
-        rows, n = run_query_sharded(nq, kept, group)
+        rows, n = run_query_sharded(nq, kept, group, virtual)
         n_windows = int((win_idx >= 0).sum()) if not _dense(store, opt, win_idx) else nq * win_idx.shape[1]
     elif mode == "window":
         wt = inf.window_table(store, opt, win_idx, batch_pad)
@@ -295,9 +371,9 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
             # the slice's queries [a, b]: only their text tokens and the clips of their videos are projected
             a, b = _query_span(store, opt, win_idx, wt, lo, hi)
             sub = inf.FeatureStore.subset(store, a, b + 1)
-            video = hooks.project_video(store, _video_row_range(store, a, b + 1))
+            video = hooks.project_video(store, _window_row_range(store, opt, win_idx, wt, lo, hi, a, b))
             return hooks.window_rows(sub, opt, _slice_table(wt, lo, hi, a, int(store.tok_off[a])), video)
-        rows_all = run_window_sharded(n_win, rows_of, group)
+        rows_all = run_window_sharded(n_win, rows_of, group, virtual)
         cand, n_valid = inf.candidate_lists(rows_all, wt, win_idx, Nq)
         rows, n = hooks.fuse_nms(cand, n_valid, opt)    # every rank, all queries: cheaper than a second collective
         n_windows = n_win
@@ -323,6 +399,14 @@ def _query_span(store, opt, win_idx, wt, lo, hi):
         return lo // K, (hi - 1) // K
     ends = wt["q_of"][[lo, hi - 1]].tolist()
     return int(ends[0]), int(ends[1])
+
+
+def _window_row_range(store, opt, win_idx, wt, lo, hi, q_a, q_b):
+    """Arena rows whose projections the windows [lo, hi) of the table may read: the band of the videos of their queries
+    (host arithmetic on the annotation order: no device read, no sync).  For ONE long video that is the whole video: its
+    top-k windows lie anywhere, and 1 / world of the windows of 64 queries already touch most clips (33 000 clips: 26
+    GFLOP of projection against 163 GFLOP of window model per rank at world 8)."""
+    return _video_row_range(store, q_a, q_b + 1)
 
 
 def _video_row_range(store, q_lo, q_hi):

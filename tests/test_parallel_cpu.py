@@ -55,9 +55,9 @@ class CheckerHooks:
     collate of the whole split, so a shard that re-derives any of them from its own queries fails here."""
     num_queries = 5
 
-    def __init__(self, opt, sd, ann, vf, qf, store):
+    def __init__(self, opt, sd, ann, vf, qf, store, ranks=None):
         self.opt, self.ann, self.store = opt, ann, store
-        self.ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+        self.ranks = ranks if ranks is not None else O.prefilter(sd, opt, ann, vf, qf)[0]
         sdt = O.as_torch_sd(sd)
         self.rows, self.meta = {}, {}
         with torch.no_grad():
@@ -85,6 +85,17 @@ class CheckerHooks:
             lst = self.ranks[r["query_id"]][:K]
             wi[i, :len(lst)] = torch.tensor(lst, dtype=torch.int32)
         return wi
+
+    # ctx-sharded pre-filter of ONE long video (exactly representable inputs: see _long_video_case): raw rows / raw cls
+    def ctx_rows(self, store, f_lo, f_hi):
+        self.ctx_rows_served = f_hi - f_lo
+        return store.vid_raw[f_lo:f_hi].clone()
+
+    def cls_norm(self, store):
+        return store.cls_raw
+
+    window_scores_fn = staticmethod(lambda v, c, W: _cpu_window_scores(v, c, W))
+    topk_fn = staticmethod(lambda x, k: _cpu_topk(x, k))
 
     def project_video(self, store, row_range=None):
         r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
@@ -275,5 +286,85 @@ def test_gloo_ctx_sharded_prefilter_equals_full_rank_list(world):
         p.start()
     for p in procs:
         p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(timeout=5) == "ok"
+
+
+# ---------------------------------------------------------------------------- ctx-sharded pre-filter -> window-sharded model
+def _long_video_case(opt, nq, ctx_l, seed):
+    """ONE long video + nq queries whose pre-filter inputs are exactly representable (clip / cls features on a coarse
+    grid: every frame score is exact in fp32 whatever the summation order, so the sharded and the whole-video scores
+    agree bit for bit and ties -- hazard H6 -- are plentiful)."""
+    ann, vf, qf = synth.make_dataset(opt, nq, 1, seed=seed, ctx_range=(ctx_l, ctx_l + 1))
+    g = np.random.default_rng(seed)
+    for k in vf:
+        vf[k] = (np.round(g.standard_normal(vf[k].shape) * 4) / 4).astype(np.float32)
+    for k in qf:
+        key = "cls_features" if "cls_features" in qf[k] else "eot_features"
+        qf[k][key] = (np.round(g.standard_normal(np.asarray(qf[k][key]).shape) * 2) / 2).astype(np.float32)
+    return ann, vf, qf
+
+
+def _composed_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cone_amd import inference as inf
+        opt = make_opt("ego4d", nms_thd=0.5, topk_window=4, eval_bsz=3, max_after_nms=5, eval_split_name="test")
+        sd = synth.make_state_dict(opt, 0)
+        for nq, ctx_l, seed in ((7, 700, 3), (2, 95, 5)):
+            ann, vf, qf = _long_video_case(opt, nq, ctx_l, seed)
+            store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"), cls_normalized=True)
+            # the single-process answer: rank lists of the whole video with the same (raw) scoring, then the oracle
+            full = _cpu_window_scores(store.vid_raw, store.cls_raw, opt.max_v_l)
+            ranks = {r["query_id"]: O.rank_windows(full[i]) for i, r in enumerate(ann)}
+            hooks = CheckerHooks(opt, sd, ann, vf, qf, store, ranks=ranks)
+            with torch.no_grad():
+                mr = O.compute_mr_results(sd, opt, ann, vf, qf, ranks)
+            fo, po, mo = O.postprocess(mr, opt)
+            hooks.served = 0
+            lists, info = par.predict_split_distributed(None, store, opt, mode="window", hooks=hooks, prefilter="ctx")
+            # stage A ran on this rank's clip range only (1 / world of the video + the halo) ...
+            w_lo, w_hi, f_lo, f_hi = par.ctx_shard(ctx_l, opt.max_v_l, rank, world)
+            assert hooks.ctx_rows_served == f_hi - f_lo < ctx_l or world == 1 or ctx_l < 2 * opt.max_v_l
+            # ... and produced the whole video's rank lists on every rank, bit for bit
+            for qi, r in enumerate(ann):
+                assert [w for w in info["win_idx"][qi].tolist() if w >= 0] == ranks[r["query_id"]][:opt.topk_window]
+            for t, ref in enumerate((fo, po, mo)):
+                for qi in range(nq):
+                    assert info["rows"][t, qi, :int(info["n"][t, qi])].tolist() == ref[qi]["predicted_times"], (t, qi)
+            assert (lists == (fo, po, mo)) if rank == 0 else (lists is None)
+            assert hooks.served <= -(-info["n_windows"] // world) + opt.topk_window
+        # virtual ranks (no collective: bench.py's shard proxy) follow the same cuts as real ones
+        ann, vf, qf = synth.make_dataset(opt, 9, 2, seed=2, ctx_range=(60, 200))
+        store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+        hooks = CheckerHooks(opt, sd, ann, vf, qf, store)
+        _, real = par.predict_split_distributed(None, store, opt, mode="window", hooks=hooks, format_shard=True)
+        served_real = hooks.served
+        hooks.served = 0
+        _, virt = par.predict_split_distributed(None, store, opt, mode="window", hooks=hooks, format_shard=True,
+                                                virtual=(rank, world))
+        assert virt["shard"] == real["shard"] and virt["n_windows"] == real["n_windows"]
+        assert hooks.served == served_real                  # the same slice of the window list went through the model
+        lo, hi = par.shard_range(real["n_windows"], rank, world)
+        assert hooks.served == hi - lo
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ctx_sharded_prefilter_feeds_window_sharded_model(world):
+    """BASELINE configs[4]'s composition (one long video: pre-filter sharded along ctx_l -> window-sharded model -> one
+    gather of proposal rows -> fusion + NMS): equals the single-process oracle bit for bit on every rank."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_composed_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=400)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out.get(timeout=5) == "ok"
