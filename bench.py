@@ -17,6 +17,12 @@ rows of all shards are all-gathered over RCCL.  Extra objects on the same line:
                        FLOPs = 2*M*N*K with the M actually processed;
   * `strong_scaling` (N > 1) -- BASELINE configs[3]: ONE such split sharded by window over the N ranks
                        (cone_amd.parallel.predict_split_distributed, one all_gather of proposal rows);
+  * `config5_sharded`, `prefilter_mad_ctx_sharded` (N > 1) -- BASELINE configs[4] and [2] over the N ranks: pre-filter
+                       sharded along ctx_l, window model sharded by window;
+  * `shard_proxy_8` (N = 1) -- rank 0's share of the 8-rank window-sharded split replayed on one GPU (no collective)
+                       and the strong-scaling efficiency it projects;
+  * `ms_per_step_full_forward` -- the headline step with the saliency head and the intermediate decoder layer's heads
+                       computed too, as the reference's CONE.forward does (and never reads);
   * `prefilter_mad`, `latency_config1`, `config5` (N = 1) -- BASELINE configs[2], [0] and [4] on one GPU: the
                        MAD-scale pre-filter against the HBM roofline (1 and 64 queries), the single-query latency,
                        64 queries x one MAD-length video end to end;
@@ -289,6 +295,89 @@ def bench_config5(ctx_l=33_000, queries=64, steps=10):
             "ms_per_step_split_bf16": None if dts is None else round(dts * 1e3, 3)}
 
 
+def bench_shard_proxy(model, store, opt, ms_1gpu, steps=5, warmup=2, world=8):
+    """ONE GPU's share of BASELINE configs[3] at `world` ranks, measured on this GPU without a process group: what rank 0
+    of predict_split_distributed(mode="window") executes -- replicated stage A, project + window model + matching on its
+    1 / world slice of the window list, fusion + NMS over ALL queries (on a gather buffer filled with copies of the local
+    rows), the JSON rows of its own query shard.  projected_efficiency = ms_per_step(1 GPU) / (world x proxy ms): the
+    strong-scaling efficiency an 8-GPU run would show if the one 1.6 MB all_gather were free (it is latency-bound: one
+    hop to each peer over xGMI)."""
+    from cone_amd import parallel as par
+    fn = lambda: par.predict_split_distributed(model, store, opt, mode="window", format_shard=True, virtual=(0, world))
+    dt, (_, info) = _timed(fn, steps, warmup)
+    lo, hi = par.shard_range(info["n_windows"], 0, world)
+    return {"what": f"rank 0 of {world} of the window-sharded split (BASELINE configs[3]) replayed on one GPU, no collective",
+            "world": world, "windows_of_rank": hi - lo, "queries_formatted": info["shard"][1] - info["shard"][0],
+            "proxy_ms": round(dt * 1e3, 3), "ms_per_step_1gpu": round(ms_1gpu, 3),
+            "projected_speedup": round(ms_1gpu / (dt * 1e3), 2),
+            "projected_efficiency": round(ms_1gpu / (world * dt * 1e3), 4)}
+
+
+def _mad_rows(lo, hi, dv, dev, block=62_000):
+    """Rows [lo, hi) of THE synthetic MAD-scale video (row block b is drawn from generator seed 1000 + b, so every rank
+    sees the same video whatever range it holds -- the halo rows of neighbouring ranks agree), L2-normalised."""
+    parts = []
+    for b in range(lo // block, (hi - 1) // block + 1):
+        g = torch.Generator(device=dev).manual_seed(1000 + b)
+        x = torch.randn(block, dv, device=dev, generator=g)
+        parts.append(x[max(lo - b * block, 0):min(hi - b * block, block)])
+    return ops.l2_normalize(torch.cat(parts, 0), 0.0)
+
+
+def bench_prefilter_mad_ctx_sharded(dist, rank, world, timed_region, ctx_l=6_200_000, dv=512, W=125, topk=30):
+    """BASELINE configs[2] over the N ranks: the 12.7 GB video sharded along ctx_l (each rank holds and streams 1 / N of the
+    clips + a W - S halo), local fused window scores + stable top-30, ONE all_gather of 30 (score, window) pairs per
+    query, exact merge (cone_amd.parallel.prefilter_ctx_sharded).  Roofline: the whole video's algorithmic bytes over
+    the max-over-ranks time against N x 8 TB/s."""
+    from cone_amd import parallel as par
+    dev = torch.device("cuda", torch.cuda.current_device())
+    w_lo, w_hi, f_lo, f_hi = par.ctx_shard(ctx_l, W, rank, world)
+    local = _mad_rows(f_lo, f_hi, dv, dev)
+    nw = ops.num_windows(ctx_l, W)
+    out = {"workload": f"BASELINE.json configs[2] sharded along ctx_l over {world} ranks: ctx_l={ctx_l} x d={dv} fp32 "
+                       f"({ctx_l * dv * 4 / 1e9:.1f} GB in all, {local.shape[0] * dv * 4 / 1e9:.2f} GB on rank 0), "
+                       f"window_len={W}, {nw} windows, stable top-{topk}; one all_gather of {topk} (score, window) pairs per query",
+           "ranks_seen": dist.get_world_size(), "collectives_per_call": 1}
+    for nq in (1, 64):
+        g = torch.Generator(device=dev).manual_seed(7)
+        txt = ops.l2_normalize(torch.randn(nq, dv, device=dev, generator=g), 0.0)
+        dt, _, _ = timed_region(lambda: par.prefilter_ctx_sharded(local, ctx_l, txt, W, topk))
+        steps = timed_region.steps
+        alg = 4.0 * ctx_l * dv + nq * 4.0 * (dv + nw)
+        out[f"q{nq}"] = {"queries": nq, "ms_per_call": round(dt / steps * 1e3, 3),
+                         "windows_per_s": round(nw * nq * steps / dt, 1),
+                         "roofline": {"bound": "hbm", "achieved": round(alg * steps / dt / 1e9, 1),
+                                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                      "frac": round(alg * steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                      "algorithmic_bytes": int(alg), "traffic": None,
+                                      "note": "whole-path time (kernel + gather + merge), all ranks; per-kernel counter "
+                                              "traffic: prefilter_mad (N = 1)"}}
+    del local
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_config5_sharded(dist, world, timed_region, ctx_l=33_000, queries=64):
+    """BASELINE configs[4] as stated: 64 concurrent queries over ONE MAD-length video on the N ranks -- pre-filter sharded
+    along ctx_l (one all_gather of top-30 pairs), window model sharded by window (one all_gather of proposal rows),
+    fusion + NMS on every rank, JSON rows of the rank's query shard (predict_split_distributed(prefilter="ctx"))."""
+    from cone_amd import parallel as par
+    opt = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=30)
+    model, _ = build_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 1).items()})
+    ann, vf, qf = synth.make_dataset(opt, queries, 1, seed=0, ctx_range=(ctx_l, ctx_l + 1))
+    store = inf.FeatureStore(opt, ann, vf, qf)         # the same video and queries on every rank (features replicated)
+    fn = lambda: par.predict_split_distributed(model, store, opt, mode="window", prefilter="ctx", format_shard=True)
+    dt, _, (_, info) = timed_region(fn)
+    steps = timed_region.steps
+    return {"workload": f"BASELINE.json configs[4]: {queries} queries x one MAD-length video (ctx_l {ctx_l}, d 512, "
+                        f"window_len 125), top-30 => {info['n_windows']} windows, over {world} ranks: ctx-sharded pre-filter "
+                        "-> window-sharded model -> one gather of proposal rows -> fusion + NMS + JSON rows",
+            "scaling": "strong", "ms_per_step": round(dt / steps * 1e3, 3),
+            "windows_per_s": round(info["n_windows"] * steps / dt, 1), "queries_per_s": round(queries * steps / dt, 1),
+            "ranks_seen": dist.get_world_size(), "collectives_per_step": 2}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +401,8 @@ def main():
                     help="only the headline timed region (profiling runs): skip the full-forward region, the split_bf16 "
                          "region and the configs[0]/[2]/[4] figures")
     ap.add_argument("--cpu_queries", type=int, default=400)
+    ap.add_argument("--mad_ctx_l", type=int, default=6_200_000,
+                    help="clips of the MAD-scale stress video of prefilter_mad_ctx_sharded (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -391,6 +482,7 @@ def main():
             dt = float(t.item())
         return dt, rec, res
 
+    timed_region.steps = args.steps
     dt, rec, (out, dp) = timed_region(step)
     n_windows = dp["n_windows"]
 
@@ -505,8 +597,14 @@ def main():
             "ms_per_step": round(sdt / args.steps * 1e3, 2), "n_windows": sinfo["n_windows"],
             "ranks_seen": dist.get_world_size(), "collectives_per_step": 1})
         del store0
+        if not args.no_extras:
+            # the other multi-GPU configs of BASELINE.json, as stated (collectives inside: every rank runs them)
+            guarded("config5_sharded", lambda: bench_config5_sharded(dist, world, timed_region))
+            guarded("prefilter_mad_ctx_sharded",
+                    lambda: bench_prefilter_mad_ctx_sharded(dist, rank, world, timed_region, ctx_l=args.mad_ctx_l))
 
     if world == 1 and not args.no_extras:
+        guarded("shard_proxy_8", lambda: bench_shard_proxy(model, store, opt, dt / args.steps * 1e3))
         del store, dp, out
         model._ws.buf = None
         torch.cuda.empty_cache()

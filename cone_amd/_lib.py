@@ -178,6 +178,24 @@ def load():
     return lib
 
 
+_pylists = None
+
+
+def pylists():
+    """The host-side list builder (cone_amd/csrc/pylists.c, ctypes.PyDLL: the call keeps the GIL)."""
+    global _pylists
+    if _pylists is None:
+        path = os.path.join(HERE, "_cone_pylists.so")
+        if not os.path.exists(path):
+            raise ConeHipError(f"{path} is missing: build with `python -m cone_amd.build`")
+        lib = C.PyDLL(path)
+        fn = lib.cone_fill_predicted_times
+        fn.restype = C.py_object
+        fn.argtypes = [C.py_object, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.py_object]
+        _pylists = lib
+    return _pylists
+
+
 def check(rc: int):
     if rc != 0:
         raise ConeHipError(f"libcone_hip error {rc}: {load().cone_last_error().decode()}")

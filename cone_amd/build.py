@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcone_hip.so")
+PYLISTS = os.path.join(HERE, "_cone_pylists.so")      # host helper (CPython C API): kept rows -> submission lists
 SOURCES = ["api.hip", "gemm.hip", "rowops.hip", "attention.hip", "window_ops.hip", "prefilter.hip",
            "postproc.hip", "prof.hip", "dec_cross.hip", "metrics.hip", "ffn.hip", "criterion.hip", "dec_cross_mfma.hip", "ffn_split.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -55,7 +56,21 @@ def build(force: bool = False) -> str:
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_pylists()
     return LIB
+
+
+def build_pylists() -> str:
+    """csrc/pylists.c -> _cone_pylists.so (gcc; plain C against the interpreter's own headers, no GPU code)."""
+    import sysconfig
+    src = os.path.join(CSRC, "pylists.c")
+    if os.path.exists(PYLISTS) and os.path.getmtime(PYLISTS) >= max(os.path.getmtime(src), os.path.getmtime(__file__)):
+        return PYLISTS
+    r = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", PYLISTS],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gcc failed for pylists.c:\n{r.stdout}\n{r.stderr}")
+    return PYLISTS
 
 
 if __name__ == "__main__":

@@ -630,12 +630,23 @@ def result_skeletons(ann, opt):
                      for _ in range(3))
 
 
+_PT_KEY = "predicted_times"
+
+
 def _format_results(ann, opt, rows, n, skeletons=None):
-    lists = _rows_to_lists(rows, n)
+    """rows (3, nq, max_after, 5) fp64, n (3, nq) int32 (device or host) -> the three lists.  One D2H copy each, then ONE
+    pass of the C helper per list (cone_amd/csrc/pylists.c: floats, rows, per-query lists and the dict slot in one loop)
+    instead of tensor.tolist() + a Python loop of 3 x nq assignments."""
+    from . import _lib
     out = skeletons if skeletons is not None else result_skeletons(ann, opt)
+    nq, A = int(rows.shape[1]), int(rows.shape[2])
+    if nq == 0:
+        return out
+    rows_h = np.ascontiguousarray(rows.detach().cpu().numpy(), dtype=np.float64)
+    n_h = np.ascontiguousarray(n.detach().cpu().numpy(), dtype=np.int32)
+    fill = _lib.pylists().cone_fill_predicted_times
     for t in range(3):
-        for item, pt in zip(out[t], lists[t]):
-            item["predicted_times"] = pt
+        fill(out[t], rows_h[t].ctypes.data, n_h[t].ctypes.data, nq, A, _PT_KEY)
     return out
 
 

@@ -1549,7 +1549,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, CONE_BENCH_ONE_DEVICE="1", CONE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--queries", "96", "--videos", "6"]
+           "--warmup", "1", "--queries", "96", "--videos", "6", "--mad_ctx_l", "400000"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1562,6 +1562,12 @@ def test_bench_two_ranks_on_one_device():
     assert st["ranks_seen"] == 2 and st["scaling"] == "strong" and st["collectives_per_step"] == 1
     assert st["n_windows"] == nw and st["value"] > 0
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
+    assert res["ms_per_step_full_forward"] > 0
+    # BASELINE configs[4] / [2] over the ranks: ctx-sharded pre-filter -> window-sharded model; ctx-sharded MAD-scale stream
+    c5 = res["config5_sharded"]
+    assert c5["ranks_seen"] == 2 and c5["collectives_per_step"] == 2 and c5["ms_per_step"] > 0, c5
+    pm = res["prefilter_mad_ctx_sharded"]
+    assert pm["ranks_seen"] == 2 and pm["q1"]["roofline"]["peak"] == 16000.0 and pm["q64"]["ms_per_call"] > 0, pm
 
 
 @pytest.mark.parametrize("q_base", [0, 8])
