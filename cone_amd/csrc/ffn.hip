@@ -49,10 +49,10 @@ typedef float f32x4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int ffn_swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
 
-constexpr int FFN_ROWS = 128;                     // token rows per workgroup (8 waves x 16)
+constexpr int FFN_ROWS = 128;                     // token rows per workgroup of the large-M form (8 waves x 16)
 constexpr int FFN_STAGE = 2 * 16 * 256;           // floats per ring stage: W1 image (16 slabs) + W2 image (16 slabs)
 constexpr int FFN_NST = 4;                        // ring depth: a stage is refilled two barriers after its last read
-constexpr int FFN_NPIECE = 4;                     // 1-KiB LDS-DMA pieces per wave per chunk (32 pieces / 8 waves)
+// 1-KiB LDS-DMA pieces per wave per chunk: 32 pieces / NW waves (NW = 8: 4, NW = 4: 8)
 
 struct FfnArgs {
     const float* X; int ldx;                      // (M, 256) block input = residual of the feed-forward block
@@ -93,8 +93,13 @@ __device__ __forceinline__ void ffn_layernorm_regs(f32x4f (&v)[16], float& rstd)
     rstd = 1.0f / sqrtf(s2 * (1.0f / 256.0f) + 1e-5f);
 }
 
-template <bool PROJ, bool QKV>
-__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
+// NW = waves per workgroup = 16-row groups per tile.  NW = 8 (128-row tiles, two waves per SIMD) is the throughput form.
+// NW = 4 (64-row tiles, ONE wave per SIMD) is the small-M form: a wave runs the very same instruction sequence on its 16
+// rows (bit-identical results), but has its SIMD's matrix pipe to itself -- a tile takes half the time -- and the tile
+// grid is twice as fine; chosen by the launcher when the 128-row tiles would leave at least half of the CUs idle.
+template <bool PROJ, bool QKV, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
+    constexpr int FFN_ROWS = 16 * NW, FFN_NPIECE = 32 / NW, NT = 64 * NW, HW = NW / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* b1s = smem + FFN_NST * FFN_STAGE;
     int M = p.M;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     // every per-channel parameter vector goes to LDS once per workgroup: b1 (ff), then 6 x 256: b2, ln_g, ln_b and
     // (PROJ) bo, pg, pb -- no ordinary global load remains inside the tile loop besides the tile's own rows
     float* prm = b1s + ff;
-    for (int i = tid; i < (ff >> 2); i += 512)
+    for (int i = tid; i < (ff >> 2); i += NT)
         reinterpret_cast<f32x4f*>(b1s)[i] = reinterpret_cast<const f32x4f*>(p.b1)[i];
     if (tid < 64) {
         reinterpret_cast<f32x4f*>(prm)[tid] = reinterpret_cast<const f32x4f*>(p.b2)[tid];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     }
     float* qbs = prm + 1536;
     if (QKV)
-        for (int i = tid; i < (p.n_qkv >> 2); i += 512)
+        for (int i = tid; i < (p.n_qkv >> 2); i += NT)
             reinterpret_cast<f32x4f*>(qbs)[i] = reinterpret_cast<const f32x4f*>(p.qb)[i];
 
     // ---- LDS-DMA pieces.  A feed-forward chunk = 32 slabs of [16 rows][16 floats]; wave w issues slabs 4w .. 4w+3
@@ -138,14 +143,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
     // piece's source is a wave-uniform base (SGPRs) + ONE per-lane offset + scalar multiples of the piece / chunk index.
     const int drow = lane >> 2;
     const int dch = (lane & 3) ^ ffn_swz16(drow);
-    const bool w2side = wave >= 4;
+    const bool w2side = wave >= HW;
     const float* fbase = w2side ? p.W2 : p.W1;                         // wave-uniform
-    const int foff = w2side ? (16 * 4 * (wave - 4) + drow) * ff + 4 * dch   // W2[16 t + row][h0 + 4 ch ..], t = 4 (w - 4) + i
-                            : drow * 256 + 16 * 4 * wave + 4 * dch;         // W1[h0 + row][16 q + 4 ch ..],  q = 4 w + i
+    const int foff = w2side ? (16 * FFN_NPIECE * (wave - HW) + drow) * ff + 4 * dch   // W2[16 t + row][h0 + 4 ch ..], t = NPIECE (w - HW) + i
+                            : drow * 256 + 16 * FFN_NPIECE * wave + 4 * dch;         // W1[h0 + row][16 q + 4 ch ..],  q = NPIECE w + i
     const int fpiece = w2side ? 16 * ff : 16;                          // + i * fpiece
     const int fchunk = w2side ? 16 : 16 * 256;                         // + c * fchunk
     // projection chunk g: Wo[32 g + 16 (pid / 16) + row][16 (pid % 16) + 4 ch ..], pid = 4 w + i
-    const int poff = PROJ ? (16 * (wave >> 2) + drow) * 256 + 16 * 4 * (wave & 3) + 4 * dch : 0;
+    const int poff = PROJ ? (16 * (wave / HW) + drow) * 256 + 16 * FFN_NPIECE * (wave % HW) + 4 * dch : 0;
     // piece i of chunk g of the current tile (projection chunks first, then the feed-forward chunks); g >= G = the
     // first chunks of the NEXT tile this workgroup will run -- the same weights, so the ring simply runs on (after
     // the last tile they land in stages nobody reads again).  sb = (chunks consumed before this tile) % FFN_NST.
@@ -172,6 +177,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
 #define FFN_RD(stg, off) (*reinterpret_cast<const f32x4f*>((stg) + (off) + rd))
 #define FFN_STAGE_OF(g) (smem + ((sb + (g)) % FFN_NST) * FFN_STAGE)
 #define FFN_SB() __builtin_amdgcn_sched_barrier(0)
+    // unit u of a chunk (8 units) issues the wave's share of the next-but-one chunk: every other unit at 4 pieces per wave,
+    // every unit at 8
+#define FFN_STREAM(g, u) { if (FFN_NPIECE == 8) stream_piece(g, u); else if ((u) & 1) stream_piece(g, (u) >> 1); }
     // a counted wait + barrier ends every chunk: the next chunk has landed (all but the 4 pieces issued last, which
     // belong to the chunk after it), and every wave is done reading the stage that the next pieces will overwrite
 #define FFN_END_CHUNK()                                                           \
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
                     FFN_MFMA(ha[r & 1], wb[r], ar[2 * u + 1][r])
                     FFN_MFMA(hb[r & 1], vb[r], ar[2 * u + 1][r])
                 }
-                if (u & 1) stream_piece(g + 2, u >> 1);            // the next-but-one chunk's pieces ride behind MFMAs
+                FFN_STREAM(g + 2, u)                               // the next-but-one chunk's pieces ride behind MFMAs
                 if (u < 7) { wa = na; wb = nb; va = nva; vb = nvb; }
             }
             xr[2 * g] += ha[0] + ha[1];
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
             else { va = FFN_RD(st, 4096); vb = FFN_RD(st, 4096 + 256); }       // unit 0 of GEMM2(0), next iteration
             FFN_SB();
             FFN_MM_A(hp, wa, wb, xr, 2 * u)
-            if (u & 1) stream_piece(NP + 2, u >> 1);
+            FFN_STREAM(NP + 2, u)
             if (u < 7) { wa = na; wb = nb; }
         }
         FFN_SB();
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
                 FFN_SB();
                 FFN_MM_AY(hp, wa, wb, xr, 2 * u, va, vb, h, 2 * u)
             }
-            if (u & 1) stream_piece(NP + i + 2, u >> 1);
+            FFN_STREAM(NP + i + 2, u)
             if (u < 7) { wa = na; wb = nb; }
             va = nva; vb = nvb;
         }
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
                     FFN_MFMA(ha[r & 1], wb[r], y[2 * u + 1][r])
                     FFN_MFMA(hb[r & 1], vb[r], y[2 * u + 1][r])
                 }
-                if (u & 1) stream_piece(NP + nc + g + 2, u >> 1);
+                FFN_STREAM(NP + nc + g + 2, u)
                 if (u < 7) { wa = na; wb = nb; va = nva; vb = nvb; }
             }
             FFN_SB();
@@ -494,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs p) {
 #undef FFN_MFMA
 #undef FFN_END_CHUNK
 #undef FFN_SB
+#undef FFN_STREAM
 #undef FFN_STAGE_OF
 #undef FFN_RD
 
@@ -503,31 +512,45 @@ bool ffn_fused_qkv_fits(int ff, int n_qkv) {
            (size_t)(FFN_NST * FFN_STAGE + ff + 6 * 256 + n_qkv) * sizeof(float) <= 160 * 1024;
 }
 
-template <bool PROJ, bool QKV>
-static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
+template <bool PROJ, bool QKV, int NW>
+static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
     CONE_REQUIRE(lds <= 160 * 1024, "fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff, a.n_qkv);
     // once per process: the opt-in to > 64 KiB of LDS (a property of the code object) and the CU count that sizes
-    // the persistent grid (one workgroup per CU: 132 KiB of LDS, 512 threads at <= 256 VGPRs)
+    // the persistent grid (one workgroup per CU: 132 KiB of LDS, 64 NW threads at <= 256 VGPRs)
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     static int n_cu = 0;
     std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
         int dev = 0;
         if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
         if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     });
     CONE_CHECK_HIP(attr_rc);
-    const int tiles = (a.M + FFN_ROWS - 1) / FFN_ROWS;
+    if (n_cu_out) { *n_cu_out = n_cu; return 0; }
+    const int tiles = (a.M + 16 * NW - 1) / (16 * NW);
     const int grid = tiles < n_cu ? tiles : n_cu;
     // FLOPs of a record: 4 * M * ff * 256 for the block, + 2 * M * 256 * 256 with the projection
     // (+ 2 * M * n_qkv * 256 with the fused q | k | v projection: booked as n_qkv / 2 extra hidden units)
     ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
-    hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV>), dim3((unsigned)grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
+}
+
+// Tile height by the HOST-known row bound M (never by the device-side count): 64-row tiles (one wave per SIMD) when the
+// 128-row tiles would occupy at most half of the CUs -- every 64-row tile then has a CU to itself and finishes in half the
+// time; the rows' results do not depend on the choice (same per-wave instruction sequence).
+template <bool PROJ, bool QKV>
+static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
+    int n_cu = 0;
+    const int rc = launch_ffn_nw<PROJ, QKV, 8>(a, s, &n_cu);
+    if (rc) return rc;
+    const int tiles128 = (a.M + 127) / 128;
+    if (!QKV && 2 * tiles128 <= n_cu) return launch_ffn_nw<PROJ, QKV, 4>(a, s, nullptr);
+    return launch_ffn_nw<PROJ, QKV, 8>(a, s, nullptr);
 }
 
 int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,

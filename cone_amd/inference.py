@@ -671,6 +671,41 @@ def query_chunks(nq: int, opt):
     return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
+def _graph_key(model, opt):
+    return (id(model), model._handle.value if getattr(model, "_handle", None) is not None else None, opt.topk_window,
+            opt.eval_bsz, opt.max_v_l, opt.nms_thd, opt.max_before_nms, opt.max_after_nms, bool(opt.no_sort_results),
+            bool(getattr(opt, "need_saliency", False)), bool(getattr(opt, "need_aux", False)),
+            int(getattr(opt, "window_batch", 32768)), float(opt.clip_length))
+
+
+@torch.no_grad()
+def _graph_replay(model, store: FeatureStore, opt):
+    """Stages A->C of ``store`` as ONE hipGraph launch (``opt.hip_graph``): the latency path for a split that is
+    evaluated again and again at the same shapes -- a resident video queried repeatedly (BASELINE configs[0]: 1 query, 20
+    windows: ~110 launches of a few microseconds each, bound by the host's launch rate when issued one by one).  The
+    device pipeline never synchronises and takes every size from host metadata, so it captures as it is: after one
+    eager warm-up (allocations, position tables, LDS attributes) the same call runs under stream capture; the store's
+    arenas are the graph's inputs (refill them in place -- ``vid_raw.copy_`` / ``tok_raw.copy_`` / ``cls_raw.copy_`` --
+    for new features of the same shapes), the returned tensors its outputs (valid until the next replay).
+    Only dense selections (every video holds at least top-k windows: no data-dependent size anywhere)."""
+    K, S = opt.topk_window, int(opt.max_v_l / 2)
+    if min(store.ctx_l) <= (K - 2) * S:
+        raise ValueError("hip_graph needs a dense window selection (every video at least topk_window windows)")
+    cache = store.__dict__.setdefault("_graphs", {})
+    key = _graph_key(model, opt)
+    hit = cache.get(key)
+    if hit is None:
+        device_pipeline(model, store, opt)              # warm-up: workspace, static tables, kernel attributes
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            dp = device_pipeline(model, store, opt)
+        hit = cache[key] = (g, dp)
+    g, dp = hit
+    g.replay()
+    return dict(dp)
+
+
 def predict_split(model, store: FeatureStore, opt):
     """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info.
 
@@ -692,7 +727,10 @@ def predict_split(model, store: FeatureStore, opt):
         return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
     chunks = query_chunks(len(store.ann), opt)
     if len(chunks) == 1:
-        dp = device_pipeline(model, store, opt)         # enqueued; nothing in it waits for the GPU
+        if getattr(opt, "hip_graph", False):
+            dp = _graph_replay(model, store, opt)       # the whole launch sequence as ONE hipGraph launch
+        else:
+            dp = device_pipeline(model, store, opt)     # enqueued; nothing in it waits for the GPU
         skel = result_skeletons(store.ann, opt)         # host work that needs no result: under the GPU's time
         torch.cuda.synchronize()
         dp["model_seconds"] = time.time() - t0

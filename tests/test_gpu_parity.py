@@ -180,6 +180,35 @@ def test_fused_ffn_matches_float64(M, ff):
     assert bool(torch.isnan(R[M:]).all())
 
 
+def test_fused_tail_small_m_form_is_bit_identical():
+    """ffn.hip runs 64-row tiles on 4 waves (one per SIMD: half the time per tile, twice the grid) when the 128-row tiles
+    would leave half of the CUs idle, 128-row tiles on 8 waves otherwise: the same per-wave instruction sequence, so a
+    row's result must not depend on which form -- i.e. on how many rows -- it was computed with."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(11)
+    M, m, ff = 40_000, 3000, 1024                     # 313 tiles of 128 -> the 8-wave form; 24 tiles -> the 4-wave form
+    X = (torch.randn(M, 256, generator=g) * 1.5).to(dev)
+    A = torch.randn(M, 256, generator=g).to(dev)
+    d = lambda t: t.to(dev).contiguous()
+    W1, b1 = d(torch.randn(ff, 256, generator=g) / 16), d(torch.randn(ff, generator=g) * 0.2)
+    W2, b2 = d(torch.randn(256, ff, generator=g) / ff ** 0.5), d(torch.randn(256, generator=g) * 0.2)
+    Wo, bo = d(torch.randn(256, 256, generator=g) / 16), d(torch.randn(256, generator=g) * 0.2)
+    lg, lb, pg, pb = (d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g)),
+                      d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g) * 0.3))
+    lib, P = _lib.load(), _lib.ptr
+    big, small = torch.empty(M, 256, device=dev), torch.empty(m, 256, device=dev)
+    _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(big), M, ff, _lib.stream()))
+    _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(small), m, ff, _lib.stream()))
+    assert torch.equal(big[:m], small)
+    big2, small2 = X.clone(), X[:m].clone()
+    _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(big2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
+                                      P(big2), M, ff, _lib.stream()))
+    _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(small2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
+                                      P(small2), m, ff, _lib.stream()))
+    assert torch.equal(big2[:m], small2)
+
+
 @pytest.mark.parametrize("n,dim", [(5, 256), (1000, 768), (3, 512), (77, 1024)])
 def test_layernorm_matches_torch(n, dim):
     from cone_amd import _lib
@@ -1794,3 +1823,31 @@ def test_split_bf16_row_gemm_matches_float64(M, N):
                                   None, M, N, 256, 0, _lib.stream()))
     torch.cuda.synchronize()
     assert err <= 2.0 * maxdiff(out32, ref) + 1e-6, (err, maxdiff(out32, ref))
+
+
+def test_hip_graph_replay_equals_eager_pipeline():
+    """opt.hip_graph: stages A->C captured once and replayed as one hipGraph launch -- bit-identical lists, also after the
+    store's arenas were refilled in place with another query's / video's features (the graph's inputs are the arenas)."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32)
+    ann, vf, qf = synth.make_dataset(opt, 3, 1, seed=5, ctx_range=(900, 901), lq_range=(12, 13))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    eager, _ = inf.predict_split(model, store, opt)
+    gopt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32, hip_graph=True)
+    for _ in range(3):
+        got, info = inf.predict_split(model, store, gopt)
+        assert got == eager
+    assert len(store._graphs) == 1
+    # same shapes, other features: refill the arenas in place, replay
+    ann2, vf2, qf2 = synth.make_dataset(opt, 3, 1, seed=6, ctx_range=(900, 901), lq_range=(12, 13))
+    other = inf.FeatureStore(opt, ann2, vf2, qf2)
+    ref2, _ = inf.predict_split(model, other, opt)
+    store.vid_raw.copy_(other.vid_raw); store.tok_raw.copy_(other.tok_raw); store.cls_raw.copy_(other.cls_raw)
+    got2, _ = inf.predict_split(model, store, gopt)
+    strip = lambda lists: [[{k: v for k, v in it.items() if k == "predicted_times"} for it in l] for l in lists]
+    assert strip(got2) == strip(ref2)
+    # a selection that is not dense cannot be captured (data-dependent sizes): refused, not silently eager
+    short = synth.make_dataset(opt, 2, 1, seed=7, ctx_range=(100, 101))
+    with pytest.raises(ValueError):
+        inf.predict_split(model, inf.FeatureStore(opt, *short), gopt)
