@@ -107,104 +107,118 @@ __global__ __launch_bounds__(256) void window_combine_kernel(const float* __rest
     win[(size_t)q * (nh + 1) + i] = m;
 }
 
-// Two-level stable top-k for long rows: level 1 -- one workgroup per chunk of TK_CH scores keeps the chunk in LDS and
-// extracts its own stable top-k (k short passes over LDS instead of k passes over the whole row in memory); level 2 --
-// topk_merge_kernel picks the k best of the (chunks x k) candidates with the same (score desc, index asc) order.  Chunks
-// cover ascending index ranges and every list is (score desc, index asc), so the merged list is the row's stable
-// descending order (the argument of parallel.merge_topk).
+// Two-level stable top-k for long rows: level 1 -- one workgroup per chunk of TK_CH scores extracts the chunk's own
+// stable top-k; level 2 -- topk_merge_kernel picks the k best of the (chunks x k) candidates with the same (score desc,
+// index asc) order.  Chunks cover ascending index ranges and every list is (score desc, index asc), so the merged list is
+// the row's stable descending order (the argument of parallel.merge_topk).
+//
+// Both levels run the same barrier-free selection (tk_select): every thread holds its share of the values in registers,
+// each WAVE extracts the top-k of its own quarter by k passes of (register scan, 6-step shuffle arg-max) -- no LDS traffic,
+// no workgroup barrier inside the passes -- and wave 0 merges the four sorted lists (4 k candidates, again in registers)
+// behind ONE barrier.  (Round 2 re-read the chunk from LDS in every pass behind three barriers: 156 us for 64 rows of
+// 100 001 windows; this form: see profiles/README.md.)
 constexpr int TK_CH = 4096;
-__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ sc, int64_t n, int k,
-                                                         float* __restrict__ cval, int* __restrict__ cidx, int n_chunks) {
-    __shared__ float v_s[TK_CH];
-    __shared__ float s_v[4];
-    __shared__ int s_i[4];
-    __shared__ float best_v;
-    __shared__ int best_i;
-    const int q = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)ch * TK_CH;
-    const int m = (int)min((int64_t)TK_CH, n - base);
-    const float* row = sc + (size_t)q * n + base;
-    for (int i = tid; i < m; i += 256) v_s[i] = row[i];
-    __syncthreads();
+constexpr int TK_PT = TK_CH / 256;      // values per thread
+constexpr int TK_KMAX = 256;            // candidates per wave list held in LDS (4 lists)
+
+// order of the selection: a precedes b iff a.v > b.v or (a.v == b.v and a.i < b.i); "after last" = strictly later
+__device__ __forceinline__ bool tk_after(float v, int i, float lv, int li_) { return (v < lv) || (v == lv && i > li_); }
+__device__ __forceinline__ bool tk_better(float v, int i, float bv, int bi) { return (v > bv) || (v == bv && i < bi); }
+
+// One wave: k passes over PT (value, index) pairs per lane (index 0x7fffffff = empty slot); pass p's winner goes to
+// out_v[p] / out_i[p] (lane 0 writes); returns nothing -- lists shorter than k are padded with (-inf, 0x7fffffff).
+template <int PT>
+__device__ __forceinline__ void tk_wave_select(const float (&v)[PT], const int (&ix)[PT], int k, float* out_v, int* out_i,
+                                               int used = PT /* slots that can hold a value (wave-uniform) */) {
+    const int lane = threadIdx.x & 63;
     float last_v = INFINITY;
     int last_i = -1;
-    float* ov = cval + ((size_t)q * n_chunks + ch) * k;
-    int* oi = cidx + ((size_t)q * n_chunks + ch) * k;
     for (int p = 0; p < k; ++p) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int j = tid; j < m; j += 256) {
-            const float v = v_s[j];
-            const bool after = (v < last_v) || (v == last_v && j > last_i);
-            if (after && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
-        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u)
+            if (u < used && ix[u] != 0x7fffffff && tk_after(v[u], ix[u], last_v, last_i) && tk_better(v[u], ix[u], bv, bi)) { bv = v[u]; bi = ix[u]; }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            const float ov2 = __shfl_xor(bv, o, 64);
-            const int oi2 = __shfl_xor(bi, o, 64);
-            if (ov2 > bv || (ov2 == bv && oi2 < bi)) { bv = ov2; bi = oi2; }
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (tk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
         }
-        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float v = s_v[0];
-            int i = s_i[0];
-            for (int w = 1; w < 4; ++w)
-                if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
-            best_v = v; best_i = i;
-            ov[p] = i == 0x7fffffff ? -INFINITY : v;
-            oi[p] = i == 0x7fffffff ? 0x7fffffff : (int)(base + i);
+        if (lane == 0) { out_v[p] = bi == 0x7fffffff ? -INFINITY : bv; out_i[p] = bi; }
+        if (bi == 0x7fffffff) {                       // (wave-uniform) nothing left: pad the rest of the list
+            for (int r = p + 1 + lane; r < k; r += 64) { out_v[r] = -INFINITY; out_i[r] = 0x7fffffff; }
+            break;
         }
-        __syncthreads();
-        last_v = best_v;
-        last_i = best_i;
-        __syncthreads();
+        last_v = bv; last_i = bi;
     }
 }
 
+// Workgroup of 256: per-wave lists into LDS, then wave 0 merges the four lists into (gv, gi)[0 .. k) in global memory.
+template <int PT>
+__device__ __forceinline__ void tk_block_select(const float (&v)[PT], const int (&ix)[PT], int k, float* gv, int* gi,
+                                                int idx_none) {
+    __shared__ float l_v[4 * TK_KMAX];
+    __shared__ int l_i[4 * TK_KMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    tk_wave_select<PT>(v, ix, k, l_v + wave * k, l_i + wave * k);
+    __syncthreads();
+    if (wave != 0) return;
+    constexpr int MT = 4 * TK_KMAX / 64;            // merge slots per lane
+    float mv[MT];
+    int mi[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int e = lane + 64 * t;
+        const bool ok = e < 4 * k;
+        mv[t] = ok ? l_v[e] : -INFINITY;
+        mi[t] = ok ? l_i[e] : 0x7fffffff;
+    }
+    // the merged list goes through the (now free) first list's LDS slots, then out with the caller's "none" index
+    tk_wave_select<MT>(mv, mi, k, l_v, l_i, (4 * k + 63) / 64);
+    __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): lane 0's ds_writes before the wave reads them back
+    for (int r = lane; r < k; r += 64) {
+        const int i = l_i[r];
+        gv[r] = l_v[r];
+        gi[r] = i == 0x7fffffff ? idx_none : i;
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ sc, int64_t n, int k,
+                                                         float* __restrict__ cval, int* __restrict__ cidx, int n_chunks) {
+    const int q = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)ch * TK_CH;
+    const int m = (int)min((int64_t)TK_CH, n - base);
+    const float* row = sc + (size_t)q * n + base;
+    float v[TK_PT];
+    int ix[TK_PT];
+#pragma unroll
+    for (int u = 0; u < TK_PT; ++u) {
+        const int j = u * 256 + tid;
+        v[u] = j < m ? row[j] : -INFINITY;
+        ix[u] = j < m ? (int)(base + j) : 0x7fffffff;       // global window index: ascending with j
+    }
+    tk_block_select<TK_PT>(v, ix, k, cval + ((size_t)q * n_chunks + ch) * k, cidx + ((size_t)q * n_chunks + ch) * k, 0x7fffffff);
+}
+
+// level 2: up to 256 * TK_PT candidates per row in registers
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
                                                          int n_cand, int k, int32_t* __restrict__ idx,
                                                          float* __restrict__ val) {
-    __shared__ float s_v[4];
-    __shared__ int s_i[4];
-    __shared__ float best_v;
-    __shared__ int best_i;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float o_v[TK_KMAX];
+    const int q = blockIdx.x, tid = threadIdx.x;
     const float* cv = cval + (size_t)q * n_cand;
     const int* ci = cidx + (size_t)q * n_cand;
-    float last_v = INFINITY;
-    int last_i = -1;
-    for (int p = 0; p < k; ++p) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int j = tid; j < n_cand; j += 256) {
-            const float v = cv[j];
-            const int gi = ci[j];
-            const bool after = (v < last_v) || (v == last_v && gi > last_i);
-            if (gi != 0x7fffffff && after && (v > bv || (v == bv && gi < bi))) { bv = v; bi = gi; }
-        }
+    float v[TK_PT];
+    int ix[TK_PT];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov2 = __shfl_xor(bv, o, 64);
-            const int oi2 = __shfl_xor(bi, o, 64);
-            if (ov2 > bv || (ov2 == bv && oi2 < bi)) { bv = ov2; bi = oi2; }
-        }
-        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float v = s_v[0];
-            int i = s_i[0];
-            for (int w = 1; w < 4; ++w)
-                if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
-            best_v = v; best_i = i;
-            idx[(size_t)q * k + p] = i == 0x7fffffff ? -1 : i;
-            if (val) val[(size_t)q * k + p] = v;
-        }
-        __syncthreads();
-        last_v = best_v;
-        last_i = best_i;
-        __syncthreads();
+    for (int u = 0; u < TK_PT; ++u) {
+        const int j = u * 256 + tid;
+        v[u] = j < n_cand ? cv[j] : -INFINITY;
+        ix[u] = j < n_cand ? ci[j] : 0x7fffffff;
     }
+    float* ov = val ? val + (size_t)q * k : o_v;
+    tk_block_select<TK_PT>(v, ix, k, ov, idx + (size_t)q * k, -1);
 }
 
 // Stable descending top-k: pass p picks the largest (score, then lowest index) strictly after the
@@ -657,16 +671,18 @@ extern "C" int cone_topk_windows_ws(const float* win_scores, int nq, int64_t num
     CONE_REQUIRE(nq > 0 && num_window > 0 && k > 0 && k <= num_window && num_window < 0x7fffffff,
                  "topk: bad sizes nq=%d num_window=%lld k=%d", nq, (long long)num_window, k);
     const size_t need = cone_topk_windows_workspace(nq, num_window, k);
-    if (need == 0 || k > cone::TK_CH / 4) return cone_topk_windows(win_scores, nq, num_window, k, idx, val, stream);
+    const int64_t n_chunks = (num_window + cone::TK_CH - 1) / cone::TK_CH;
+    // two-level selection: lists of <= TK_KMAX per wave, all candidates of a row in the merge workgroup's registers
+    if (need == 0 || k > cone::TK_KMAX || n_chunks * k > 256 * cone::TK_PT)
+        return cone_topk_windows(win_scores, nq, num_window, k, idx, val, stream);
     CONE_REQUIRE(ws && ws_bytes >= need, "topk: workspace too small (%zu < %zu)", ws_bytes, need);
-    const int n_chunks = (int)((num_window + cone::TK_CH - 1) / cone::TK_CH);
     float* cval = (float*)ws;
     int* cidx = (int*)((char*)ws + need / 2);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cone::topk_chunk_kernel, dim3(n_chunks, nq), dim3(256), 0, s, win_scores, num_window, k, cval, cidx,
-                       n_chunks);
+    hipLaunchKernelGGL(cone::topk_chunk_kernel, dim3((unsigned)n_chunks, nq), dim3(256), 0, s, win_scores, num_window, k, cval,
+                       cidx, (int)n_chunks);
     CONE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cone::topk_merge_kernel, dim3(nq), dim3(256), 0, s, cval, cidx, n_chunks * k, k, idx, val);
+    hipLaunchKernelGGL(cone::topk_merge_kernel, dim3(nq), dim3(256), 0, s, cval, cidx, (int)(n_chunks * k), k, idx, val);
     CONE_LAUNCH_CHECK();
     return 0;
 }

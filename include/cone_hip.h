@@ -113,7 +113,7 @@ int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* 
 int cone_topk_windows(const float* win_scores, int nq, int64_t num_window, int k,
                       int32_t* idx, float* val, void* stream);
 /* The same with caller-owned scratch: rows longer than 8 192 windows (MAD scale) run as a two-level selection -- a
- * stable top-k per 4 096-window chunk out of LDS, then a merge of the chunk lists (same order, bit for bit) -- instead
+ * stable top-k per 4 096-window chunk (per-wave selection out of registers, no barrier inside the passes), then a merge of the chunk lists (same order, bit for bit) -- instead
  * of k passes over the whole row.  ws >= cone_topk_windows_workspace(...) bytes (0 for short rows). */
 size_t cone_topk_windows_workspace(int nq, int64_t num_window, int k);
 int cone_topk_windows_ws(const float* win_scores, int nq, int64_t num_window, int k, int32_t* idx, float* val,
