@@ -69,6 +69,9 @@ def _layer_losses(matcher, crit, outputs, targets, neg_outputs, want_saliency):
         sal = _f32(outputs["saliency_scores"])
         pos, neg = _i32(targets["saliency_pos_labels"].to(dev)), _i32(targets["saliency_neg_labels"].to(dev))
         L, P = sal.shape[1], pos.shape[1]
+        lo, hi = int(torch.minimum(pos.min(), neg.min())), int(torch.maximum(pos.max(), neg.max()))
+        if lo < 0 or hi >= L:       # the reference's advanced indexing raises here (cone/model.py:335-338)
+            raise IndexError(f"saliency label index out of range for {L} clips: [{lo}, {hi}]")
         if neg_outputs is not None:
             nsal = _f32(neg_outputs["saliency_scores"])
             L2 = nsal.shape[1]

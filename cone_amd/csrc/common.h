@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/cone_hip.h"
 
 namespace cone {
@@ -31,6 +33,33 @@ void set_error(const char* fmt, ...);
 #define CONE_LAUNCH_CHECK() CONE_CHECK_HIP(hipGetLastError())
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// One-time kernel setup PER DEVICE: the opt-in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute) applies to the
+// current device's copy of the code object, and persistent grids are sized by that device's CU count -- a process that
+// drives several GPUs through this library (the C ABI takes arbitrary streams) must get both for each of them.
+constexpr int CONE_MAX_DEVICES = 64;
+struct DeviceOnce {
+    std::mutex mu;
+    bool done[CONE_MAX_DEVICES] = {};
+    hipError_t rc[CONE_MAX_DEVICES] = {};
+    int n_cu[CONE_MAX_DEVICES] = {};
+};
+template <typename F>
+static inline hipError_t device_once(DeviceOnce& st, F&& setup, int* n_cu = nullptr) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= CONE_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!st.done[dev]) {
+        st.rc[dev] = setup();
+        if (st.rc[dev] == hipSuccess)
+            st.rc[dev] = hipDeviceGetAttribute(&st.n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        st.done[dev] = true;
+    }
+    if (n_cu) *n_cu = st.n_cu[dev];
+    return st.rc[dev];
+}
 
 // ---------------------------------------------------------------- device helpers
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64) void criterion_window_kernel(CritArgs a) {
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);
         const float prob = e0 / (e0 + e1);
+        if (T == 0) continue;                                   // no targets: spans may be NULL (forward(outputs, None))
         const float c = a.spans[2 * i], w = a.spans[2 * i + 1];
         for (int j = 0; j < T; ++j) {
             const float tc = a.tgt[2 * (t0 + j)], tw = a.tgt[2 * (t0 + j) + 1];

@@ -295,13 +295,11 @@ static int launch_one(const float* DQ, const float* XP, const float* X, const fl
                       const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
                       hipStream_t s) {
     using C = DecCrossCfg<NQ, NKL>;
-    static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)dec_cross_kernel<NQ, NKL, POSTAB>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
-    });
-    CONE_CHECK_HIP(attr_rc);
+    static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)dec_cross_kernel<NQ, NKL, POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_FLOATS * 4);
+    }));
     hipLaunchKernelGGL((dec_cross_kernel<NQ, NKL, POSTAB>), dim3(B), dim3(C::NT), C::LDS_FLOATS * 4, s, DQ, XP, X,
                        pos_rows, vlen, off, Wk, WvT, bv, OUT);
     CONE_LAUNCH_CHECK();

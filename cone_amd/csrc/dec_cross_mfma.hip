@@ -306,13 +306,11 @@ static int launch_mfma_one(const float* DQ, const float* XP, const float* X, con
                            const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
                            float* qk_slabs, hipStream_t s) {
     using C = DecCrossMfmaCfg<KTW>;
-    static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)dec_cross_mfma_kernel<KTW, POSTAB>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
-    });
-    CONE_CHECK_HIP(attr_rc);
+    static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)dec_cross_mfma_kernel<KTW, POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_FLOATS * 4);
+    }));
     if (qk_slabs) {     // window-independent queries: the operand slabs once, by one workgroup (window 0's rows)
         hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB>), dim3(1), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
                            pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs);

@@ -49,7 +49,6 @@ typedef float f32x4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int ffn_swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
 
-constexpr int FFN_ROWS = 128;                     // token rows per workgroup of the large-M form (8 waves x 16)
 constexpr int FFN_STAGE = 2 * 16 * 256;           // floats per ring stage: W1 image (16 slabs) + W2 image (16 slabs)
 constexpr int FFN_NST = 4;                        // ring depth: a stage is refilled two barriers after its last read
 // 1-KiB LDS-DMA pieces per wave per chunk: 32 pieces / NW waves (NW = 8: 4, NW = 4: 8)
@@ -516,19 +515,14 @@ template <bool PROJ, bool QKV, int NW>
 static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
     CONE_REQUIRE(lds <= 160 * 1024, "fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff, a.n_qkv);
-    // once per process: the opt-in to > 64 KiB of LDS (a property of the code object) and the CU count that sizes
+    // once per device: the opt-in to > 64 KiB of LDS (a property of the code object) and the CU count that sizes
     // the persistent grid (one workgroup per CU: 132 KiB of LDS, 64 NW threads at <= 256 VGPRs)
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    static int n_cu = 0;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-        int dev = 0;
-        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
-        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    });
-    CONE_CHECK_HIP(attr_rc);
+    static DeviceOnce once;
+    int n_cu = 0;
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
+    }, &n_cu));
     if (n_cu_out) { *n_cu_out = n_cu; return 0; }
     const int tiles = (a.M + 16 * NW - 1) / (16 * NW);
     const int grid = tiles < n_cu ? tiles : n_cu;

@@ -517,17 +517,11 @@ static int launch_ffn_split_t(const FfnSplitArgs& a, hipStream_t s) {
     const size_t lds = (size_t)SP_NSLOT * SP_SLOT + (size_t)(a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
     CONE_REQUIRE(lds <= 160 * 1024, "split-bf16 fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff,
                  a.n_qkv);
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    static int n_cu = 0;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)ffn_split_kernel<PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-        int dev = 0;
-        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
-        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    });
-    CONE_CHECK_HIP(attr_rc);
+    static DeviceOnce once;
+    int n_cu = 0;
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)ffn_split_kernel<PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }, &n_cu));
     const int tiles = (a.M + SP_ROWS - 1) / SP_ROWS;
     const int grid = tiles < n_cu ? tiles : n_cu;
     // FLOPs of a record = 4 M ff 256 (+ 2 M 256 256 with the projection); the fused q | k | v projection adds
@@ -580,17 +574,12 @@ int launch_rows256_split(const float* X, int ldx, const void* Wimg, const float*
     CONE_REQUIRE(rows256_split_supported(N), "split-bf16 row GEMM: N=%d unsupported", N);
     CONE_REQUIRE(X && Wimg && C && ldx % 4 == 0 && ldc % 4 == 0, "split-bf16 row GEMM: bad argument");
     if (M <= 0) return 0;
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    static int n_cu = 0;
-    std::call_once(once, [] {
-        attr_rc = hipFuncSetAttribute((const void*)rows256_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      SP_NSLOT * SP_SLOT + 3072 * (int)sizeof(float));
-        int dev = 0;
-        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
-        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    });
-    CONE_CHECK_HIP(attr_rc);
+    static DeviceOnce once;
+    int n_cu = 0;
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)rows256_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SP_NSLOT * SP_SLOT + 3072 * (int)sizeof(float));
+    }, &n_cu));
     RowsSplitArgs a{X, ldx, Wimg, bias, C, ldc, M, M_dev, N};
     const int tiles = (M + SP_ROWS - 1) / SP_ROWS;
     const int grid = tiles < n_cu ? tiles : n_cu;

@@ -616,16 +616,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const bool need_rows = a.C2 != nullptr;
     CONE_REQUIRE(!need_rows || (rows_ok && a.ADD), "gemm: second output needs the row tile (N %% 256 == 0, no A2)");
     if (use_rows || need_rows) {
-        static std::once_flag once;     // the opt-in to > 64 KiB of LDS is a property of the code object: set it once
-        static hipError_t attr_rc = hipSuccess;
-        std::call_once(once, [] {
-            attr_rc = hipFuncSetAttribute((const void*)gemm_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          RowTile<16>::LDS_BYTES);
-            if (attr_rc == hipSuccess)
-                attr_rc = hipFuncSetAttribute((const void*)gemm_rows_kernel<16>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, RowTile<16>::LDS_BYTES);
-        });
-        CONE_CHECK_HIP(attr_rc);
+        static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
+        CONE_CHECK_HIP(device_once(once, [] {
+            hipError_t rc = hipFuncSetAttribute((const void*)gemm_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                RowTile<16>::LDS_BYTES);
+            if (rc == hipSuccess)
+                rc = hipFuncSetAttribute((const void*)gemm_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         RowTile<16>::LDS_BYTES);
+            return rc;
+        }));
         const bool waves8 = a.variant != GEMM_ROWS4;
         const int row_tiles = (a.M + RT_BM - 1) / RT_BM;
         dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (a.N / RT_BN)));      // 1-D, see the tile order in the kernel

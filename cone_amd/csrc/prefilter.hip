@@ -398,20 +398,16 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* _
 }
 
 static int prefilter_grid_setup(int* n_cu_out) {
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    static int n_cu = 0;
-    std::call_once(once, [] {
+    static DeviceOnce once;     // the many-query kernel's 128 KiB of LDS: opt-in once per device; its grid = one workgroup per CU
+    const hipError_t rc = device_once(once, [] {
         const void* fns[4] = {(const void*)frame_score_mq_kernel<4, false>, (const void*)frame_score_mq_kernel<4, true>,
                               (const void*)frame_score_mq_kernel<2, false>, (const void*)frame_score_mq_kernel<2, true>};
-        for (int i = 0; i < 4 && attr_rc == hipSuccess; ++i)
-            attr_rc = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        int dev = 0;
-        if (attr_rc == hipSuccess) attr_rc = hipGetDevice(&dev);
-        if (attr_rc == hipSuccess) attr_rc = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    });
-    *n_cu_out = n_cu;
-    return attr_rc == hipSuccess ? 0 : -1;
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        return e;
+    }, n_cu_out);
+    return rc == hipSuccess ? 0 : -1;
 }
 
 static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, int S, int64_t nh, const float* txt, int nq,
