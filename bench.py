@@ -50,8 +50,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Peak F
 HBM_PEAK_GBS = 8000.0           # same guide: HBM3E peak BW (spec); 6.29 TB/s measured float4 copy
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn16_kernel", 4: "frame_score_kernel",
-                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_mfma_kernel", 8: "ffn_fused_kernel<false, false>",
-                9: "ffn_fused_kernel<true, false>"}
+                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_mfma_kernel", 8: "ffn_fused_kernel<false, false, 8>",
+                9: "ffn_fused_kernel<true, false, 8>"}
 GEMM_KINDS = (0, 1, 2, 5, 6, 8, 9)   # records (kind, M, N, K, ms): 2*M*N*K FLOPs; kinds 8 / 9 (N = ff, K = 256): the
 #                                      feed-forward block = two such GEMMs, kind 9 + the 256 x 256 output projection
 

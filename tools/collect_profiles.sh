@@ -46,3 +46,8 @@ tail -8 $out/${tag}_pmc_prefilter.log
 cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv $out/${tag}_pmc_prefilter.json $out/${tag}_pmc_prefilter_counters.csv profiles/
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 cat $out/${tag}_bench_line.json
+# gpurun copies back at most 64 MiB: the rocpd databases and raw counter tables stay on the box, their summaries travel
+mkdir -p $out/${tag}_profiles
+cp $out/${tag}_*.csv $out/${tag}_*.json $out/${tag}_step_gaps.txt $out/${tag}_profiles/ 2>/dev/null
+rm -rf $out/prof_$tag $out/prof_${tag}_step $out/prof_${tag}_split $out/pmc_fetch $out/pmc_write $out/pmc_mfma \
+       $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf
