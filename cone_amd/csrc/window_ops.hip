@@ -389,22 +389,37 @@ __global__ __launch_bounds__(256) void window_table_kernel(const int* __restrict
                                                            int* __restrict__ video_start, int* __restrict__ txt_row0,
                                                            int* __restrict__ txt_len, int* __restrict__ cls_row) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int q = b / K;
-    const int wi = win_idx[b];
-    int start = (wi - 1) * S;                       // window 0 is the half window ahead of the video (:229-234)
-    int end = start + W;
-    start = start < 0 ? 0 : start;
-    const int cl = q_ctx_l[q];
-    end = end < cl ? end : cl;
-    const int vlen = end - start;
-    vid_row0[b] = q_vid_off[q] + start;
-    vid_len[b] = vlen;
-    video_start[b] = start;
-    txt_row0[b] = tok_off[q];
-    txt_len[b] = tok_len[q];
-    cls_row[b] = q;
-    if (batch_max) atomicMax(batch_max + (q + q_base) / eval_bsz, vlen);
+    int vlen = 0, bid = -1;
+    if (b < B) {
+        const int q = b / K;
+        const int wi = win_idx[b];
+        int start = (wi - 1) * S;                   // window 0 is the half window ahead of the video (:229-234)
+        int end = start + W;
+        start = start < 0 ? 0 : start;
+        const int cl = q_ctx_l[q];
+        end = end < cl ? end : cl;
+        vlen = end - start;
+        vid_row0[b] = q_vid_off[q] + start;
+        vid_len[b] = vlen;
+        video_start[b] = start;
+        txt_row0[b] = tok_off[q];
+        txt_len[b] = tok_len[q];
+        cls_row[b] = q;
+        bid = (q + q_base) / eval_bsz;
+    }
+    if (!batch_max) return;
+    // longest window of every reference batch: rows of a batch are consecutive, so a wave holds one or two batches -- one
+    // wave maximum and ONE atomic per (wave, batch) instead of eval_bsz * K contended atomics per batch slot
+    unsigned long long todo = __ballot(bid >= 0);
+    while (todo) {
+        const int leader = __builtin_amdgcn_readlane(bid, __builtin_ctzll(todo));
+        const bool mine = bid == leader;
+        int m = mine ? vlen : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == __builtin_ctzll(todo)) atomicMax(batch_max + leader, m);
+        todo &= ~__ballot(mine);
+    }
 }
 
 __global__ __launch_bounds__(256) void window_pad_kernel(int B, int K, int q_base, int eval_bsz,

@@ -125,18 +125,22 @@ class FeatureStore:
 
     def prefilter_plan(self):
         """Static index metadata of the pre-filter (depends on the annotation file only): groups of one
-        video x up to 4 of its queries, and per-query offsets into the flat score buffers."""
+        video x up to 4 of its queries, and per-query offsets into the flat score buffers.  ``band`` = the arena rows
+        [r0, r1) of the videos this store's queries refer to (a view of a few queries of a big split -- a rank's share
+        -- adapts and scores only those); group row offsets are relative to r0."""
         if self._plan is not None:
             return self._plan
         S = int(self.opt.max_v_l / 2)
         by_vid = OrderedDict()
         for qi, v in enumerate(self.q_vid.tolist()):
             by_vid.setdefault(v, []).append(qi)
+        r0 = int(min(self.vid_off[v] for v in by_vid)) if by_vid else 0
+        r1 = int(max(self.vid_off[v + 1] for v in by_vid)) if by_vid else 0
         g_row0, g_ctx_l, g_q = [], [], []
         for v, qis in by_vid.items():
             for c0 in range(0, len(qis), 4):
                 grp = qis[c0:c0 + 4]
-                g_row0.append(int(self.vid_off[v])); g_ctx_l.append(self.ctx_l[v])
+                g_row0.append(int(self.vid_off[v]) - r0); g_ctx_l.append(self.ctx_l[v])
                 g_q.append(grp + [-1] * (4 - len(grp)))
         q_ctx = np.array([self.ctx_l[v] for v in self.q_vid.tolist()], dtype=np.int64)
         q_nw = (q_ctx + S - 1) // S + 1
@@ -144,7 +148,7 @@ class FeatureStore:
         t = lambda a, dt: torch.tensor(np.asarray(a), dtype=dt, device=dev)
         self._plan = dict(
             g_row0=t(g_row0, torch.int64), g_ctx_l=t(g_ctx_l, torch.int32), g_q=t(g_q, torch.int32).contiguous(),
-            ng=len(g_row0), max_ctx_l=int(max(self.ctx_l)),
+            ng=len(g_row0), max_ctx_l=int(max(self.ctx_l[v] for v in by_vid)) if by_vid else 0, band=(r0, r1),
             q_fs_off=t(np.concatenate([[0], np.cumsum(q_ctx)[:-1]]), torch.int64),
             q_win_off=t(np.concatenate([[0], np.cumsum(q_nw)[:-1]]), torch.int64),
             q_ctx_l=t(q_ctx, torch.int32), fs_total=int(q_ctx.sum()), win_total=int(q_nw.sum()))
@@ -287,11 +291,14 @@ class FeatureStore:
 @torch.no_grad()
 def prefilter(model, store: FeatureStore, opt, k=None):
     """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window);
-    ``k`` overrides opt.topk_window (the window-recall table ranks deeper than the model consumes)."""
-    vid_norm = ops.l2_normalize(store.vid_raw, 1e-5)          # PreFilteringDataset :459
+    ``k`` overrides opt.topk_window (the window-recall table ranks deeper than the model consumes).  Only the clip rows of
+    the videos ``store``'s queries refer to are normalised, adapted and scored (the whole arena for a whole split)."""
+    plan = store.prefilter_plan()
+    r0, r1 = plan["band"]
+    vid_norm = ops.l2_normalize(store.vid_raw[r0:r1], 1e-5)   # PreFilteringDataset :459
     ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
     cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :473
-    win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, store.prefilter_plan(), opt.max_v_l, k or opt.topk_window)
+    win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, plan, opt.max_v_l, k or opt.topk_window)
     return win_idx
 
 
@@ -325,10 +332,23 @@ def reference_batch_pad(store: FeatureStore, opt, win_idx):
     longest window of that batch (cone/inference.py:306-313, utils/tensor_utils.py:36-39), and the proposal
     mean of forward_clip_matching divides by a length clipped to that padding (cone/model.py:186-199, hazard
     H3).  Returns (ceil(nq_split / eval_bsz),) int64; entries of batches this store holds no query of are 0."""
-    q_of, _, _, vlen = _window_geometry(store, opt, win_idx)
     nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
+    nq, K = win_idx.shape
+    if nq and win_idx.is_cuda and min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2) and not getattr(opt, "window_table_torch", False):
+        return _dense_table(store, opt, win_idx, None, nb)["batch_pad"].to(torch.int64)     # one launch (cone_window_table)
+    q_of, _, _, vlen = _window_geometry(store, opt, win_idx)
     bid = (q_of + store.q_base) // opt.eval_bsz
     return torch.zeros(nb, dtype=torch.int64, device=win_idx.device).scatter_reduce_(0, bid, vlen, reduce="amax")
+
+
+def _dense_table(store: FeatureStore, opt, win_idx, batch_pad, nb):
+    """cone_window_table on a dense selection (every query owns exactly K windows): the table columns + ``batch_pad``."""
+    st = store.index_tensors()
+    i32 = st.get("i32")
+    if i32 is None:
+        i32 = st["i32"] = tuple(st[k].to(torch.int32).contiguous() for k in ("q_ctx_l", "q_vid_off", "tok_off", "tok_len"))
+    bp = None if batch_pad is None else batch_pad.to(torch.int32).contiguous()
+    return ops.window_table_dense(win_idx.contiguous(), *i32, store.q_base, opt.eval_bsz, opt.max_v_l, bp, nb)
 
 
 def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
@@ -347,16 +367,12 @@ def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
                              f"batch (eval_bsz {opt.eval_bsz}): pass batch_pad=reference_batch_pad(split, ...)")
     if nq and win_idx.is_cuda and min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2) and not getattr(opt, "window_table_torch", False):
         # dense selection (every video has at least K windows): the whole table is one launch (cone_window_table)
-        i32 = st.get("i32")
-        if i32 is None:
-            i32 = st["i32"] = tuple(st[k].to(torch.int32).contiguous() for k in ("q_ctx_l", "q_vid_off", "tok_off", "tok_len"))
         dense = st.get(("dense", K))
         if dense is None:
             ar = torch.arange(nq * K, device=win_idx.device)
             dense = st[("dense", K)] = (ar // K, ar % K)
         nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
-        bp = None if batch_pad is None else batch_pad.to(torch.int32).contiguous()
-        wt = ops.window_table_dense(win_idx.contiguous(), *i32, store.q_base, opt.eval_bsz, opt.max_v_l, bp, nb)
+        wt = _dense_table(store, opt, win_idx, batch_pad, nb)
         wt.pop("batch_pad")
         wt["q_of"], wt["slot"] = dense
         return wt

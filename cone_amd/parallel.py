@@ -312,6 +312,61 @@ def prefilter_one_video_ctx_sharded(store, opt, hooks, group=None):
     return idx.contiguous()
 
 
+def _dense_host(store, opt):
+    """Every video holds at least topk_window windows (host metadata only): the window list is (query, rank slot)
+    row-major whatever the pre-filter selects, so shard cuts and candidate layout are known before stage A runs."""
+    return min(store.ctx_l) > (opt.topk_window - 2) * int(opt.max_v_l / 2)
+
+
+@torch.no_grad()
+def _window_sharded_dense(store, opt, hooks, group, virtual, format_shard):
+    """Window-sharded stages A->C for a dense selection (the Ego4D / MAD splits: every video longer than top-k half
+    windows).  NOTHING of stage A or of the window table is replicated: row r of the window list belongs to query r // K, so
+    a rank knows its queries [a, b] from the cut alone and runs the pre-filter, the window table and the reference-batch
+    padding (hazard H3) only for the eval_bsz-ALIGNED hull of that range -- whole reference batches, hence the split's
+    own padding -- then the window model on its slice.  ONE fixed-size all_gather of the proposal rows; the gathered
+    (n_win, Nq, 4) buffer IS the (nq, K Nq, 4) candidate layout (no scatter); fusion + NMS of all queries on every rank."""
+    from . import inference as inf
+    rank, world = _rank_world(group, virtual)
+    nq, K, Nq, bsz = len(store.ann), opt.topk_window, hooks.num_queries, opt.eval_bsz
+    n_win = nq * K
+    lo, hi = shard_range(n_win, rank, world)
+    dev = store.vid_raw.device
+    win_hull, hull = None, (0, 0)
+
+    def rows_of(lo, hi):
+        nonlocal win_hull, hull
+        if hi == lo:
+            return torch.zeros(0, Nq, 4, device=dev)
+        a, b = lo // K, (hi - 1) // K
+        ha, hb = (a // bsz) * bsz, min(nq, -(-(b + 1) // bsz) * bsz)
+        # the two views (and the static index tables they cache on the device) depend on the annotations and the cut
+        # only: built once per (store, cut), not once per step
+        views = store.__dict__.setdefault("_shard_views", {})
+        key = (a, b, ha, hb)
+        if key not in views:
+            if len(views) > 16:
+                views.clear()
+            views[key] = (inf.FeatureStore.subset(store, ha, hb), inf.FeatureStore.subset(store, a, b + 1))
+        hull_store, sub = views[key]
+        win_hull, hull = hooks.prefilter(hull_store, opt), (ha, hb)
+        wt = inf.window_table(hull_store, opt, win_hull)            # whole reference batches: the split's padding
+        video = hooks.project_video(store, _video_row_range(store, a, b + 1))
+        table = _slice_table(wt, lo - ha * K, hi - ha * K, a - ha, int(store.tok_off[a]) - int(store.tok_off[ha]))
+        return hooks.window_rows(sub, opt, table, video)
+    rows_all = run_window_sharded(n_win, rows_of, group, virtual)
+    cand = rows_all.reshape(nq, K * Nq, 4)
+    n_valid = torch.full((nq,), K * Nq, dtype=torch.int32, device=cand.device)
+    rows, n = hooks.fuse_nms(cand, n_valid, opt)        # every rank, all queries: cheaper than a second collective
+    q_lo, q_hi = shard_range(nq, rank, world)
+    info = dict(rows=rows, n=n, win_idx=win_hull, win_idx_range=hull, n_windows=n_win, shard=(q_lo, q_hi), world=world)
+    if format_shard:
+        return inf.format_results(store.ann[q_lo:q_hi], opt, rows[:, q_lo:q_hi], n[:, q_lo:q_hi]), info
+    if rank != 0:
+        return None, info
+    return inf.format_results(store.ann, opt, rows, n), info
+
+
 @torch.no_grad()
 def predict_split_distributed(model, store, opt, mode: str = "window", group=None, hooks=None,
                               format_shard: bool = False, prefilter: str = "replicated", virtual=None):
@@ -326,6 +381,10 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     ``virtual=(rank, world)``: replay what that rank of a `world`-rank run computes, on one GPU and without a process
     group -- the gathers are filled with copies of the local shard (bench.py's ``shard_proxy_8``; replicated stage A only).
 
+    Window mode on a dense selection with the replicated pre-filter takes ``_window_sharded_dense``: stage A and the
+    window table run only for the rank's own (batch-aligned) query range -- ``info['win_idx']`` then holds the window table
+    of queries ``info['win_idx_range']`` instead of the whole split's.
+
     Returns ``(lists, info)``: ``info['rows'] / info['n']`` = the kept rows of ALL queries, on every rank (tensors);
     ``lists`` = the three submission lists -- of all queries on rank 0 and ``None`` elsewhere, or, with
     ``format_shard=True``, of the rank's own query shard ``info['shard']`` on every rank (the host formatting
@@ -335,6 +394,8 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     rank, world = _rank_world(group, virtual)
     nq = len(store.ann)
     Nq = hooks.num_queries
+    if mode == "window" and prefilter == "replicated" and _dense_host(store, opt):
+        return _window_sharded_dense(store, opt, hooks, group, virtual, format_shard)
     if prefilter == "ctx":
         if virtual is not None:
             raise ValueError("virtual ranks replay the replicated pre-filter only")
