@@ -43,6 +43,10 @@ struct cone_model {
     cone::Linear dec_k, dec_v;
     // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
     const float* dec_vT[CONE_MAX_LAYERS] = {};
+    // derived: the first decoder layer's window-independent rows (tgt = 0, cone/transformer.py:66: its self-attention block
+    // and its cross-attention queries depend on the checkpoint only): norm1 output (nq, 256) and the cross-attention query
+    // projection (nq, 256), computed once at creation by the same kernels a step would run on ONE window's rows
+    float* dec0_tgt1 = nullptr; float* dec0_dq = nullptr; float* dec0_scratch = nullptr;
     // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
     int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 = on the matrix
                               // cores (dec_cross_mfma.hip), 1 = on the VALU (dec_cross.hip), 0 = K/V GEMMs + small_attn
@@ -76,6 +80,8 @@ struct ArenaBuilder {
         total += align_up(n, 64);
     }
 };
+
+static int dec0_constants(cone_model* m, hipStream_t s);
 
 static int build_model(const cone_weights* w, cone_model** out) {
     CONE_REQUIRE(w && out, "model_create: null argument");
@@ -147,7 +153,8 @@ static int build_model(const cone_weights* w, cone_model** out) {
             set_error("model_create: a required weight pointer is null");
             return CONE_E_INVALID;
         }
-    const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64 + (size_t)m->n_dec * d * d;
+    const size_t dec0_floats = (size_t)m->nq * (256 * 2 + 256 + 512 + 256 + 256) + 6 * 64;
+    const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64 + (size_t)m->n_dec * d * d + dec0_floats;
     hipError_t e = hipMalloc((void**)&m->arena, (ab.total + stacked) * sizeof(float));
     if (e != hipSuccess) {
         delete m;
@@ -205,6 +212,9 @@ static int build_model(const cone_weights* w, cone_model** out) {
             m->dec_vT[i] = dst;
         }
     }
+    m->dec0_tgt1 = m->arena + cur; cur += align_up((size_t)m->nq * 256, 64);
+    m->dec0_dq = m->arena + cur; cur += align_up((size_t)m->nq * 256, 64);
+    m->dec0_scratch = m->arena + cur; cur += align_up((size_t)m->nq * (256 + 512 + 256 + 256), 64);
     if (d == 256 && ffn_split_supported(m->ff)) {   // split-bf16 images of every layer tail (13 MB at ff = 1024; opt-in path)
         const size_t per = ffn_split_proj_image_bytes() + ffn_split_image_bytes(m->ff);
         const size_t qkv = rows256_split_image_bytes(768);
@@ -236,6 +246,12 @@ static int build_model(const cone_weights* w, cone_model** out) {
             return CONE_E_HIP;
         }
     }
+    if (dec0_constants(m, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
+        if (m->split_img) (void)hipFree(m->split_img);
+        (void)hipFree(m->arena);
+        delete m;
+        return CONE_E_HIP;
+    }
     *out = m;
     return 0;
 }
@@ -263,6 +279,31 @@ static GemmArgs G(const cone_model* m, const float* A, int lda, const float* W, 
 }
 
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// First decoder layer on tgt = 0 (cone/transformer.py:66, 296-311): self-attention over the nq slots (q = k = query_embed
+// W^T, v = bias rows), out_proj + norm1, and the cross-attention query projection -- no window enters, so the nq rows
+// are per-checkpoint constants.  Computed with the kernels and the row count (nq) a step used for them, hence the same bits.
+static int dec0_constants(cone_model* m, hipStream_t s) {
+    const DecLayer& dl = m->dec[0];
+    const int nq = m->nq;
+    float* TGT = m->dec0_scratch;                       // (nq, 256) zeros
+    float* DQK = TGT + (size_t)nq * 256;                // (nq, 512)
+    float* DV = DQK + (size_t)nq * 512;                 // (nq, 256)
+    float* DATT = DV + (size_t)nq * 256;                // (nq, 256)
+    CONE_CHECK_HIP(hipMemsetAsync(TGT, 0, (size_t)nq * 256 * sizeof(float), s));
+    GemmArgs g = G(m, TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, DQK, 512, nq, nullptr, 512, 256);
+    g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = nq;
+    RUN(launch_gemm(g, s));
+    RUN(launch_gemm(G(m, TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, DV, 256, nq, nullptr, 256, 256), s));
+    RUN(launch_small_attn(DQK, 512, DQK + 256, 512, DV, 256, DATT, 256, nullptr, 1, nq, nq, s));
+    g = G(m, DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, m->dec0_tgt1, 256, nq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+    g.R = TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
+    RUN(launch_gemm(g, s));
+    g = G(m, m->dec0_tgt1, 256, dl.ca.in_w, 256, dl.ca.in_b, m->dec0_dq, 256, nq, nullptr, 256, 256);
+    g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = nq;
+    RUN(launch_gemm(g, s));
+    return 0;
+}
 
 // input_{vid,txt}_proj: LN -> Linear -> ReLU (all but last) with the next LN fused into the GEMM epilogue.
 static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
@@ -466,28 +507,32 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
         RUN(launch_gemm(G(m, MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
     }
-    CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
+    if (!m->opt_dec0_const)          // tgt = 0 is only read by the first layer's own projections (constants otherwise)
+        CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));
     for (int l = 0; l < nd; ++l) {
         const DecLayer& dl = m->dec[l];
         // Layer 0 starts from tgt = 0 (cone/transformer.py:66): its self-attention block and its cross-attention
         // queries do not depend on the window.  They are computed for ONE window's nq rows by the same kernels
         // (rows of a GEMM are independent: identical bits) and replicated, instead of T = B*nq identical rows.
-        const int Tq = (l == 0 && m->opt_dec0_const) ? m->nq : T;
-        const int Bq = (l == 0 && m->opt_dec0_const) ? 1 : B;
-        GemmArgs g = G(m, f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, Tq, nullptr, 512, 256);
-        g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
-        RUN(launch_gemm(g, s));
-        RUN(launch_gemm(G(m, f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, Tq, nullptr, 256, 256), s));
-        RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, Bq, m->nq, m->nq, s));
-        g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, Tq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
-        g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
-        RUN(launch_gemm(g, s));
-        g = G(m, f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, Tq, nullptr, 256, 256);
-        g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
-        RUN(launch_gemm(g, s));
-        if (Tq != T) {
-            RUN(launch_tile_rows(f.TGT1, m->nq, T, s));
-            RUN(launch_tile_rows(f.DQ, m->nq, T, s));
+        const bool dec0 = l == 0 && m->opt_dec0_const;
+        const int Tq = dec0 ? m->nq : T;
+        GemmArgs g;
+        if (dec0) {
+            // the layer's self-attention block and cross-attention queries: per-checkpoint constants (dec0_constants, at
+            // cone_model_create), replicated to the T rows of the batch in one launch
+            RUN(launch_tile_rows2(f.TGT1, m->dec0_tgt1, f.DQ, m->dec0_dq, m->nq, T, s));
+        } else {
+            g = G(m, f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, T, nullptr, 512, 256);
+            g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+            RUN(launch_gemm(g, s));
+            RUN(launch_gemm(G(m, f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, T, nullptr, 256, 256), s));
+            RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
+            g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+            g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
+            RUN(launch_gemm(g, s));
+            g = G(m, f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, T, nullptr, 256, 256);
+            g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+            RUN(launch_gemm(g, s));
         }
         if (fold && m->opt_dec_fold >= 2)
             RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
@@ -761,6 +806,8 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
     if (!strcmp(name, "gemm")) {
         CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
         m->opt_gemm = value;
+        // the first decoder layer's constants come from these GEMMs: keep them what a step would compute
+        if (dec0_constants(m, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) return CONE_E_HIP;
         return 0;
     }
     cone::set_error("set_option: unknown option '%s'", name);

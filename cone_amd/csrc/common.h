@@ -192,6 +192,7 @@ struct AttnSrc {
 };
 int launch_enc_attn(int mode, const AttnSrc& src, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
 int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s);
+int launch_tile_rows2(float* d0, const float* s0, float* d1, const float* s1, int period, int64_t n_rows, hipStream_t s);
 // fused decoder cross-attention with the memory K/V projections folded in (dec_cross.hip).  Keys = memory + pos:
 // either XP (M, 256) = memory + pos precomputed, or (XP == nullptr) memory rows X plus the static sine rows
 // pos_rows[(vlen[b], p)] of clip tokens added in the staging loads.

@@ -121,6 +121,26 @@ int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s) {
     return 0;
 }
 
+// Two matrices in one launch, from separate `period`-row sources: dst{0,1} rows [0, n_rows) <- src{0,1}[r % period]
+// (the first decoder layer's per-checkpoint constants, replicated to every window of a batch).
+__global__ __launch_bounds__(256) void tile_rows2_kernel(float* __restrict__ d0, const float* __restrict__ s0,
+                                                         float* __restrict__ d1, const float* __restrict__ s1, int period,
+                                                         int64_t n_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t sr = row % period;
+    reinterpret_cast<float4*>(d0 + row * 256)[lane] = reinterpret_cast<const float4*>(s0 + sr * 256)[lane];
+    reinterpret_cast<float4*>(d1 + row * 256)[lane] = reinterpret_cast<const float4*>(s1 + sr * 256)[lane];
+}
+
+int launch_tile_rows2(float* d0, const float* s0, float* d1, const float* s1, int period, int64_t n_rows, hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(tile_rows2_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, d0, s0, d1, s1, period, n_rows);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 // Heads with 1-2 outputs over d=256 inputs: class_embed, last span_embed layer (+sigmoid)
 // (cone/model.py:112-115).
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int ldx,
