@@ -451,7 +451,7 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
         if "aux_outputs" in out:        # (n_dec - 1, B, Nq, 2) each, stacked over the intermediate decoder layers
             outs.setdefault("aux_logits", []).append(torch.stack([a["pred_logits"] for a in out["aux_outputs"]], 1))
             outs.setdefault("aux_spans", []).append(torch.stack([a["pred_spans"] for a in out["aux_outputs"]], 1))
-    return {k: torch.cat(v, 0) for k, v in outs.items()}
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}      # one chunk: no copy
 
 
 def compute_mr_results(model, store: FeatureStore, opt, win_idx=None):
@@ -569,14 +569,26 @@ def write_submissions(opt, fusion, proposal, matching, save_submission_filename)
     return paths
 
 
-def candidate_lists(rows, wt, win_idx, Nq):
+def candidate_lists(rows, wt, win_idx, Nq, dense=False):
     """Per-window rows (Nw, Nq, 4) -> per-query candidate lists (nq, K*Nq, 4) in (window rank, slot) order --
-    the order cone/inference.py:141-149 extends ``predicted_times`` in -- and their valid counts."""
+    the order cone/inference.py:141-149 extends ``predicted_times`` in -- and their valid counts.  ``dense`` (every
+    query owns exactly K windows, host-known): the rows already ARE that layout -- a view, no scatter."""
     nq, K = win_idx.shape
+    if dense and rows.shape[0] == nq * K:
+        key = ("n_valid", nq, K * Nq, str(rows.device))
+        n_valid = _CONST.get(key)
+        if n_valid is None:
+            if len(_CONST) > 64:
+                _CONST.clear()
+            n_valid = _CONST[key] = torch.full((nq,), K * Nq, dtype=torch.int32, device=rows.device)
+        return rows.reshape(nq, K * Nq, 4), n_valid
     cand = torch.zeros(nq, K * Nq, 4, dtype=rows.dtype, device=rows.device)
     cand.view(nq, K, Nq, 4)[wt["q_of"], wt["slot"]] = rows
     n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
     return cand, n_valid
+
+
+_CONST = {}     # small constant device tensors keyed by shape (valid counts of dense selections)
 
 
 @torch.no_grad()
@@ -590,7 +602,9 @@ def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=Non
     wt = window_table(store, opt, win_idx, batch_pad)
     res = run_windows(model, store, opt, wt, project_features(model, store, video))
     rows = res["rows"]
-    cand, n_valid = candidate_lists(rows, wt, win_idx, model.num_queries)
+    K = win_idx.shape[1]
+    dense = min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2)            # host metadata: every video holds K windows
+    cand, n_valid = candidate_lists(rows, wt, win_idx, model.num_queries, dense)
     out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
     return dict(rows=out_rows, n=out_n, idx=out_idx, win_idx=win_idx, windows=wt, cand=cand,
                 n_windows=int(rows.shape[0]), outputs=res)
