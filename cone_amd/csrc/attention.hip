@@ -8,7 +8,14 @@
 //                       (cone/transformer.py:296-311): self-attention over the slots and
 //                       cross-attention to the window's memory tokens.
 //
-// enc_attn16_kernel layout (exact-fp32 MFMA 16x16x4), one wave per 16-query tile, workgroup = ceil(Lmax/16) waves:
+// enc_attn16_kernel layout (exact-fp32 MFMA 16x16x4), one wave per 16-query tile, workgroup = ceil(Lmax/16) waves.
+// What bounds it (round 3, tools/attn_bench.py, one box): the time is invariant to the instruction count (a form without
+// the per-key-tile branches: 1 164 -> 723 instructions, 201 -> 14 branches: 2.74 vs 2.74 ms), to the LDS instruction count
+// (round 2) and to the HBM traffic (gather mode reads a quarter of the bytes of the packed mode: same time) -- a
+// workgroup's LIFETIME (load round trips -> stage -> barrier -> S^T -> softmax -> P.V -> store) times the four workgroups
+// a CU holds (7 waves each, 32 wave slots) is what counts.  Hence: all loads of a workgroup in ONE round trip (was four
+// serial ones: 2.79 -> 2.66 ms), every key tile always walked (no branches, zero rows + masked scores).
+//
 //   a window of 101 tokens pads to 112 x 112 scores, a wave keeps 4 registers per key tile.
 //   S^T tile: A = K (keys on accumulator rows 4g + r, g = lane / 16), B = Q^T (query = lane % 16): a lane owns one
 //             query column, so the row softmax is an in-register reduction plus two cross-group shuffles, and the
@@ -22,6 +29,7 @@
 namespace cone {
 
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
+
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
@@ -37,7 +45,6 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
     const int b = blockIdx.y, head = blockIdx.x;        // the 8 heads of a window are dispatched together
     const int t0 = off[b];
     const int L = off[b + 1] - t0;
-    const int nkt = (L + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -55,48 +62,67 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
         }
     };
 
-    // this lane's query values d = 8 lg .. 8 lg + 7 (fetched before the K/V staging: independent round trips)
+    // ONE memory round trip per workgroup: the query values, both staging passes (key rows kr and kr + NT/8: KP = 2 NT/8
+    // exactly) and their position rows are all requested before anything is waited for.  Rows past the window re-read its
+    // last row and are zeroed by a mask, the position row of a text token re-reads the token's own row and is masked, so no
+    // load sits behind a branch (the compiler otherwise waits out every conditional load where it stands: four serial
+    // round trips -- q, q's position row, and the two staging passes -- in front of the first MFMA).
     const int q0 = wave * 16;
-    float qv[8];
-    if (q0 < L) {
+    const int kr = tid >> 3, c = tid & 7;
+    float4 qx[2], qt[2], kv[2], vv[2], kt_[2];
+    bool q_add = false, k_ok[2], k_add[2];
+    {
         int qrow = q0 + li;
         qrow = qrow < L ? qrow : L - 1;
         const float *qp, *kp_, *vp_, *qadd;
         rows_of(qrow, qp, kp_, vp_, qadd);
         qp += head * 32 + 8 * lg;
+        q_add = MODE != ATTN_PACKED && qadd != nullptr;
+        const float* ap = q_add ? qadd + head * 32 + 8 * lg : qp;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float4 x = reinterpret_cast<const float4*>(qp)[u];
-            if (MODE != ATTN_PACKED && qadd) {
-                const float4 t = reinterpret_cast<const float4*>(qadd + head * 32 + 8 * lg)[u];
-                x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
-            }
-            qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
-            qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+            qx[u] = reinterpret_cast<const float4*>(qp)[u];
+            if (MODE != ATTN_PACKED) qt[u] = reinterpret_cast<const float4*>(ap)[u];
         }
     }
-    {   // stage K (d-major) and V for all keys of the window; zero rows past L
-        const int kr = tid >> 3, c = tid & 7;
-        for (int key = kr; key < nkt * 16; key += NT / 8) {
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < L) {
-                const float *qp, *kp_, *vp_, *add;
-                rows_of(key, qp, kp_, vp_, add);
-                kv = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
-                vv = *reinterpret_cast<const float4*>(vp_ + head * 32 + c * 4);
-                if (MODE != ATTN_PACKED && add) {
-                    const float4 t = *reinterpret_cast<const float4*>(add + 256 + head * 32 + c * 4);
-                    kv.x += t.x; kv.y += t.y; kv.z += t.z; kv.w += t.w;
-                }
-            }
-            KsT[(4 * c + 0) * LDK + key] = kv.x; KsT[(4 * c + 1) * LDK + key] = kv.y;
-            KsT[(4 * c + 2) * LDK + key] = kv.z; KsT[(4 * c + 3) * LDK + key] = kv.w;
-            *reinterpret_cast<float4*>(Vs + key * LDV + c * 4) = vv;
-        }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int key = kr + it * (NT / 8);
+        k_ok[it] = key < L;
+        const int row = k_ok[it] ? key : L - 1;
+        const float *qp, *kp_, *vp_, *add;
+        rows_of(row, qp, kp_, vp_, add);
+        k_add[it] = MODE != ATTN_PACKED && add != nullptr;
+        kv[it] = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
+        vv[it] = *reinterpret_cast<const float4*>(vp_ + head * 32 + c * 4);
+        if (MODE != ATTN_PACKED)
+            kt_[it] = *reinterpret_cast<const float4*>((k_add[it] ? add + 256 : kp_) + head * 32 + c * 4);
+    }
+    float qv[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float4 x = qx[u];
+        if (MODE != ATTN_PACKED && q_add) { x.x += qt[u].x; x.y += qt[u].y; x.z += qt[u].z; x.w += qt[u].w; }
+        qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
+        qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int key = kr + it * (NT / 8);
+        float4 k4 = kv[it], v4 = vv[it];
+        if (MODE != ATTN_PACKED && k_add[it]) { k4.x += kt_[it].x; k4.y += kt_[it].y; k4.z += kt_[it].z; k4.w += kt_[it].w; }
+        if (!k_ok[it]) { k4 = make_float4(0.f, 0.f, 0.f, 0.f); v4 = k4; }
+        KsT[(4 * c + 0) * LDK + key] = k4.x; KsT[(4 * c + 1) * LDK + key] = k4.y;
+        KsT[(4 * c + 2) * LDK + key] = k4.z; KsT[(4 * c + 3) * LDK + key] = k4.w;
+        *reinterpret_cast<float4*>(Vs + key * LDV + c * 4) = v4;
     }
     __syncthreads();
     if (q0 >= L) return;
 
+    // All NKT key tiles are always walked: the rows past the window's last key are staged as zeros, their scores masked
+    // to -inf (probability exactly 0), so the extra MFMAs add exact zeros -- and the per-tile "does this tile exist"
+    // branches (7 x 4 loops of scalar compare + branch around every MFMA group: 200 branches per wave, the SALU port the
+    // most loaded issue port of the SIMD) are gone.  A batch pads to its own longest window (the launcher picks NKT).
     f32x4m sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) sc[kt] = f32x4m{0.f, 0.f, 0.f, 0.f};
@@ -105,21 +131,16 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
         const float* kp = KsT + (8 * lg + st) * LDK + li;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
-            if (kt < nkt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
     }
-    // softmax over the keys of this lane's query: registers, then the four lane groups.  Only the last key tile can
-    // hold padding; exp(s - m) is one fma + one v_exp_f32 (exp2((s - m) * log2 e)).
+    const int lim = L - 4 * lg;                     // key 16 kt + 4 lg + r is real iff 16 kt + r < lim
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
-            if (kt == nkt - 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + 4 * lg + r >= L) sc[kt][r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+        for (int r = 0; r < 4; ++r) {
+            sc[kt][r] = (16 * kt + r < lim) ? sc[kt][r] : -INFINITY;
+            m = fmaxf(m, sc[kt][r]);
         }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -127,33 +148,26 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
-                sc[kt][r] = e;
-                l += e;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
+            sc[kt][r] = e;
+            l += e;
         }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
-            const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
-            // k-step r covers keys r, 4 + r, 8 + r, 12 + r of the tile: past the window's last key the probabilities
-            // are exactly 0, so the ragged last tile stops early (uniform branch)
-            const int rem = L - kt * 16;
+    for (int kt = 0; kt < NKT; ++kt) {
+        const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < rem) {
-                    const float pr = sc[kt][r] * inv;
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV + 16], o1, 0, 0, 0);
-                }
+        for (int r = 0; r < 4; ++r) {
+            const float pr = sc[kt][r] * inv;
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV + 16], o1, 0, 0, 0);
         }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qrow = q0 + 4 * lg + r;
