@@ -14,7 +14,9 @@
 // (round 2) and to the HBM traffic (gather mode reads a quarter of the bytes of the packed mode: same time) -- a
 // workgroup's LIFETIME (load round trips -> stage -> barrier -> S^T -> softmax -> P.V -> store) times the four workgroups
 // a CU holds (7 waves each, 32 wave slots) is what counts.  Hence: all loads of a workgroup in ONE round trip (was four
-// serial ones: 2.79 -> 2.66 ms), every key tile always walked (no branches, zero rows + masked scores).
+// serial ones: 2.79 -> 2.66 ms), every key tile always walked (no branches, zero rows + masked scores).  Two query tiles
+// per wave (4-wave workgroups, five per CU instead of four 7-wave ones, all loads still in one round trip) measured
+// 2.61 / 2.67 / 2.83 ms against 2.64 / 2.67 / 2.91 (packed / gather / pos-add): within 3 %, not kept.
 //
 //   a window of 101 tokens pads to 112 x 112 scores, a wave keeps 4 registers per key tile.
 //   S^T tile: A = K (keys on accumulator rows 4g + r, g = lane / 16), B = Q^T (query = lane % 16): a lane owns one
