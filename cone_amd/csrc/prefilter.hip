@@ -154,14 +154,75 @@ __device__ __forceinline__ void tk_wave_select(const float (&v)[PT], const int (
     }
 }
 
+// Bitonic sort of one (value, index) pair per lane over the 64 lanes of a wave, best first (lane 0 = largest value, ties
+// to the lower index); empty slots (index 0x7fffffff, value -inf) sink to the end.
+__device__ __forceinline__ void tk_wave_sort(float& v, int& i) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const float pv = __shfl_xor(v, j, 64);
+            const int pi = __shfl_xor(i, j, 64);
+            const bool take_better = ((lane & j) == 0) == ((lane & k2) == 0);
+            const bool p_better = tk_better(pv, pi, v, i), p_worse = tk_better(v, i, pv, pi);
+            if (take_better ? p_better : p_worse) { v = pv; i = pi; }
+        }
+}
+
+// Threshold selection for k <= 64 (the pre-filter's top-k is 20 - 30): sort the 64 per-lane bests; the k-th of them, T,
+// cannot precede the k-th best of ALL values (the k best lane-bests are k distinct values at or ahead of T), so every
+// member of the top-k is at or ahead of T; typically ~1.3 k values are (40 of 1 024 at k = 30).  They are compacted into
+// `scr` (64 slots of this wave), sorted once more, and lanes 0 .. k-1 hold the answer: ~700 instructions instead of k
+// passes over all PT values (5 100 at k = 30, PT = 16).  More than 64 survivors (values clustered in few lanes) -> false:
+// the caller falls back to the pass-based selection.  Same total order, hence the same list, bit for bit.
+template <int PT>
+__device__ __forceinline__ bool tk_wave_select_fast(const float (&v)[PT], const int (&ix)[PT], int k, float* out_v, int* out_i,
+                                                    float* scr_v, int* scr_i, int used = PT) {
+    const int lane = threadIdx.x & 63;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+        if (u < used && ix[u] != 0x7fffffff && tk_better(v[u], ix[u], bv, bi)) { bv = v[u]; bi = ix[u]; }
+    tk_wave_sort(bv, bi);
+    const float tv = __shfl(bv, k - 1, 64);
+    const int ti = __shfl(bi, k - 1, 64);           // 0x7fffffff: fewer than k lanes hold anything -> everything survives
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+        c += (u < used && ix[u] != 0x7fffffff && !tk_better(tv, ti, v[u], ix[u])) ? 1 : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (total > 64) return false;
+    int pos = incl - c;
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+        if (u < used && ix[u] != 0x7fffffff && !tk_better(tv, ti, v[u], ix[u])) { scr_v[pos] = v[u]; scr_i[pos] = ix[u]; ++pos; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's ds_writes ahead of its ds_reads
+    float cv = lane < total ? scr_v[lane] : -INFINITY;
+    int ci = lane < total ? scr_i[lane] : 0x7fffffff;
+    tk_wave_sort(cv, ci);
+    if (lane < k) { out_v[lane] = ci == 0x7fffffff ? -INFINITY : cv; out_i[lane] = ci; }
+    return true;
+}
+
 // Workgroup of 256: per-wave lists into LDS, then wave 0 merges the four lists into (gv, gi)[0 .. k) in global memory.
 template <int PT>
 __device__ __forceinline__ void tk_block_select(const float (&v)[PT], const int (&ix)[PT], int k, float* gv, int* gi,
                                                 int idx_none) {
     __shared__ float l_v[4 * TK_KMAX];
     __shared__ int l_i[4 * TK_KMAX];
+    __shared__ float s_v[4 * 64];
+    __shared__ int s_i[4 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    tk_wave_select<PT>(v, ix, k, l_v + wave * k, l_i + wave * k);
+    if (!(k <= 64 && tk_wave_select_fast<PT>(v, ix, k, l_v + wave * k, l_i + wave * k, s_v + wave * 64, s_i + wave * 64)))
+        tk_wave_select<PT>(v, ix, k, l_v + wave * k, l_i + wave * k);
     __syncthreads();
     if (wave != 0) return;
     constexpr int MT = 4 * TK_KMAX / 64;            // merge slots per lane
@@ -175,8 +236,10 @@ __device__ __forceinline__ void tk_block_select(const float (&v)[PT], const int 
         mi[t] = ok ? l_i[e] : 0x7fffffff;
     }
     // the merged list goes through the (now free) first list's LDS slots, then out with the caller's "none" index
-    tk_wave_select<MT>(mv, mi, k, l_v, l_i, (4 * k + 63) / 64);
-    __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): lane 0's ds_writes before the wave reads them back
+    const int used = (4 * k + 63) / 64;
+    if (!(k <= 64 && tk_wave_select_fast<MT>(mv, mi, k, l_v, l_i, s_v, s_i, used)))
+        tk_wave_select<MT>(mv, mi, k, l_v, l_i, used);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the list's ds_writes before the wave reads it back
     for (int r = lane; r < k; r += 64) {
         const int i = l_i[r];
         gv[r] = l_v[r];
@@ -195,8 +258,10 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < TK_PT; ++u) {
         const int j = u * 256 + tid;
-        v[u] = j < m ? row[j] : -INFINITY;
-        ix[u] = j < m ? (int)(base + j) : 0x7fffffff;       // global window index: ascending with j
+        const float x = j < m ? row[j] : -INFINITY;
+        const bool ok = j < m && x == x;                    // a NaN score is never selected (as in the one-level kernel)
+        v[u] = ok ? x : -INFINITY;
+        ix[u] = ok ? (int)(base + j) : 0x7fffffff;          // global window index: ascending with j
     }
     tk_block_select<TK_PT>(v, ix, k, cval + ((size_t)q * n_chunks + ch) * k, cidx + ((size_t)q * n_chunks + ch) * k, 0x7fffffff);
 }

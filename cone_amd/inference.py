@@ -730,10 +730,11 @@ def _graph_replay(model, store: FeatureStore, opt):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             dp = device_pipeline(model, store, opt)
-        hit = cache[key] = (g, dp)
-    g, dp = hit
-    g.replay()
-    return dict(dp)
+        # everything the captured launches point at must outlive the graph: the model (weights, position tables) and the
+        # workspace buffer of THIS capture (the model's grow-only workspace may be replaced by a larger one later)
+        hit = cache[key] = (g, dp, model, model._ws.buf, getattr(model, "_pos_tabs", None))
+    hit[0].replay()
+    return dict(hit[1])
 
 
 def predict_split(model, store: FeatureStore, opt):

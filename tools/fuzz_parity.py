@@ -29,7 +29,7 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 model.set_option("split_bf16", split_bf16)        # 1: the opt-in bf16-split layer tails, same checks, same tolerances
 A = lambda r: np.array(r["pred_relevant_windows"])
 worst = dict(prop=0.0, sec=0.0, match_bad=0.0)
-tot = dict(rows=0, bad=0, bnd=0)
+tot = dict(rows=0, bad=0, bnd=0, reordered=0)
 sd_t = O.as_torch_sd(sd)
 cpu = lambda t: t.detach().cpu()
 t_start = time.time()
@@ -55,9 +55,28 @@ for it in range(iters):
     assert len(mine) == len(mr), f"{tag}: {len(mine)} windows vs {len(mr)}"
     for a, b in zip(mine, mr):
         assert a["query_id"] == b["query_id"], tag
-    dp = max(np.abs(A(a)[:, 2] - A(b)[:, 2]).max() for a, b in zip(mine, mr))
-    ds = max(np.abs(A(a)[:, :2] - A(b)[:, :2]).max() for a, b in zip(mine, mr))
-    dm = np.concatenate([np.abs(A(a)[:, 3] - A(b)[:, 3]) for a, b in zip(mine, mr)])
+    # rows of a window are sorted by the UNROUNDED proposal probability (cone/inference.py:81-82): two proposals whose
+    # probabilities differ by less than an exp ulp (typically both ~1e-6, printed 0.0000) may legitimately come out in the
+    # other order.  Such a window is re-aligned -- each of our rows to the oracle row with the same span -- provided the
+    # swapped rows' probabilities agree within the 2e-4 row tolerance; counted, never silently dropped.
+    sec_tol = 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
+    pairs = []
+    for a, b in zip(mine, mr):
+        ra, rb = A(a), A(b)
+        if np.abs(ra[:, :2] - rb[:, :2]).max() > sec_tol:
+            perm, free = [], list(range(len(rb)))
+            for r in ra:
+                j = min(free, key=lambda j: np.abs(rb[j, :2] - r[:2]).max())
+                free.remove(j)
+                perm.append(j)
+            moved = [i for i, j in enumerate(perm) if i != j]
+            assert all(abs(rb[i, 2] - rb[perm[i], 2]) <= 2e-4 for i in moved), f"{tag}: rows of {a['query_id']} in another order than the oracle's, not a near-tie:\n{ra}\n{rb}"
+            rb = rb[perm]
+            tot["reordered"] += 1
+        pairs.append((ra, rb))
+    dp = max(np.abs(ra[:, 2] - rb[:, 2]).max() for ra, rb in pairs)
+    ds = max(np.abs(ra[:, :2] - rb[:, :2]).max() for ra, rb in pairs)
+    dm = np.concatenate([np.abs(ra[:, 3] - rb[:, 3]) for ra, rb in pairs])
     assert dp <= 2e-4, f"{tag}: proposal scores off by {dp}"
     assert ds <= 1e-4 * opt.max_v_l * opt.clip_length + 1e-4, f"{tag}: spans off by {ds} s"
     bad = float((dm > 2e-4).mean())
@@ -83,4 +102,5 @@ for it in range(iters):
 print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
       f"worst span diff {worst['sec']:.2e} s; matching: every proposal within {worst['match_alt']:.1e} of the oracle's pooling of its "
       f"own span, {tot['bad']} of {tot['rows']} rows ({tot['bad'] / max(tot['rows'], 1):.2%}) beyond 2e-4 of the oracle's rows "
-      f"({tot['bnd']} proposals next to a clip boundary; worst split {worst['match_bad']:.0%})")
+      f"({tot['bnd']} proposals next to a clip boundary; worst split {worst['match_bad']:.0%}); "
+      f"{tot['reordered']} windows with near-tied proposals in the other order")
