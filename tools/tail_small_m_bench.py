@@ -19,7 +19,7 @@ Wo, bo = d(torch.randn(256, 256, generator=g) / 16), d(torch.randn(256, generato
 lg, lb, pg, pb = (d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g)),
                   d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g) * 0.3))
 lib, P = _lib.load(), _lib.ptr
-for M in (100, 2000, 9600, 12500, 16384, 16512, 32768, 100000):
+for M in (100, 2000, 9600, 12500, 16384, 16512, 32768, 36000, 40000, 49152, 100000, 265000, 270000):
     X = torch.randn(M, 256, device=dev)
     A = torch.randn(M, 256, device=dev)
     out = torch.empty(M, 256, device=dev)
