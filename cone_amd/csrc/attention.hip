@@ -294,11 +294,63 @@ __global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict_
         }
 }
 
+// Decoder SELF-attention over the NQ slots of a window (cone/transformer.py:296-305), one wavefront per WINDOW: lane = (head
+// l / 8, four channels 4 (l % 8) .. of the head's 32), so a slot's 256-channel row is one coalesced 1-KiB load per operand;
+// the 32-channel dot products are finished by three shuffle steps inside the head's eight lanes; softmax over NQ keys in
+// registers; the output row again one coalesced store.  (small_attn_kernel spends a whole wavefront on every (window, head):
+// 160 000 one-wave workgroups for 20 000 windows, 264 us; this form 20 000 waves.)
+template <int NQ>
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
+                                                            int ldk, const float* __restrict__ V, int ldv,
+                                                            float* __restrict__ OUT, int ldo, int B) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    float4 q[NQ], k[NQ], v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const size_t row = (size_t)b * NQ + i;
+        q[i] = reinterpret_cast<const float4*>(Q + row * ldq)[lane];
+        k[i] = reinterpret_cast<const float4*>(K + row * ldk)[lane];
+        v[i] = reinterpret_cast<const float4*>(V + row * ldv)[lane];
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float sc[NQ];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            float d = ((q[i].x * kQScale) * k[j].x + (q[i].y * kQScale) * k[j].y) + ((q[i].z * kQScale) * k[j].z + (q[i].w * kQScale) * k[j].w);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            sc[j] = d;
+            m = fmaxf(m, d);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { sc[j] = expf(sc[j] - m); l += sc[j]; }
+        const float inv = 1.0f / l;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const float p = sc[j] * inv;
+            o.x = fmaf(p, v[j].x, o.x); o.y = fmaf(p, v[j].y, o.y); o.z = fmaf(p, v[j].z, o.z); o.w = fmaf(p, v[j].w, o.w);
+        }
+        reinterpret_cast<float4*>(OUT + ((size_t)b * NQ + i) * ldo)[lane] = o;
+    }
+}
+
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s) {
     CONE_REQUIRE(nq >= 1 && nq <= 8, "decoder attention: num_queries=%d not in [1,8]", nq);
     CONE_REQUIRE(Lmax <= kSmallMaxKeys, "decoder attention: %d keys > %d", Lmax, kSmallMaxKeys);
     if (B <= 0) return 0;
+    if (!off && nq == 5 && (ldq | ldk | ldv | ldo) % 4 == 0) {     // self-attention over the slots, the shipped slot count
+        hipLaunchKernelGGL(dec_self_attn_kernel<5>, dim3((B + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, B);
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(small_attn_kernel, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);
     CONE_LAUNCH_CHECK();
     return 0;

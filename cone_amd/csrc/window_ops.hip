@@ -257,7 +257,16 @@ __global__ __launch_bounds__(256) void proposal_mean_kernel(const float* __restr
     const int nv = dv >> 2;
     for (int ch = lane; ch < nv; ch += 64) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = s; r < e_val; ++r) {
+        int r = s;
+        // eight rows requested before the first is added (the adds keep the row order: same sums as the plain loop)
+        for (; r + 8 <= e_val; r += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4*>(base + (size_t)(r + u) * dv)[ch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += x[u].x; a.y += x[u].y; a.z += x[u].z; a.w += x[u].w; }
+        }
+        for (; r < e_val; ++r) {
             const float4 x = reinterpret_cast<const float4*>(base + (size_t)r * dv)[ch];
             a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
         }
