@@ -47,6 +47,11 @@ struct cone_model {
     // and its cross-attention queries depend on the checkpoint only): norm1 output (nq, 256) and the cross-attention query
     // projection (nq, 256), computed once at creation by the same kernels a step would run on ONE window's rows
     float* dec0_tgt1 = nullptr; float* dec0_dq = nullptr; float* dec0_scratch = nullptr;
+    // derived: the slot-position term of the decoder's projections.  q = k = (tgt + query_embed) W^T + b is linear, so
+    // (tgt + qe) W^T + b = tgt W^T + (qe W^T + b): per layer a (nq, 768) table [qe W_q^T + b_q | qe W_k^T + b_k | b_v] for the
+    // self-attention in_proj (ONE N = 768 GEMM on tgt, the table as a row-periodic residual) and a (nq, 256) table
+    // qe W_q^T + b_q for the cross-attention query projection -- the same move as the encoder's position tables
+    float* dec_sa_tab[CONE_MAX_LAYERS] = {}; float* dec_ca_tab[CONE_MAX_LAYERS] = {};
     // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
     int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 = on the matrix
                               // cores (dec_cross_mfma.hip), 1 = on the VALU (dec_cross.hip), 0 = K/V GEMMs + small_attn
@@ -153,7 +158,8 @@ static int build_model(const cone_weights* w, cone_model** out) {
             set_error("model_create: a required weight pointer is null");
             return CONE_E_INVALID;
         }
-    const size_t dec0_floats = (size_t)m->nq * (256 * 2 + 256 + 512 + 256 + 256) + 6 * 64;
+    const size_t dec0_floats = (size_t)m->nq * (256 * 2 + 256 + 768 + 256) + 6 * 64 +
+                               (size_t)m->n_dec * (align_up((size_t)m->nq * 768, 64) + align_up((size_t)m->nq * 256, 64));
     const size_t stacked = (size_t)m->n_dec * (d * d + d) * 2 + 4 * 64 + (size_t)m->n_dec * d * d + dec0_floats;
     hipError_t e = hipMalloc((void**)&m->arena, (ab.total + stacked) * sizeof(float));
     if (e != hipSuccess) {
@@ -214,7 +220,11 @@ static int build_model(const cone_weights* w, cone_model** out) {
     }
     m->dec0_tgt1 = m->arena + cur; cur += align_up((size_t)m->nq * 256, 64);
     m->dec0_dq = m->arena + cur; cur += align_up((size_t)m->nq * 256, 64);
-    m->dec0_scratch = m->arena + cur; cur += align_up((size_t)m->nq * (256 + 512 + 256 + 256), 64);
+    m->dec0_scratch = m->arena + cur; cur += align_up((size_t)m->nq * (256 + 768 + 256), 64);
+    for (int i = 0; i < m->n_dec; ++i) {
+        m->dec_sa_tab[i] = m->arena + cur; cur += align_up((size_t)m->nq * 768, 64);
+        m->dec_ca_tab[i] = m->arena + cur; cur += align_up((size_t)m->nq * 256, 64);
+    }
     if (d == 256 && ffn_split_supported(m->ff)) {   // split-bf16 images of every layer tail (13 MB at ff = 1024; opt-in path)
         const size_t per = ffn_split_proj_image_bytes() + ffn_split_image_bytes(m->ff);
         const size_t qkv = rows256_split_image_bytes(768);
@@ -280,27 +290,33 @@ static GemmArgs G(const cone_model* m, const float* A, int lda, const float* W, 
 
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-// First decoder layer on tgt = 0 (cone/transformer.py:66, 296-311): self-attention over the nq slots (q = k = query_embed
-// W^T, v = bias rows), out_proj + norm1, and the cross-attention query projection -- no window enters, so the nq rows
-// are per-checkpoint constants.  Computed with the kernels and the row count (nq) a step used for them, hence the same bits.
+// Per-checkpoint constants of the decoder (cone/transformer.py:296-311).  (1) The slot-position tables of every layer (see
+// cone_model).  (2) The first layer on tgt = 0 (:66): its self-attention over the nq slots (q | k | v = the table rows), out_proj
+// + norm1, and its cross-attention queries -- no window enters, so the nq rows are constants too.  Computed with the kernels
+// and the row count (nq) a step uses for one window, hence the same bits as the per-window path (dec0_const = 0).
 static int dec0_constants(cone_model* m, hipStream_t s) {
-    const DecLayer& dl = m->dec[0];
     const int nq = m->nq;
     float* TGT = m->dec0_scratch;                       // (nq, 256) zeros
-    float* DQK = TGT + (size_t)nq * 256;                // (nq, 512)
-    float* DV = DQK + (size_t)nq * 512;                 // (nq, 256)
-    float* DATT = DV + (size_t)nq * 256;                // (nq, 256)
+    float* QKV = TGT + (size_t)nq * 256;                // (nq, 768)
+    float* DATT = QKV + (size_t)nq * 768;               // (nq, 256)
     CONE_CHECK_HIP(hipMemsetAsync(TGT, 0, (size_t)nq * 256 * sizeof(float), s));
-    GemmArgs g = G(m, TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, DQK, 512, nq, nullptr, 512, 256);
-    g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = nq;
+    for (int l = 0; l < m->n_dec; ++l) {
+        const DecLayer& dl = m->dec[l];
+        // [qe W_q^T + b_q | qe W_k^T + b_k]  and  b_v rows (0 W_v^T + b_v)
+        RUN(launch_gemm(G(m, m->query_embed, 256, dl.sa.in_w, 256, dl.sa.in_b, m->dec_sa_tab[l], 768, nq, nullptr, 512, 256), s));
+        RUN(launch_gemm(G(m, TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, m->dec_sa_tab[l] + 512, 768, nq, nullptr, 256, 256), s));
+        RUN(launch_gemm(G(m, m->query_embed, 256, dl.ca.in_w, 256, dl.ca.in_b, m->dec_ca_tab[l], 256, nq, nullptr, 256, 256), s));
+    }
+    const DecLayer& d0 = m->dec[0];
+    GemmArgs g = G(m, TGT, 256, d0.sa.in_w, 256, nullptr, QKV, 768, nq, nullptr, 768, 256, EPI_RESIDUAL);
+    g.R = m->dec_sa_tab[0]; g.ldr = 768; g.r_mod = nq;
     RUN(launch_gemm(g, s));
-    RUN(launch_gemm(G(m, TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, DV, 256, nq, nullptr, 256, 256), s));
-    RUN(launch_small_attn(DQK, 512, DQK + 256, 512, DV, 256, DATT, 256, nullptr, 1, nq, nq, s));
-    g = G(m, DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, m->dec0_tgt1, 256, nq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
-    g.R = TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
+    RUN(launch_small_attn(QKV, 768, QKV + 256, 768, QKV + 512, 768, DATT, 256, nullptr, 1, nq, nq, s));
+    g = G(m, DATT, 256, d0.sa.out.w, 256, d0.sa.out.b, m->dec0_tgt1, 256, nq, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
+    g.R = TGT; g.ldr = 256; g.ln_g = d0.n1.g; g.ln_b = d0.n1.b;
     RUN(launch_gemm(g, s));
-    g = G(m, m->dec0_tgt1, 256, dl.ca.in_w, 256, dl.ca.in_b, m->dec0_dq, 256, nq, nullptr, 256, 256);
-    g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = nq;
+    g = G(m, m->dec0_tgt1, 256, d0.ca.in_w, 256, nullptr, m->dec0_dq, 256, nq, nullptr, 256, 256, EPI_RESIDUAL);
+    g.R = m->dec_ca_tab[0]; g.ldr = 256; g.r_mod = nq;
     RUN(launch_gemm(g, s));
     return 0;
 }
@@ -371,7 +387,7 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
     }
     if (!p.fold) { f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd); }
     f.TGT = c.take<float>(T * 256); f.TGT1 = c.take<float>(T * 256); f.TGT2 = c.take<float>(T * 256);
-    f.DQK = c.take<float>(T * 512); f.DV = c.take<float>(T * 256); f.DATT = c.take<float>(T * 256);
+    f.DQK = c.take<float>(T * 768); f.DV = nullptr; f.DATT = c.take<float>(T * 256);      // DQK: the slots' q | k | v
     f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
     f.HS = c.take<float>(nd * T * 256); f.S1 = c.take<float>(nd * T * 256); f.S2 = c.take<float>(nd * T * 256);
     f.LG = c.take<float>(nd * T * 2); f.SP = c.take<float>(nd * T * 2);
@@ -522,16 +538,16 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             // cone_model_create), replicated to the T rows of the batch in one launch
             RUN(launch_tile_rows2(f.TGT1, m->dec0_tgt1, f.DQ, m->dec0_dq, m->nq, T, s));
         } else {
-            g = G(m, f.TGT, 256, dl.sa.in_w, 256, dl.sa.in_b, f.DQK, 512, T, nullptr, 512, 256);
-            g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+            // q | k | v of the slots in ONE N = 768 GEMM on tgt, the slot-position term from the layer's table
+            g = G(m, f.TGT, 256, dl.sa.in_w, 256, nullptr, f.DQK, 768, T, nullptr, 768, 256, EPI_RESIDUAL);
+            g.R = m->dec_sa_tab[l]; g.ldr = 768; g.r_mod = m->nq;
             RUN(launch_gemm(g, s));
-            RUN(launch_gemm(G(m, f.TGT, 256, dl.sa.in_w + 512 * 256, 256, dl.sa.in_b + 512, f.DV, 256, T, nullptr, 256, 256), s));
-            RUN(launch_small_attn(f.DQK, 512, f.DQK + 256, 512, f.DV, 256, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
+            RUN(launch_small_attn(f.DQK, 768, f.DQK + 256, 768, f.DQK + 512, 768, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
             g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT1, 256, T, nullptr, 256, 256, EPI_RESIDUAL | EPI_LN);
             g.R = f.TGT; g.ldr = 256; g.ln_g = dl.n1.g; g.ln_b = dl.n1.b;
             RUN(launch_gemm(g, s));
-            g = G(m, f.TGT1, 256, dl.ca.in_w, 256, dl.ca.in_b, f.DQ, 256, T, nullptr, 256, 256);
-            g.A2 = m->query_embed; g.lda2 = 256; g.a2_mod = m->nq;
+            g = G(m, f.TGT1, 256, dl.ca.in_w, 256, nullptr, f.DQ, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+            g.R = m->dec_ca_tab[l]; g.ldr = 256; g.r_mod = m->nq;
             RUN(launch_gemm(g, s));
         }
         if (fold && m->opt_dec_fold >= 2)

@@ -107,6 +107,7 @@ struct GemmArgs {
     const float* W; int ldw;              // (N,K): torch Linear weight
     const float* bias;                    // (N) or null
     const float* R; int ldr;              // residual (M,N), EPI_RESIDUAL
+    int r_mod;                            // > 0: the residual is row-periodic, row m reads R[m % r_mod] (a per-slot table)
     const float* ln_g; const float* ln_b; // EPI_LN (N == 256)
     float* C; int ldc;
     float* C2; const float* ADD;          // optional second output C2 = C + ADD (same ldc), row tile only

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 const int m = m0 + wm * 64 + tm * 32 + acc_row(r, lane);
                 float v = acc[tm][tn][r] + bv;
                 if (flags & EPI_RELU) v = fmaxf(v, 0.f);
-                if ((flags & EPI_RESIDUAL) && m < M && n < N) v += p.R[(size_t)m * p.ldr + n];
+                if ((flags & EPI_RESIDUAL) && m < M && n < N) v += p.R[(size_t)(p.r_mod ? m % p.r_mod : m) * p.ldr + n];
                 acc[tm][tn][r] = v;
             }
         }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, (RBK == 32 ? 1 : 2)) void gemm_rows_kernel(Gem
             int i = min(8 * g + k, rows_here - 1);
             i = i < 0 ? 0 : i;
             const size_t m = (size_t)min(mrow0 + i, M - 1);
-            if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + m * p.ldr + n0 + c4);
+            if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? m % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
             if (p.C2) ad[k] = *reinterpret_cast<const float4*>(p.ADD + m * p.ldc + n0 + c4);
             v[k] = *reinterpret_cast<const float4*>(ep + k * RT_EP_LD + c4);
         }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
                 int i = min(8 * g + 4 * hf + k, rows_here - 1);
                 i = i < 0 ? 0 : i;
                 const size_t m = (size_t)min(mrow0 + i, M - 1);
-                if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + m * p.ldr + n0 + c4);
+                if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? m % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
                 v[k] = *reinterpret_cast<const float4*>(ep + (4 * hf + k) * RT_EP_LD + c4);
             }
 #pragma unroll
