@@ -602,6 +602,97 @@ __global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small-M form of the row tile: a full 128 x 256 tile keeps one CU busy for >= 27 us of exact-fp32 MFMA whatever the row
+// count (16.8 MFLOP at 256 FLOP / clock), so a launch over a few hundred rows -- the decoder / head / matching GEMMs of the
+// single-query path, 19 of them per step at 38 - 42 us each -- is bound by that one tile.  Here a workgroup (4 waves) owns
+// 16 rows x 256 columns, wave w the column tiles 4w .. 4w+3; the operands come straight from global memory / L2 as the
+// fragment float4 of gemm_rows16_kernel (A: row li, channels 16 kt + 4 lg ..; W: row n0 + 16 t + li, same channels), the
+// accumulation runs the SAME chain -- for kt, for j: acc[t] = mfma(a[j], b[j], acc[t]) -- and the epilogue the same per-row
+// code (one float4 per lane and row: bias, ReLU, residual, LayerNorm by wave_sum_dpp), so a row's result is bit-identical
+// to the 128-row tile's: the choice depends on the host-known row bound only.
+constexpr int RS_EP_LD = RT_BN + 4;
+
+__global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float ep[16 * RS_EP_LD];
+    int M = p.M;
+    if (p.M_dev) { int md = *p.M_dev; M = md < M ? md : M; }
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * RT_BN;
+    if (m0 >= M) return;
+    const int K = p.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int arow = min(m0 + li, M - 1);                         // rows past M feed unstored outputs
+    const float* __restrict__ ap = p.A + (size_t)arow * p.lda + 4 * lg;
+    const float* __restrict__ wp = p.W + (size_t)(n0 + 64 * wave + li) * p.ldw + 4 * lg;
+    const size_t wt = (size_t)16 * p.ldw;                         // next column tile
+    f32x4a acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / 16;
+    f32x4a a = *reinterpret_cast<const f32x4a*>(ap), b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x4a*>(wp + t * wt);
+    for (int kt = 0; kt < nk; ++kt) {
+        f32x4a an = a, bn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bn[t] = b[t];
+        if (kt + 1 < nk) {                                        // the next slab's fragments under this slab's MFMAs
+            an = *reinterpret_cast<const f32x4a*>(ap + (kt + 1) * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[t] = *reinterpret_cast<const f32x4a*>(wp + t * wt + (kt + 1) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[t][j], acc[t], 0, 0, 0);
+        a = an;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = bn[t];
+    }
+    // accumulator (t, r) of lane (li, lg) = row 4 lg + r, column 64 wave + 16 t + li
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(4 * lg + r) * RS_EP_LD + 64 * wave + 16 * t + li] = acc[t][r];
+    __syncthreads();
+    const int flags = p.flags;
+    const int c4 = lane * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = bias4, be4 = bias4;
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
+    if (flags & EPI_LN) {
+        g4 = *reinterpret_cast<const float4*>(p.ln_g + c4);
+        be4 = *reinterpret_cast<const float4*>(p.ln_b + c4);
+    }
+    float4 v[4], rr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                 // wave w walks rows 4w .. 4w+3
+        const size_t m = (size_t)min(m0 + 4 * wave + k, M - 1);
+        if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? m % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
+        v[k] = *reinterpret_cast<const float4*>(ep + (4 * wave + k) * RS_EP_LD + c4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 x = v[k];
+        x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
+        if (flags & EPI_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        if (flags & EPI_RESIDUAL) { x.x += rr[k].x; x.y += rr[k].y; x.z += rr[k].z; x.w += rr[k].w; }
+        if (flags & EPI_LN) {
+            const float mean = wave_sum_dpp((x.x + x.y) + (x.z + x.w)) * (1.0f / 256.0f);
+            const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+            const float var = wave_sum_dpp((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            x.x = d0 * rstd * g4.x + be4.x; x.y = d1 * rstd * g4.y + be4.y;
+            x.z = d2 * rstd * g4.z + be4.z; x.w = d3 * rstd * g4.w + be4.w;
+        }
+        const int m = m0 + 4 * wave + k;
+        if (m < M) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n0 + c4) = x;
+    }
+}
+
+constexpr int RS_MAX_ROWS = 4096;     // at most this many rows (host bound): 256 workgroups per 256 columns
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     CONE_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm: lda/ldw must be multiples of 4");
@@ -611,7 +702,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const bool rows_ok = a.N % 256 == 0 && !a.A2;
     // The tile family is a function of the SHAPE and of a.variant only (never of M or of process state), so a row
     // of C is computed by the same instruction sequence whatever batch it sits in: results are bit-identical
-    // across batch compositions.
+    // across batch compositions.  (The row tile's small-M form, chosen by the host-known row bound, runs the same fma
+    // chains and the same per-row epilogue on 16-row tiles: same bits.)
     const bool use_rows = rows_ok && a.variant != GEMM_SQUARE;
     const bool need_rows = a.C2 != nullptr;
     CONE_REQUIRE(!need_rows || (rows_ok && a.ADD), "gemm: second output needs the row tile (N %% 256 == 0, no A2)");
@@ -626,6 +718,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             return rc;
         }));
         const bool waves8 = a.variant != GEMM_ROWS4;
+        if (waves8 && !a.C2 && a.M <= RS_MAX_ROWS && a.K % 16 == 0 && a.variant == GEMM_AUTO) {
+            // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)
+            ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);
+            hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(256), 0, s, a);
+            CONE_LAUNCH_CHECK();
+            return 0;
+        }
         const int row_tiles = (a.M + RT_BM - 1) / RT_BM;
         dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * (a.N / RT_BN)));      // 1-D, see the tile order in the kernel
         ProfScope ps(waves8 ? PK_GEMM_ROWS16 : PK_GEMM_ROWS, a.M, a.N, a.K, a.M_dev, s);

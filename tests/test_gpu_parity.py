@@ -180,6 +180,30 @@ def test_fused_ffn_matches_float64(M, ff):
     assert bool(torch.isnan(R[M:]).all())
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(100, 256, 256, 0), (777, 768, 256, 1), (37, 256, 1024, 2 | 4), (4096, 512, 256, 2),
+                                         (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0)])
+def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
+    """gemm.hip: launches of at most 4 096 rows take 16-row tiles spread over the CUs (gemm_rows_small_kernel) instead of one
+    128 x 256 tile per 128 rows; same fma chains, same per-row epilogue -- the same bits as the 128-row tile (forced here
+    with the tile-family test hook), so a row's result does not depend on the size of the batch it is computed in."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(M * 7 + N + K + flags)
+    d = lambda t: t.to(dev).contiguous()
+    A, W = d(torch.randn(M, K, generator=g)), d(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias, R = d(torch.randn(N, generator=g)), d(torch.randn(M, N, generator=g))
+    lg, lb = d(torch.rand(N, generator=g) + 0.5), d(torch.randn(N, generator=g))
+    lib, P = _lib.load(), _lib.ptr
+    outs = []
+    for fam in (0, 0x300):                              # automatic (small-M form at this size) / forced 8-wave 128-row tile
+        C = torch.full((M, N), float("nan"), device=dev)
+        _lib.check(lib.cone_test_gemm(P(A), None, 0, P(W), P(bias), P(R) if flags & 2 else None, P(lg), P(lb), P(C), None, None,
+                                      M, N, K, flags | fam, _lib.stream()))
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
+
+
 def test_fused_tail_small_m_form_is_bit_identical():
     """ffn.hip runs 64-row tiles on 4 waves (one per SIMD: half the time per tile, twice the grid) when the 128-row tiles
     would leave half of the CUs idle, 128-row tiles on 8 waves otherwise: the same per-wave instruction sequence, so a
