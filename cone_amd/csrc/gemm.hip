@@ -691,7 +691,12 @@ __global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmArgs p) {
     }
 }
 
-constexpr int RS_MAX_ROWS = 4096;     // at most this many rows (host bound): 256 workgroups per 256 columns
+// The small form pays while its 16 x 256 tiles are at most two per CU (tools/gemm_small_bench.py: N = 256: 12 us up to 4 096
+// rows, 23 us at 8 192 against 38 - 40 us of the 128-row tile, level at 12 500; N = 768: 31 us at 4 096, behind from 8 192)
+#ifndef CONE_RS_MAX_WGS
+#define CONE_RS_MAX_WGS 512
+#endif
+constexpr int RS_MAX_WGS = CONE_RS_MAX_WGS;
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
@@ -718,7 +723,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             return rc;
         }));
         const bool waves8 = a.variant != GEMM_ROWS4;
-        if (waves8 && !a.C2 && a.M <= RS_MAX_ROWS && a.K % 16 == 0 && a.variant == GEMM_AUTO) {
+        if (waves8 && !a.C2 && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS && a.variant == GEMM_AUTO) {
             // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)
             ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);
             hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(256), 0, s, a);

@@ -183,7 +183,7 @@ def test_fused_ffn_matches_float64(M, ff):
 @pytest.mark.parametrize("M,N,K,flags", [(100, 256, 256, 0), (777, 768, 256, 1), (37, 256, 1024, 2 | 4), (4096, 512, 256, 2),
                                          (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
-    """gemm.hip: launches of at most 4 096 rows take 16-row tiles spread over the CUs (gemm_rows_small_kernel) instead of one
+    """gemm.hip: launches of at most 512 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel) instead of one
     128 x 256 tile per 128 rows; same fma chains, same per-row epilogue -- the same bits as the 128-row tile (forced here
     with the tile-family test hook), so a row's result does not depend on the size of the batch it is computed in."""
     from cone_amd import _lib
