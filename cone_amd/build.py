@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcone_hip.so")
 PYLISTS = os.path.join(HERE, "_cone_pylists.so")      # host helper (CPython C API): kept rows -> submission lists
 SOURCES = ["api.hip", "gemm.hip", "rowops.hip", "attention.hip", "window_ops.hip", "prefilter.hip",
-           "postproc.hip", "prof.hip", "dec_cross.hip", "metrics.hip", "ffn.hip", "criterion.hip", "dec_cross_mfma.hip", "ffn_split.hip"]
+           "postproc.hip", "prof.hip", "dec_cross.hip", "metrics.hip", "ffn.hip", "criterion.hip", "dec_cross_mfma.hip", "ffn_split.hip", "ffn_wide.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # Files whose scalar arithmetic must round operation by operation like the reference's torch / Python
 # code (HIP's __fmul_rn & co. are plain operators and would otherwise be contracted into fma).

@@ -143,6 +143,17 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
 bool ffn_fused_qkv_fits(int ff, int n_qkv);
 // r_idx != null: residual row i is gathered -- r_idx[i] >= 0: row r_idx[i] of R, else row ~r_idx[i] of R2 (launch_row_index)
 
+// ---------------------------------------------------------------- wide form for a few row groups (ffn_wide.hip)
+// The same two computations with ONE workgroup per 16 rows whose eight waves split the output elements (projection and
+// GEMM2 by output channels, GEMM1 by hidden units): every element's fma chain is ffn.hip's, results are bit-identical.
+bool ffn_wide_supported(int ff);
+int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
+                    const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s);
+int launch_proj_ffn_wide(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                         const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                         const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
+                         hipStream_t s, const int* r_idx, const float* R2);
+
 // ---------------------------------------------------------------- the same on the bf16 matrix cores (ffn_split.hip)
 // fp32 products as six partial products of three-piece bf16 operands, fp32 accumulation: fp32-MFMA accuracy (measured),
 // 2.7x its rate.  Wimg = the layer's W1 / W2 split and laid out once by launch_ffn_split_pack

@@ -538,6 +538,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
 #undef FFN_RD
 
 bool ffn_fused_supported(int ff) { return ff >= 32 && ff % 16 == 0 && ff <= 4096; }
+
+// Launches of at most this many 16-row groups (host bound) take the wide form (ffn_wide.hip: one workgroup per group,
+// the eight waves split the output elements; ~40 us per group against 176 us of a wave's serial pass over the weights)
+#ifndef CONE_FFN_WIDE_GROUPS
+#define CONE_FFN_WIDE_GROUPS 256
+#endif
+constexpr int FFN_WIDE_GROUPS = CONE_FFN_WIDE_GROUPS;
 bool ffn_fused_qkv_fits(int ff, int n_qkv) {
     return ffn_fused_supported(ff) && n_qkv >= 32 && n_qkv % 32 == 0 &&
            (size_t)(FFN_NST * FFN_STAGE + ff + 6 * 256 + n_qkv) * sizeof(float) <= 160 * 1024;
@@ -586,6 +593,8 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
     CONE_REQUIRE(X && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused FFN: null argument");
     CONE_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "fused FFN: row strides must be multiples of 4");
     if (M <= 0) return 0;
+    if ((M + 15) / 16 <= FFN_WIDE_GROUPS && ffn_wide_supported(ff))     // a few row groups: the wide form (same bits)
+        return launch_ffn_wide(X, ldx, W1, b1, W2, b2, ln_g, ln_b, OUT, ldo, M, M_dev, ff, s);
     FfnArgs a{};
     a.X = X; a.ldx = ldx; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
@@ -602,6 +611,8 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
     CONE_REQUIRE(A && Wo && bo && R && pg && pb && W1 && b1 && W2 && b2 && ln_g && ln_b && OUT, "fused layer tail: null argument");
     CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "fused layer tail: row strides must be multiples of 4");
     if (M <= 0) return 0;
+    if (!Wq && (M + 15) / 16 <= FFN_WIDE_GROUPS && ffn_wide_supported(ff))     // a few row groups: the wide form (same bits)
+        return launch_proj_ffn_wide(A, lda, Wo, bo, R, ldr, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, ldo, M, M_dev, ff, s, r_idx, R2);
     FfnArgs a{};
     a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;

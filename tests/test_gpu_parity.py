@@ -204,14 +204,18 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
 
 
-def test_fused_tail_small_m_form_is_bit_identical():
-    """ffn.hip runs 64-row tiles on 4 waves (one per SIMD: half the time per tile, twice the grid) when the 128-row tiles
-    would leave half of the CUs idle, 128-row tiles on 8 waves otherwise: the same per-wave instruction sequence, so a
-    row's result must not depend on which form -- i.e. on how many rows -- it was computed with."""
+@pytest.mark.parametrize("ff", [1024, 384])
+def test_fused_tail_small_m_form_is_bit_identical(ff):
+    """The fused layer tail has three forms: 128-row tiles on 8 waves, 64-row tiles on 4 waves (one per SIMD: half the
+    time per tile, twice the grid) when the 128-row tiles would leave half of the CUs idle, and -- for at most
+    CONE_FFN_WIDE_GROUPS = 256 groups of 16 rows -- the wide form of ffn_wide.hip (one workgroup per 16 rows, its waves
+    sharing the block's OUTPUT elements).  Every output element goes through the same fma chain in all three, so a row's
+    result must not depend on which form -- i.e. on how many rows -- it was computed with.  (ff = 384: an odd number of
+    chunk groups per wave in the wide form.)"""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(11)
-    M, m, ff = 40_000, 3000, 1024                     # 313 tiles of 128 -> the 8-wave form; 24 tiles -> the 4-wave form
+    M = 40_000                                         # 313 tiles of 128 -> the 8-wave form
     X = (torch.randn(M, 256, generator=g) * 1.5).to(dev)
     A = torch.randn(M, 256, generator=g).to(dev)
     d = lambda t: t.to(dev).contiguous()
@@ -221,16 +225,20 @@ def test_fused_tail_small_m_form_is_bit_identical():
     lg, lb, pg, pb = (d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g)),
                       d(torch.rand(256, generator=g) + 0.5), d(torch.randn(256, generator=g) * 0.3))
     lib, P = _lib.load(), _lib.ptr
-    big, small = torch.empty(M, 256, device=dev), torch.empty(m, 256, device=dev)
+    big = torch.empty(M, 256, device=dev)
     _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(big), M, ff, _lib.stream()))
-    _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(small), m, ff, _lib.stream()))
-    assert torch.equal(big[:m], small)
-    big2, small2 = X.clone(), X[:m].clone()
+    big2 = X.clone()
     _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(big2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
                                       P(big2), M, ff, _lib.stream()))
-    _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(small2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
-                                      P(small2), m, ff, _lib.stream()))
-    assert torch.equal(big2[:m], small2)
+    # 1 .. 4096 rows: the wide form (a ragged last group, one group, all 256 groups); 4100, 12 000: the 4-wave form
+    for m in (1, 37, 3000, 4096, 4100, 12_000):
+        small = torch.empty(m, 256, device=dev)
+        _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(small), m, ff, _lib.stream()))
+        assert torch.equal(big[:m], small), m
+        small2 = X[:m].clone()
+        _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(small2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg),
+                                          P(lb), P(small2), m, ff, _lib.stream()))
+        assert torch.equal(big2[:m], small2), m
 
 
 @pytest.mark.parametrize("n,dim", [(5, 256), (1000, 768), (3, 512), (77, 1024)])
