@@ -539,10 +539,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
 
 bool ffn_fused_supported(int ff) { return ff >= 32 && ff % 16 == 0 && ff <= 4096; }
 
-// Launches of at most this many 16-row groups (host bound) take the wide form (ffn_wide.hip: one workgroup per group,
-// the eight waves split the output elements; ~40 us per group against 176 us of a wave's serial pass over the weights)
+// Launches of at most this many 16-row groups (host bound) take the wide form (ffn_wide.hip: one workgroup per group and
+// CU, the eight waves split the output elements): 45 - 60 us per round of 256 groups against 160 - 200 us of a wave's
+// serial pass over the weights.  tools/tail_wide_bench.py, out_proj + LN + FFN: 52 / 62 / 124 / 183 us at 16 / 4 096 /
+// 8 192 / 12 288 rows against 168 / 181 / 187 / 194 us; from the fourth round on (12 500 rows: 226 us) the row forms win.
 #ifndef CONE_FFN_WIDE_GROUPS
-#define CONE_FFN_WIDE_GROUPS 256
+#define CONE_FFN_WIDE_GROUPS 768
 #endif
 constexpr int FFN_WIDE_GROUPS = CONE_FFN_WIDE_GROUPS;
 bool ffn_fused_qkv_fits(int ff, int n_qkv) {

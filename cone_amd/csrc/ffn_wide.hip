@@ -2,9 +2,9 @@
 //     x1  = LayerNorm_p(R + A Wo^T + bo)                       (PROJ; else x1 = X)
 //     out = LayerNorm(x1 + W2 relu(W1 x1 + b1) + b2)           (cone/transformer.py:239-245, 308-316)
 //
-// In ffn.hip a wave owns 16 token rows for the WHOLE block: 9 216 exact-fp32 MFMAs in a row, 0.18 ms even with a SIMD to
+// In ffn.hip a wave owns 16 token rows for the WHOLE block: 9 216 exact-fp32 MFMAs in a row, 0.15 ms even with a SIMD to
 // itself -- whatever the number of rows.  A launch of a few hundred rows (the four layer tails of the single-query path,
-// the decoder tails of a 64-query video or of an 8-GPU rank's share) is bound by that serial chain while most CUs idle.
+// the decoder tails of a small batch) is bound by that serial chain while most CUs idle.
 // Here ONE workgroup of 8 waves owns 16 rows and the waves split the block's OUTPUT elements:
 //   projection : wave w computes channels [32 w, 32 w + 32) of A Wo^T  (pair g = w of ffn.hip),
 //   GEMM1      : wave w computes the hidden chunks c = w, w + 8, ...   (16 hidden units each),
@@ -13,9 +13,17 @@
 // LDS.  Every output element is accumulated by the SAME fma chain as in ffn.hip (same MFMA k-slot assignment, same order
 // of steps, same partial chains and the same order of their final additions; the LayerNorm moments by the same routine on
 // the same register layout), so the result is bit-identical to the 8-wave / 4-wave forms: a row's result does not depend
-// on which form -- i.e. on how many rows -- it was computed with.  Weight fragments come straight from global memory /
-// L2 in the operand layout (row = lane % 16, four consecutive k at 16 q + 4 (lane / 16)), the next unit's requested ahead.
-// 1 152 MFMAs per wave instead of 9 216: ~40 us per launch of up to one workgroup per CU.
+// on which form -- i.e. on how many rows -- it was computed with.
+//
+// Weight stream.  Every wave needs its OWN weights (no reuse inside the workgroup), as operand slabs [16 rows][16 floats]:
+// 32 for the projection, 16 per hidden chunk, 2 per hidden chunk in GEMM2.  A slab is fetched by ONE LDS-DMA instruction
+// (global_load_lds_dwordx4: lane -> row = lane / 4, 16-B chunk = lane % 4, i.e. 64 contiguous bytes per 4 adjacent lanes)
+// into the wave's private 8-slab ring and read back as the MFMA operand (row = lane % 16, chunk = lane / 16) with
+// gemm.hip's chunk XOR swizzle (conflict-free).  [Measured: the same bytes loaded straight into the operand layout --
+// 16 B per lane, adjacent lanes 1 KiB apart -- cost 9 us per GEMM on top of 18 us of MFMA; one coalesced instruction per
+// slab 1.3 us.]  The ring runs through the three phases without a break (their slab counts are multiples of 8): pair
+// step p multiplies slabs 2p, 2p + 1 (already in registers), reads 2p + 2, 2p + 3 from the ring and refills the two
+// slots with slabs 2p + 8, 2p + 9 -- 6 to 8 KiB in flight per wave, one counted s_waitcnt vmcnt per pair.
 #include "common.h"
 
 namespace cone {
@@ -31,6 +39,13 @@ struct FfnWideArgs {
 };
 
 constexpr int FW_XLD = 260;     // row stride (floats) of the 16 x 256 exchange tile
+constexpr int FW_RING = 8 * 256;    // floats per wave: 8 slabs of [16 rows][16 floats]
+
+#define FW_GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ __forceinline__ int fw_swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
 
 // the same moments as ffn.hip's ffn_layernorm_regs: a token's 256 channels as v[16] (channel 16 t + 4 lg + r in v[t][r])
 __device__ __forceinline__ void fw_layernorm_regs(f32x4w (&v)[16], float& rstd) {
@@ -52,12 +67,42 @@ __device__ __forceinline__ void fw_layernorm_regs(f32x4w (&v)[16], float& rstd) 
 }
 
 #define FW_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0)
+#define FW_SB() __builtin_amdgcn_sched_barrier(0)
+// workgroup barrier for data written with ds_write: __syncthreads() would also drain the LDS-DMA ring (its fence waits
+// for every LDS write in flight, vmcnt(0)); the ring slots are wave-private and ordered by the counted waits
+#define FW_BARRIER()                                           \
+    {                                                          \
+        FW_SB();                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        FW_SB();                                               \
+    }
+// slabs 2p + 2, 2p + 3 have landed (at most the four issued after them are still in flight) -> registers
+#define FW_STEP_BEGIN(s0, s1)                                  \
+    {                                                          \
+        FW_SB();                                               \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       \
+        n0 = *reinterpret_cast<const f32x4w*>(ring + (s0) * 256 + rdo); \
+        n1 = *reinterpret_cast<const f32x4w*>(ring + (s1) * 256 + rdo); \
+        FW_SB();                                               \
+    }
+// the pair's slots (read one step ago, consumed by the MFMAs above) take slabs 2p + 8, 2p + 9
+#define FW_STEP_END(src0, src1, s0, s1)                        \
+    {                                                          \
+        FW_SB();                                               \
+        FW_GLDS16(src0, ring + (s0) * 256);                    \
+        FW_GLDS16(src1, ring + (s1) * 256);                    \
+        c0 = n0; c1 = n1;                                      \
+        FW_SB();                                               \
+    }
 
 template <bool PROJ>
 __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ff = p.ff, nc = ff >> 4;
     float* XS = smem;                               // [16 tokens][FW_XLD]: projected rows, later the block's output rows
-    float* HS = smem + 16 * FW_XLD;                 // [ff / 16 chunks][64 lanes][4]: hidden tiles in accumulator layout
+    float* HS = XS + 16 * FW_XLD;                   // [ff / 16 chunks][64 lanes][4]: hidden tiles in accumulator layout
+    float* B1 = HS + ff * 16;                       // b1 (no ordinary global load inside the DMA-counted loops)
     int M = p.M;
     if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
     const int row0 = blockIdx.x * 16;
@@ -65,13 +110,33 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int ff = p.ff, nc = ff >> 4;
+    float* ring = B1 + ff + wave * FW_RING;         // this wave's slab ring
     const int my_row = row0 + li;
     const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);       // rows past M feed unstored outputs
+    const int n1c = nc >> 3;                        // hidden chunks per wave
 
+    // slab sources: uniform base + lane offset (row = lane / 4, source chunk = the one that lands in physical chunk lane % 4)
+    const int drow = lane >> 2;
+    const int dq = ((lane & 3) ^ fw_swz16(drow)) << 2;
+    const int off256 = drow * 256 + dq;             // Wo, W1 (row stride 256)
+    const int offff = drow * ff + dq;               // W2 (row stride ff)
+    const int rdo = li * 16 + ((lg ^ fw_swz16(li)) << 2);       // operand read: row li, chunk lg
+    const float* baseA = p.Wo + (size_t)(32 * wave) * 256;                                 // + 16 t * 256 + 16 q
+    const float* baseB = p.W1 + (size_t)(16 * wave) * 256;                                 // + 128 i * 256 + 16 q
+    const float* baseC = p.W2 + (size_t)(32 * wave) * ff;                                  // + 16 t * ff + 16 c
+    auto srcA = [&](int q, int t) { return baseA + (t * 16 * 256 + 16 * q) + off256; };
+    auto srcB = [&](int i, int q) { return baseB + ((size_t)i * (128 * 256) + 16 * q) + off256; };
+    auto srcC = [&](int c, int t) { return baseC + ((size_t)t * 16 * ff + 16 * c) + offff; };
+
+    for (int i = tid; i < ff; i += 512) B1[i] = p.b1[i];
+
+    f32x4w c0, c1, n0, n1;                          // the current / next slab pair as MFMA operands
     // ---- the block input x1 (every wave holds the 16 rows: xr[q][r] = row[token li][16 q + 4 lg + r])
     f32x4w xr[16];
     if (PROJ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { FW_GLDS16(srcA(j, 0), ring + (2 * j) * 256); FW_GLDS16(srcA(j, 1), ring + (2 * j + 1) * 256); }
+        FW_SB();
         f32x4w ar[16];
         const float* ap = p.A + ld_row * p.lda + 4 * lg;
 #pragma unroll
@@ -81,35 +146,32 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
             const int ix = p.r_idx[ld_row];
             rp = (ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr) + 4 * lg;
         }
-        // pair g = wave: channels [32 g, 32 g + 32) of A Wo^T, two partial chains per tile as in ffn.hip.  All 32 weight
-        // fragments are requested at once (a wave that waits for one L2 round trip per fragment spends its time waiting)
-        const float* w_lo = p.Wo + (size_t)(32 * wave + li) * 256 + 4 * lg;          // rows 32 g + li
-        const float* w_hi = w_lo + 16 * 256;                                          // rows 32 g + 16 + li
-        f32x4w wl[16], wh[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            wl[q] = *reinterpret_cast<const f32x4w*>(w_lo + 16 * q);
-            wh[q] = *reinterpret_cast<const f32x4w*>(w_hi + 16 * q);
-        }
         const f32x4w r0 = *reinterpret_cast<const f32x4w*>(rp + 32 * wave);          // the residual of this wave's two tiles
         const f32x4w r1 = *reinterpret_cast<const f32x4w*>(rp + 32 * wave + 16);
-        __builtin_amdgcn_sched_barrier(0);                  // the whole burst before the first MFMA
+        FW_SB();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the younger row loads are needed by the first MFMA anyway)
+        c0 = *reinterpret_cast<const f32x4w*>(ring + rdo);
+        c1 = *reinterpret_cast<const f32x4w*>(ring + 256 + rdo);
+        // pair g = wave: channels [32 g, 32 g + 32) of A Wo^T, two partial chains per tile as in ffn.hip
         f32x4w ha[2], hb[2];
         ha[0] = f32x4w{0.f, 0.f, 0.f, 0.f}; ha[1] = ha[0]; hb[0] = ha[0]; hb[1] = ha[0];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            FW_STEP_BEGIN((2 * q + 2) & 7, (2 * q + 3) & 7);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                FW_MFMA(ha[r & 1], wl[q][r], ar[q][r]);
-                FW_MFMA(hb[r & 1], wh[q][r], ar[q][r]);
+                FW_MFMA(ha[r & 1], c0[r], ar[q][r]);
+                FW_MFMA(hb[r & 1], c1[r], ar[q][r]);
             }
+            if (q + 4 < 16) { FW_STEP_END(srcA(q + 4, 0), srcA(q + 4, 1), (2 * q) & 7, (2 * q + 1) & 7); }
+            else { FW_STEP_END(srcB(0, 2 * (q - 12)), srcB(0, 2 * (q - 12) + 1), (2 * q) & 7, (2 * q + 1) & 7); }
         }
         // residual + projection of this wave's two tiles -> LDS; register r of lane (li, lg) = channel 16 t + 4 lg + r
         const f32x4w x0 = r0 + (ha[0] + ha[1]);
         const f32x4w x1 = r1 + (hb[0] + hb[1]);
         *reinterpret_cast<f32x4w*>(XS + li * FW_XLD + 32 * wave + 4 * lg) = x0;
         *reinterpret_cast<f32x4w*>(XS + li * FW_XLD + 32 * wave + 16 + 4 * lg) = x1;
-        __syncthreads();
+        FW_BARRIER();                                       // (also: b1 is in LDS)
 #pragma unroll
         for (int t = 0; t < 16; ++t)
             xr[t] = *reinterpret_cast<const f32x4w*>(XS + li * FW_XLD + 16 * t + 4 * lg) +
@@ -124,94 +186,71 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
             for (int r = 0; r < 4; ++r) xr[t][r] = xr[t][r] * rstd * g4[r] + b4[r];
         }
     } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) FW_GLDS16(srcB(0, j), ring + j * 256);
+        FW_SB();
         const float* xp = p.X + ld_row * p.ldx + 4 * lg;
 #pragma unroll
         for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const f32x4w*>(xp + 16 * q);
+        FW_SB();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c0 = *reinterpret_cast<const f32x4w*>(ring + rdo);
+        c1 = *reinterpret_cast<const f32x4w*>(ring + 256 + rdo);
+        FW_BARRIER();                                       // b1 is in LDS
     }
 
-    // ---- GEMM1: hidden chunks c = wave, wave + 8, ...: four partial chains over the 16 k-slabs, as ffn.hip's FFN_MM_A.
-    // The 16 weight fragments of the NEXT chunk are in flight while this chunk's 64 MFMAs run.
+    // ---- GEMM1: hidden chunks c = wave, wave + 8, ...: four partial chains over the 16 k-slabs, as ffn.hip's FFN_MM_A
     f32x4w r0 = xr[0], r1 = xr[1];                          // the block input of this wave's two output tiles (residual)
 #pragma unroll
     for (int g = 1; g < 8; ++g)
         if (wave == g) { r0 = xr[2 * g]; r1 = xr[2 * g + 1]; }
-    {
-        f32x4w wA[16], wB[16], bA, bB;                      // ping-pong: no register copies, exact wait counts
-        auto load_chunk = [&](f32x4w (&w)[16], f32x4w& bias, int c) {
-            const bool live = c < nc;                       // past the end: every lane re-reads W1's first bytes (unused)
-            const float* w1p = live ? p.W1 + (size_t)(16 * c + li) * 256 + 4 * lg : p.W1;
+    for (int i = 0; i < n1c; ++i) {
+        const int c = wave + 8 * i;
+        const bool last = i + 1 >= n1c;                     // the look-ahead of the last chunk's second half: GEMM2's first slabs
+        f32x4w hp[4];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = *reinterpret_cast<const f32x4w*>(w1p + 16 * q);
-            bias = *reinterpret_cast<const f32x4w*>(live ? p.b1 + 16 * c + 4 * lg : p.b1);
-            __builtin_amdgcn_sched_barrier(0);              // keep the burst ahead of the MFMAs it overlaps
-        };
-        auto mm_chunk = [&](const f32x4w (&w)[16], const f32x4w& bias, int c) {
-            f32x4w hp[4];
+        for (int r = 0; r < 4; ++r) hp[r] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[r] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 8; ++u) {
+            FW_STEP_BEGIN((2 * u + 2) & 7, (2 * u + 3) & 7);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c0[r], xr[2 * u][r]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], w[q][r], xr[q][r]);
+            for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c1[r], xr[2 * u + 1][r]);
+            if (u < 4) { FW_STEP_END(srcB(i, 2 * u + 8), srcB(i, 2 * u + 9), (2 * u) & 7, (2 * u + 1) & 7); }
+            else {
+                const float* s0 = last ? srcC(u - 4, 0) : srcB(i + 1, 2 * u - 8);
+                const float* s1 = last ? srcC(u - 4, 1) : srcB(i + 1, 2 * u - 7);
+                FW_STEP_END(s0, s1, (2 * u) & 7, (2 * u + 1) & 7);
             }
-            f32x4w h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + bias;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
-            *reinterpret_cast<f32x4w*>(HS + (size_t)c * 256 + lane * 4) = h;    // k slot lg of step r <-> hidden unit 16 c + 4 lg + r
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // the look-ahead load is unconditional (past the end it reads one dummy line): behind a branch it makes the
-        // compiler wait for ALL loads in flight before the first MFMA of the chunk
-        load_chunk(wA, bA, wave);
-        for (int c = wave; c < nc; c += 16) {
-            load_chunk(wB, bB, c + 8);
-            mm_chunk(wA, bA, c);
-            if (c + 8 >= nc) break;
-            load_chunk(wA, bA, c + 16);
-            mm_chunk(wB, bB, c + 8);
         }
+        f32x4w h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + *reinterpret_cast<const f32x4w*>(B1 + 16 * c + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+        *reinterpret_cast<f32x4w*>(HS + (size_t)c * 256 + lane * 4) = h;        // k slot lg of step r <-> hidden unit 16 c + 4 lg + r
     }
+    FW_BARRIER();                                           // the hidden tile is complete
 
-    // ---- GEMM2: output tiles 2 w, 2 w + 1 over all hidden chunks in order, as ffn.hip's FFN_MM_Y; weight fragments by
-    // groups of 8 chunks, the next group in flight (the first one across the barrier)
+    // ---- GEMM2: output tiles 2 w, 2 w + 1 over all hidden chunks in order, as ffn.hip's FFN_MM_Y
     const int t0 = 2 * wave;
     f32x4w y0 = f32x4w{0.f, 0.f, 0.f, 0.f}, y1 = y0;
-    {
-        const float* w2a = p.W2 + (size_t)(16 * t0 + li) * ff + 4 * lg;
-        const float* w2b = w2a + (size_t)16 * ff;
-        f32x4w uA[8], vA[8], uB[8], vB[8];
-        auto load_group = [&](f32x4w (&u)[8], f32x4w (&v)[8], int c0) {
-            const float* pa = c0 < nc ? w2a + 16 * c0 : p.W2;
-            const float* pb = c0 < nc ? w2b + 16 * c0 : p.W2;
+    for (int cb = 0; cb < nc; cb += 4) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                u[j] = *reinterpret_cast<const f32x4w*>(pa + 16 * j);
-                v[j] = *reinterpret_cast<const f32x4w*>(pb + 16 * j);
+        for (int j = 0; j < 4; ++j) {
+            const f32x4w hh = *reinterpret_cast<const f32x4w*>(HS + (size_t)(cb + j) * 256 + lane * 4);
+            FW_STEP_BEGIN((2 * j + 2) & 7, (2 * j + 3) & 7);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                FW_MFMA(y0, c0[r], hh[r]);
+                FW_MFMA(y1, c1[r], hh[r]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto mm_group = [&](const f32x4w (&u)[8], const f32x4w (&v)[8], int c0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4w hh = *reinterpret_cast<const f32x4w*>(HS + (size_t)(c0 + j) * 256 + lane * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    FW_MFMA(y0, u[j][r], hh[r]);
-                    FW_MFMA(y1, v[j][r], hh[r]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        load_group(uA, vA, 0);
-        __syncthreads();                                    // the hidden tile is complete
-        for (int c0 = 0; c0 < nc; c0 += 16) {
-            load_group(uB, vB, c0 + 8);
-            mm_group(uA, vA, c0);
-            if (c0 + 8 >= nc) break;
-            load_group(uA, vA, c0 + 16);
-            mm_group(uB, vB, c0 + 8);
+            const bool more = cb + 4 + j < nc;              // past the end: one dummy line (keeps the wait count exact)
+            const float* s0 = more ? srcC(cb + 4 + j, 0) : p.W2;
+            const float* s1 = more ? srcC(cb + 4 + j, 1) : p.W2;
+            FW_STEP_END(s0, s1, (2 * j) & 7, (2 * j + 1) & 7);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup's LDS allocation
     // ---- epilogue: + b2 + residual of this wave's tiles -> LDS, full rows back, LayerNorm (same routine, same layout)
     y0 = y0 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t0 + 4 * lg) + r0;
     y1 = y1 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * (t0 + 1) + 4 * lg) + r1;
@@ -240,13 +279,19 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     }
 }
 
+#undef FW_STEP_BEGIN
+#undef FW_STEP_END
+#undef FW_SB
+#undef FW_BARRIER
 #undef FW_MFMA
 
-bool ffn_wide_supported(int ff) { return ff >= 128 && ff % 128 == 0 && (size_t)(16 * FW_XLD + ff * 16) * sizeof(float) <= 160 * 1024; }
+static size_t fw_lds_bytes(int ff) { return (size_t)(16 * FW_XLD + ff * 17 + 8 * FW_RING) * sizeof(float); }
+
+bool ffn_wide_supported(int ff) { return ff >= 128 && ff % 128 == 0 && fw_lds_bytes(ff) <= 160 * 1024; }
 
 template <bool PROJ>
 static int launch_wide_t(const FfnWideArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(16 * FW_XLD + a.ff * 16) * sizeof(float);
+    const size_t lds = fw_lds_bytes(a.ff);
     static DeviceOnce once;
     CONE_CHECK_HIP(device_once(once, [] {
         return hipFuncSetAttribute((const void*)ffn_wide_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -208,7 +208,7 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
 def test_fused_tail_small_m_form_is_bit_identical(ff):
     """The fused layer tail has three forms: 128-row tiles on 8 waves, 64-row tiles on 4 waves (one per SIMD: half the
     time per tile, twice the grid) when the 128-row tiles would leave half of the CUs idle, and -- for at most
-    CONE_FFN_WIDE_GROUPS = 256 groups of 16 rows -- the wide form of ffn_wide.hip (one workgroup per 16 rows, its waves
+    CONE_FFN_WIDE_GROUPS = 768 groups of 16 rows -- the wide form of ffn_wide.hip (one workgroup per 16 rows, its waves
     sharing the block's OUTPUT elements).  Every output element goes through the same fma chain in all three, so a row's
     result must not depend on which form -- i.e. on how many rows -- it was computed with.  (ff = 384: an odd number of
     chunk groups per wave in the wide form.)"""
@@ -230,8 +230,8 @@ def test_fused_tail_small_m_form_is_bit_identical(ff):
     big2 = X.clone()
     _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(big2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
                                       P(big2), M, ff, _lib.stream()))
-    # 1 .. 4096 rows: the wide form (a ragged last group, one group, all 256 groups); 4100, 12 000: the 4-wave form
-    for m in (1, 37, 3000, 4096, 4100, 12_000):
+    # 1 .. 12 288 rows: the wide form (one ragged group; one, two, three rounds of 256 groups); 12 500, 16 000: 4 waves
+    for m in (1, 37, 3000, 4096, 4100, 12_288, 12_500, 16_000):
         small = torch.empty(m, 256, device=dev)
         _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(small), m, ff, _lib.stream()))
         assert torch.equal(big[:m], small), m

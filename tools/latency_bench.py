@@ -1,12 +1,14 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cone_amd import synth, inference as inf
 from cone_amd.config import make_opt
 from cone_amd.model import build_model
 opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20)
 model, _ = build_model(opt)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
-for nq, nv in ((1, 1), (8, 1), (64, 4)):
+cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1, 1), (8, 1), (64, 4)]   # e.g. 1x1
+for nq, nv in cases:
     ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=0, ctx_range=(900, 901))
     store = inf.FeatureStore(opt, ann, vf, qf)
     for _ in range(5): inf.predict_split(model, store, opt)
