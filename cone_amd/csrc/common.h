@@ -95,7 +95,7 @@ bool prof_enabled();
 struct ProfScope {
     ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
     ~ProfScope();
-    int idx_; hipStream_t s_;
+    int idx_; hipStream_t s_; bool counted_;
 };
 
 // ---------------------------------------------------------------- GEMM launcher (gemm.hip)
@@ -147,12 +147,14 @@ bool ffn_fused_qkv_fits(int ff, int n_qkv);
 // The same two computations with ONE workgroup per 16 rows whose eight waves split the output elements (projection and
 // GEMM2 by output channels, GEMM1 by hidden units): every element's fma chain is ffn.hip's, results are bit-identical.
 bool ffn_wide_supported(int ff);
+// m_off: the rows are rows m_off .. m_off + M of a larger job whose device-side row count is *M_dev
 int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
-                    const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s);
+                    const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s,
+                    int m_off = 0);
 int launch_proj_ffn_wide(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
                          const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
-                         hipStream_t s, const int* r_idx, const float* R2);
+                         hipStream_t s, const int* r_idx, const float* R2, int m_off = 0);
 
 // ---------------------------------------------------------------- the same on the bf16 matrix cores (ffn_split.hip)
 // fp32 products as six partial products of three-piece bf16 operands, fp32 accumulation: fp32-MFMA accuracy (measured),

@@ -588,6 +588,20 @@ static int launch_ffn_t(const FfnArgs& a, hipStream_t s) {
     return launch_ffn_nw<PROJ, QKV, 8>(a, s, nullptr);
 }
 
+// Rows past the last FULL round of the persistent grid (n_cu tiles of 128 rows) cost the row forms a partial round -- half
+// a round or more (0.15 - 0.29 ms) whatever their number; up to FFN_SPLIT_GROUPS groups of them are handed to the wide form
+// instead (52 / 124 us for <= 4 096 / 8 192 rows; same bits).  Returns the row count of the full rounds, or M (no split).
+#ifndef CONE_FFN_SPLIT_GROUPS
+#define CONE_FFN_SPLIT_GROUPS 512
+#endif
+static int ffn_full_round_rows(int M, int n_cu, int ff) {
+    const int tiles = (M + 127) / 128;
+    if (tiles <= n_cu || !ffn_wide_supported(ff)) return M;
+    const int64_t full = (int64_t)(tiles / n_cu) * n_cu * 128;
+    const int64_t rem = M - full;
+    return rem > 0 && (rem + 15) / 16 <= CONE_FFN_SPLIT_GROUPS ? (int)full : M;
+}
+
 int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
                      const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
                      hipStream_t s) {
@@ -600,7 +614,15 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
     FfnArgs a{};
     a.X = X; a.ldx = ldx; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
-    return launch_ffn_t<false, false>(a, s);
+    int n_cu = 0;
+    if (int rc = launch_ffn_nw<false, false, 8>(a, s, &n_cu)) return rc;
+    const int m1 = ffn_full_round_rows(M, n_cu, ff);
+    if (m1 == M) return launch_ffn_t<false, false>(a, s);
+    ProfScope ps(PK_FFN_FUSED, M, ff, 256, M_dev, s);        // one record for the two launches
+    a.M = m1;
+    if (int rc = launch_ffn_t<false, false>(a, s)) return rc;
+    return launch_ffn_wide(X + (size_t)m1 * ldx, ldx, W1, b1, W2, b2, ln_g, ln_b, OUT + (size_t)m1 * ldo, ldo, M - m1, M_dev, ff,
+                           s, m1);
 }
 
 int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr,
@@ -624,7 +646,16 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
         a.Wq = Wq; a.qb = qb; a.QKV = QKV; a.ldq = ldq; a.n_qkv = n_qkv;
         return launch_ffn_t<true, true>(a, s);
     }
-    return launch_ffn_t<true, false>(a, s);
+    int n_cu = 0;
+    if (int rc = launch_ffn_nw<true, false, 8>(a, s, &n_cu)) return rc;
+    const int m1 = ffn_full_round_rows(M, n_cu, ff);
+    if (m1 == M) return launch_ffn_t<true, false>(a, s);
+    ProfScope ps(PK_FFN_PROJ, M, ff, 256, M_dev, s);         // one record for the two launches
+    a.M = m1;
+    if (int rc = launch_ffn_t<true, false>(a, s)) return rc;
+    return launch_proj_ffn_wide(A + (size_t)m1 * lda, lda, Wo, bo, r_idx ? R : R + (size_t)m1 * ldr, ldr, pg, pb, W1, b1, W2, b2,
+                                ln_g, ln_b, OUT + (size_t)m1 * ldo, ldo, M - m1, M_dev, ff, s, r_idx ? r_idx + m1 : nullptr, R2,
+                                m1);
 }
 
 }  // namespace cone

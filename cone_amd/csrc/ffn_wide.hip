@@ -35,7 +35,7 @@ struct FfnWideArgs {
     const float* A; int lda; const float* R; int ldr; const int* r_idx; const float* R2;
     const float* Wo; const float* bo; const float* pg; const float* pb;
     const float* W1; const float* b1; const float* W2; const float* b2; const float* ln_g; const float* ln_b;
-    float* OUT; int ldo; int M; const int* M_dev; int ff;
+    float* OUT; int ldo; int M; const int* M_dev; int ff; int m_off;
 };
 
 constexpr int FW_XLD = 260;     // row stride (floats) of the 16 x 256 exchange tile
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     float* HS = XS + 16 * FW_XLD;                   // [ff / 16 chunks][64 lanes][4]: hidden tiles in accumulator layout
     float* B1 = HS + ff * 16;                       // b1 (no ordinary global load inside the DMA-counted loops)
     int M = p.M;
-    if (p.M_dev) { const int md = *p.M_dev; M = md < M ? md : M; }
+    if (p.M_dev) { const int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
     const int row0 = blockIdx.x * 16;
     if (row0 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -303,8 +303,10 @@ static int launch_wide_t(const FfnWideArgs& a, hipStream_t s) {
 }
 
 int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
-                    const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s) {
+                    const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s,
+                    int m_off) {
     FfnWideArgs a{};
+    a.m_off = m_off;
     a.X = X; a.ldx = ldx; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
     return launch_wide_t<false>(a, s);
@@ -313,8 +315,9 @@ int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, c
 int launch_proj_ffn_wide(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
                          const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff,
-                         hipStream_t s, const int* r_idx, const float* R2) {
+                         hipStream_t s, const int* r_idx, const float* R2, int m_off) {
     FfnWideArgs a{};
+    a.m_off = m_off;
     a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb; a.r_idx = r_idx; a.R2 = R2;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;

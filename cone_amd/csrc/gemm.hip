@@ -604,58 +604,90 @@ __global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Small-M form of the row tile: a full 128 x 256 tile keeps one CU busy for >= 27 us of exact-fp32 MFMA whatever the row
-// count (16.8 MFLOP at 256 FLOP / clock), so a launch over a few hundred rows -- the decoder / head / matching GEMMs of the
-// single-query path, 19 of them per step at 38 - 42 us each -- is bound by that one tile.  Here a workgroup (4 waves) owns
-// 16 rows x 256 columns, wave w the column tiles 4w .. 4w+3; the operands come straight from global memory / L2 as the
-// fragment float4 of gemm_rows16_kernel (A: row li, channels 16 kt + 4 lg ..; W: row n0 + 16 t + li, same channels), the
-// accumulation runs the SAME chain -- for kt, for j: acc[t] = mfma(a[j], b[j], acc[t]) -- and the epilogue the same per-row
+// count (16.8 MFLOP at 256 FLOP / clock), so a launch over a few hundred or thousand rows -- the decoder / head / matching
+// GEMMs of the single-query path, the context projections of one long video -- is bound by that one tile, and a launch of
+// 258 tiles by the two CUs that run two.  Here a workgroup of 8 waves owns 16 rows x 256 columns, wave w the column tiles
+// 2w, 2w + 1.  The 16 activation rows are staged once as operand slabs [16 rows][16 floats] (16-B chunks XOR-swizzled, the
+// slab format of gemm_rows16_kernel); a wave's weight slabs -- nobody else needs them -- stream through its private ring of
+// three k-steps (one coalesced global_load_lds per slab, a counted s_waitcnt vmcnt per step).  The accumulation runs the
+// SAME chain as the 128-row tile -- for kt, for j: acc[t] = mfma(a[j], b[j], acc[t]) -- and the epilogue the same per-row
 // code (one float4 per lane and row: bias, ReLU, residual, LayerNorm by wave_sum_dpp), so a row's result is bit-identical
 // to the 128-row tile's: the choice depends on the host-known row bound only.
 constexpr int RS_EP_LD = RT_BN + 4;
+constexpr int RS_RING = 6 * 256;                                  // floats per wave: 3 k-steps x 2 column tiles
 
-__global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float ep[16 * RS_EP_LD];
+static size_t rs_lds_bytes(int K) {
+    const int a_floats = 16 * K > 16 * RS_EP_LD ? 16 * K : 16 * RS_EP_LD;      // A slabs, later the epilogue image
+    return (size_t)(a_floats + 8 * RS_RING) * sizeof(float);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     int M = p.M;
     if (p.M_dev) { int md = *p.M_dev; M = md < M ? md : M; }
     const int m0 = blockIdx.x * 16, n0 = blockIdx.y * RT_BN;
     if (m0 >= M) return;
-    const int K = p.K;
+    const int K = p.K, nk = K / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int arow = min(m0 + li, M - 1);                         // rows past M feed unstored outputs
-    const float* __restrict__ ap = p.A + (size_t)arow * p.lda + 4 * lg;
-    const float* __restrict__ wp = p.W + (size_t)(n0 + 64 * wave + li) * p.ldw + 4 * lg;
-    const size_t wt = (size_t)16 * p.ldw;                         // next column tile
-    f32x4a acc[4];
+    float* As = smem;                                             // [nk] slabs
+    float* ep = smem;                                             // (after the main loop) [16][RS_EP_LD]
+    float* ring = smem + (16 * K > 16 * RS_EP_LD ? 16 * K : 16 * RS_EP_LD) + wave * RS_RING;
+    // slab sources: lane -> row = lane / 4, source chunk = the one that lands in physical chunk lane % 4
+    const int drow = lane >> 2;
+    const int dq = ((lane & 3) ^ swz16(drow)) << 2;
+    const int arow = min(m0 + drow, M - 1);                       // rows past M feed unstored outputs
+    const float* __restrict__ asrc = p.A + (size_t)arow * p.lda + dq;
+    const float* __restrict__ wsrc = p.W + (size_t)(n0 + 32 * wave + drow) * p.ldw + dq;     // + 16 t * ldw + 16 kt
+    const size_t wt = (size_t)16 * p.ldw;
+    const int rdo = li * 16 + ((lg ^ swz16(li)) << 2);            // operand read: row li, chunk lg
+
+    for (int kt = wave; kt < nk; kt += 8) GLDS16(asrc + 16 * kt, As + kt * 256);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4a{0.f, 0.f, 0.f, 0.f};
-    const int nk = K / 16;
-    f32x4a a = *reinterpret_cast<const f32x4a*>(ap), b[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x4a*>(wp + t * wt);
-    for (int kt = 0; kt < nk; ++kt) {
-        f32x4a an = a, bn[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bn[t] = b[t];
-        if (kt + 1 < nk) {                                        // the next slab's fragments under this slab's MFMAs
-            an = *reinterpret_cast<const f32x4a*>(ap + (kt + 1) * 16);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bn[t] = *reinterpret_cast<const f32x4a*>(wp + t * wt + (kt + 1) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[t][j], acc[t], 0, 0, 0);
-        a = an;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = bn[t];
+    for (int kt = 0; kt < 3; ++kt) {
+        const bool live = kt < nk;                                // past the end: one dummy line (keeps the wait count exact)
+        GLDS16(live ? wsrc + 16 * kt : p.W, ring + (2 * kt) * 256);
+        GLDS16(live ? wsrc + wt + 16 * kt : p.W, ring + (2 * kt + 1) * 256);
     }
-    // accumulator (t, r) of lane (li, lg) = row 4 lg + r, column 64 wave + 16 t + li
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // this wave's A slabs (older than the six W slabs)
+    __builtin_amdgcn_s_barrier();                                 // every wave's A slabs
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // W slabs of k-step 0
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4a acc[2];
+    acc[0] = f32x4a{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+    f32x4a a = *reinterpret_cast<const f32x4a*>(As + rdo);
+    f32x4a b0 = *reinterpret_cast<const f32x4a*>(ring + rdo), b1 = *reinterpret_cast<const f32x4a*>(ring + 256 + rdo);
+    int slot = 0;                                                 // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // k-step kt + 1 has landed (kt + 2 may be in flight)
+        const int kn = kt + 1 < nk ? kt + 1 : kt;
+        const f32x4a an = *reinterpret_cast<const f32x4a*>(As + kn * 256 + rdo);
+        const f32x4a bn0 = *reinterpret_cast<const f32x4a*>(ring + (2 * nslot) * 256 + rdo);
+        const f32x4a bn1 = *reinterpret_cast<const f32x4a*>(ring + (2 * nslot + 1) * 256 + rdo);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kt + 3 < nk;                            // this step's slots (read one step ago) take k-step kt + 3
+        GLDS16(more ? wsrc + 16 * (kt + 3) : p.W, ring + (2 * slot) * 256);
+        GLDS16(more ? wsrc + wt + 16 * (kt + 3) : p.W, ring + (2 * slot + 1) * 256);
+        a = an; b0 = bn0; b1 = bn1;
+        slot = nslot;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may outlive the workgroup's LDS allocation
+    __syncthreads();                                              // every wave is done with the A slabs: epilogue image
+    // accumulator (t, r) of lane (li, lg) = row 4 lg + r, column 32 wave + 16 t + li
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ep[(4 * lg + r) * RS_EP_LD + 64 * wave + 16 * t + li] = acc[t][r];
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(4 * lg + r) * RS_EP_LD + 32 * wave + 16 * t + li] = acc[t][r];
     __syncthreads();
     const int flags = p.flags;
     const int c4 = lane * 4;
@@ -665,15 +697,15 @@ __global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmArgs p) {
         g4 = *reinterpret_cast<const float4*>(p.ln_g + c4);
         be4 = *reinterpret_cast<const float4*>(p.ln_b + c4);
     }
-    float4 v[4], rr[4];
+    float4 v[2], rr[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                                 // wave w walks rows 4w .. 4w+3
-        const size_t m = (size_t)min(m0 + 4 * wave + k, M - 1);
+    for (int k = 0; k < 2; ++k) {                                 // wave w walks rows 2w, 2w + 1
+        const size_t m = (size_t)min(m0 + 2 * wave + k, M - 1);
         if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? m % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
-        v[k] = *reinterpret_cast<const float4*>(ep + (4 * wave + k) * RS_EP_LD + c4);
+        v[k] = *reinterpret_cast<const float4*>(ep + (2 * wave + k) * RS_EP_LD + c4);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2; ++k) {
         float4 x = v[k];
         x.x += bias4.x; x.y += bias4.y; x.z += bias4.z; x.w += bias4.w;
         if (flags & EPI_RELU) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
@@ -686,15 +718,16 @@ __global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmArgs p) {
             x.x = d0 * rstd * g4.x + be4.x; x.y = d1 * rstd * g4.y + be4.y;
             x.z = d2 * rstd * g4.z + be4.z; x.w = d3 * rstd * g4.w + be4.w;
         }
-        const int m = m0 + 4 * wave + k;
+        const int m = m0 + 2 * wave + k;
         if (m < M) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n0 + c4) = x;
     }
 }
 
-// The small form pays while its 16 x 256 tiles are at most two per CU (tools/gemm_small_bench.py: N = 256: 12 us up to 4 096
-// rows, 23 us at 8 192 against 38 - 40 us of the 128-row tile, level at 12 500; N = 768: 31 us at 4 096, behind from 8 192)
+// The small form streams every weight byte from L2 once per 16 rows: 8.7 us per 256 tiles at K = 256 (13.3 at K = 512), i.e.
+// tools/gemm_small_bench.py, N = 256, K = 256: 9 / 17.5 / 31 us at 4 096 / 8 192 / 16 384 rows against 38 - 41 us of the 128-row
+// tile, behind from ~20 000 rows (57 vs 46 us at 32 768); N = 768: 24 us at 4 096 rows (768 tiles) against 40, level at 8 192.
 #ifndef CONE_RS_MAX_WGS
-#define CONE_RS_MAX_WGS 512
+#define CONE_RS_MAX_WGS 1280
 #endif
 constexpr int RS_MAX_WGS = CONE_RS_MAX_WGS;
 
@@ -720,13 +753,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             if (rc == hipSuccess)
                 rc = hipFuncSetAttribute((const void*)gemm_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          RowTile<16>::LDS_BYTES);
+            if (rc == hipSuccess)
+                rc = hipFuncSetAttribute((const void*)gemm_rows_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return rc;
         }));
         const bool waves8 = a.variant != GEMM_ROWS4;
-        if (waves8 && !a.C2 && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS && a.variant == GEMM_AUTO) {
+        if (waves8 && !a.C2 && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS && a.variant == GEMM_AUTO &&
+            rs_lds_bytes(a.K) <= 160 * 1024) {
             // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)
             ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);
-            hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(512),
+                               rs_lds_bytes(a.K), s, a);
             CONE_LAUNCH_CHECK();
             return 0;
         }

@@ -27,8 +27,14 @@ static hipEvent_t take_event() {
     return g_pool[g_pool_used++];
 }
 
-ProfScope::ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s) : idx_(-1), s_(s) {
+// A scope opened inside another one (a launcher that splits its rows over two kernels opens one for the whole job)
+// records nothing: the outer record covers both launches.
+static int g_depth = 0;
+
+ProfScope::ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s) : idx_(-1), s_(s), counted_(false) {
     if (!g_on) return;
+    counted_ = true;
+    if (g_depth++ > 0) return;
     ProfRec r{take_event(), take_event(), kind, a, b, c, -1};
     if (!r.e0 || !r.e1) return;
     if (a_dev && g_host_m && g_host_m_used < g_host_m_cap) {
@@ -40,6 +46,7 @@ ProfScope::ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev
     g_recs.push_back(r);
 }
 ProfScope::~ProfScope() {
+    if (counted_) --g_depth;
     if (idx_ >= 0) (void)hipEventRecord(g_recs[idx_].e1, s_);
 }
 
@@ -50,6 +57,7 @@ extern "C" int cone_prof_enable(int on) {
     g_recs.clear();
     g_pool_used = 0;
     g_host_m_used = 0;
+    g_depth = 0;
     if (on && !g_host_m) {
         g_host_m_cap = 1 << 16;
         CONE_CHECK_HIP(hipHostMalloc((void**)&g_host_m, sizeof(int) * g_host_m_cap, hipHostMallocDefault));
