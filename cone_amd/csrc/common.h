@@ -112,6 +112,7 @@ struct GemmArgs {
     float* C; int ldc;
     float* C2; const float* ADD;          // optional second output C2 = C + ADD (same ldc), row tile only
     int M; const int* M_dev;              // rows; *M_dev wins when non-null (grid sized by M)
+    int m_off;                            // the rows are rows m_off .. m_off + M of a larger job: *M_dev and r_mod count from its row 0
     int N, K;
     int flags;
     int variant;                          // tile family: 0 automatic (GEMM_ROWS8 where the shape allows), else forced

@@ -624,7 +624,7 @@ static size_t rs_lds_bytes(int K) {
 __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int M = p.M;
-    if (p.M_dev) { int md = *p.M_dev; M = md < M ? md : M; }
+    if (p.M_dev) { int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
     const int m0 = blockIdx.x * 16, n0 = blockIdx.y * RT_BN;
     if (m0 >= M) return;
     const int K = p.K, nk = K / 16;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {                                 // wave w walks rows 2w, 2w + 1
         const size_t m = (size_t)min(m0 + 2 * wave + k, M - 1);
-        if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? m % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
+        if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(p.R + (p.r_mod ? (m + (size_t)p.m_off) % (size_t)p.r_mod : m) * p.ldr + n0 + c4);
         v[k] = *reinterpret_cast<const float4*>(ep + (2 * wave + k) * RS_EP_LD + c4);
     }
 #pragma unroll
@@ -730,6 +730,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
 #define CONE_RS_MAX_WGS 1280
 #endif
 constexpr int RS_MAX_WGS = CONE_RS_MAX_WGS;
+// Two 128-row tiles on one CU run at about half speed each, so a launch of a few tiles more than a multiple of the CU count
+// (258 tiles for the 33 000 context rows of a MAD-length video: 134 us against 80 us for 256) waits for the CUs that hold two.
+// Up to this many small-form tiles of rows past the last full round are launched as the small form instead (same bits).
+#ifndef CONE_RS_SPLIT_WGS
+#define CONE_RS_SPLIT_WGS 256
+#endif
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
@@ -757,9 +763,28 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                 rc = hipFuncSetAttribute((const void*)gemm_rows_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return rc;
         }));
+        int n_cu = 0;
+        CONE_CHECK_HIP(device_once(once, [] { return hipSuccess; }, &n_cu));
         const bool waves8 = a.variant != GEMM_ROWS4;
-        if (waves8 && !a.C2 && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS && a.variant == GEMM_AUTO &&
-            rs_lds_bytes(a.K) <= 160 * 1024) {
+        const bool small_ok = waves8 && !a.C2 && a.variant == GEMM_AUTO && rs_lds_bytes(a.K) <= 160 * 1024;
+        if (small_ok && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) > RS_MAX_WGS && a.m_off == 0) {
+            const int nc = a.N / RT_BN;
+            const int64_t G = (int64_t)((a.M + RT_BM - 1) / RT_BM) * nc;
+            const int64_t m1 = G / n_cu * n_cu / nc * RT_BM;          // rows of the full rounds of 128-row tiles
+            const int64_t rem = a.M - m1;
+            if (m1 > 0 && rem > 0 && (rem + 15) / 16 * nc <= CONE_RS_SPLIT_WGS) {
+                ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);     // one record for the two launches
+                GemmArgs h = a;
+                h.M = (int)m1;
+                h.variant = GEMM_ROWS8;                               // (the full rounds: no further split)
+                if (int rc = launch_gemm(h, s)) return rc;
+                GemmArgs t = a;
+                t.A = a.A + (size_t)m1 * a.lda; t.C = a.C + (size_t)m1 * a.ldc; t.M = (int)rem; t.m_off = (int)m1;
+                if (a.R && !a.r_mod) t.R = a.R + (size_t)m1 * a.ldr;
+                return launch_gemm(t, s);
+            }
+        }
+        if (small_ok && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS) {
             // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)
             ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);
             hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(512),

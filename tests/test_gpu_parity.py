@@ -181,11 +181,15 @@ def test_fused_ffn_matches_float64(M, ff):
 
 
 @pytest.mark.parametrize("M,N,K,flags", [(100, 256, 256, 0), (777, 768, 256, 1), (37, 256, 1024, 2 | 4), (4096, 512, 256, 2),
-                                         (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0)])
+                                         (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0),
+                                         (20_000, 256, 256, 2 | 4), (33_000, 256, 512, 1 | 2), (33_000, 768, 256, 2),
+                                         (100_000, 256, 256, 1 | 2 | 4)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
-    """gemm.hip: launches of at most 512 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel) instead of one
-    128 x 256 tile per 128 rows; same fma chains, same per-row epilogue -- the same bits as the 128-row tile (forced here
-    with the tile-family test hook), so a row's result does not depend on the size of the batch it is computed in."""
+    """gemm.hip: launches of at most 1 280 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel)
+    instead of one 128 x 256 tile per 128 rows, and the rows past the last full round of 128-row tiles (33 000 rows = 258
+    tiles on 256 CUs; 100 000 = 782) are launched as that small form too; same fma chains, same per-row epilogue -- the same
+    bits as the 128-row tile (forced here with the tile-family test hook), so a row's result does not depend on the size of
+    the batch it is computed in."""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(M * 7 + N + K + flags)
@@ -231,6 +235,18 @@ def test_fused_tail_small_m_form_is_bit_identical(ff):
     _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(big2), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
                                       P(big2), M, ff, _lib.stream()))
     # 1 .. 12 288 rows: the wide form (one ragged group; one, two, three rounds of 256 groups); 12 500, 16 000: 4 waves
+    # 40 000 rows = 313 tiles: one full round of the 8-wave form on rows 0 .. 32 767, the other 7 232 rows by the wide form;
+    # 60 000 rows: 213 tiles past the full round are too many to hand over -- the 8-wave form for all of them
+    M6 = 60_000
+    X6, A6 = torch.cat([X, X[:M6 - M] * 0.5]), torch.cat([A, A[:M6 - M] * 0.5])
+    big6 = torch.empty(M6, 256, device=dev)
+    _lib.check(lib.cone_test_ffn(P(X6), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(big6), M6, ff, _lib.stream()))
+    assert torch.equal(big6[:M], big)
+    big6 = X6.clone()
+    _lib.check(lib.cone_test_proj_ffn(P(A6), P(Wo), P(bo), P(big6), P(pg), P(pb), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb),
+                                      P(big6), M6, ff, _lib.stream()))
+    assert torch.equal(big6[:M], big2)
+    del X6, A6, big6
     for m in (1, 37, 3000, 4096, 4100, 12_288, 12_500, 16_000):
         small = torch.empty(m, 256, device=dev)
         _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(small), m, ff, _lib.stream()))

@@ -27,13 +27,12 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 1).items()})
     ann, vf, qf = synth.make_dataset(opt, args.queries, 1, seed=0, ctx_range=(args.ctx_l, args.ctx_l + 1))
     store = inf.FeatureStore(opt, ann, vf, qf)
-    for _ in range(2):
-        dp = inf.device_pipeline(model, store, opt)
+    for _ in range(3):
+        out, dp = inf.predict_split(model, store, opt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dp = inf.device_pipeline(model, store, opt)
-        out = inf.format_results(store.ann, opt, dp["rows"], dp["n"])
+        out, dp = inf.predict_split(model, store, opt)       # the call bench.py's config5 times
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"MAD-length video: ctx_l={args.ctx_l}, d=512, window_len=125, {args.queries} queries, "
