@@ -251,6 +251,15 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
         out[f"q{nq}"] = {"queries": nq, "ms_per_call": round(dt * 1e3, 3), "windows_per_s": round(nw * nq / dt, 1),
                          "frame_score_kernel_ms": round(k_ms, 3), "kernel": kernel, "roofline": roof,
                          "path_frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        if nq >= 8:
+            # the same launch against the OTHER roof: 2 * Q * ctx_l * dv exact-fp32 FLOPs over 4 * ctx_l * dv bytes = Q / 2
+            # FLOP per byte; the ridge of this part is 157.3 TFLOP/s / 8 TB/s = 19.7, so from 40 queries on the contraction,
+            # not the stream, is what bounds the kernel (and `roofline.frac` above cannot approach 1)
+            fl = 2.0 * nq * ctx_l * dv
+            out[f"q{nq}"]["roofline_mfma"] = {
+                "bound": "mfma", "achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "flop_per_byte": round(fl / alg, 1), "ridge_flop_per_byte": round(FP32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1)}
         del txt
     del vid
     torch.cuda.empty_cache()
