@@ -888,7 +888,8 @@ extern "C" int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_v
     AttnSrc a{};
     a.Q = QKV; a.K = QKV ? QKV + 256 : nullptr; a.V = QKV ? QKV + 512 : nullptr; a.ldq = a.ldk = a.ldv = 768;
     a.qkv_vid = qkv_vid; a.qkv_txt = qkv_txt; a.pos_qk = pos_qk; a.vrow0 = vrow0; a.vlen = vlen; a.trow0 = trow0;
-    return launch_enc_attn(mode, a, OUT, off, B, Lmax, (hipStream_t)stream);
+    a.form = (mode >> 8) & 3;                     // mode | 0x200: the wave-per-(window, head) form (enc_attn_wave_kernel)
+    return launch_enc_attn(mode & 0xff, a, OUT, off, B, Lmax, (hipStream_t)stream);
 }
 extern "C" int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen,
                                    const int32_t* off, const float* Wk, const float* WvT, const float* bv, float* OUT,

@@ -181,10 +181,176 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// enc_attn_wave_kernel: ONE WAVE per (window, head), the head's K and V resident in REGISTERS, no LDS, no barrier -- a second,
+// independent formulation of the same arithmetic (same MFMA operand assignment, same order of every sum: IDENTICAL BITS, which
+// tests/test_gpu_parity.py asserts), kept as a cross-check and as the record of what bounds this kernel.  A wave loads its
+// head's keys once as the A operand of S^T (lane = key, 8 registers per key tile) and its values once as the B operand of P.V
+// (lane = channel, 8 registers per key tile), then walks the window's query tiles: 16 NKT MFMAs per tile back to back, the row
+// softmax in registers in between.  20 NKT + ~50 VGPRs: two waves per SIMD up to NKT = 9.
+//
+// Measured (tools/attn_bench.py, 20 000 windows; every variant verified bit-identical): this form 2.72 / 2.97 / 3.13 ms (packed /
+// gather / pos-add) against 2.71 / 2.83 / 2.94 of enc_attn16_kernel; persistent workgroups, the second wave of a SIMD started
+// half an item late, the S^T MFMAs of tile i + 1 interleaved with the softmax of tile i (sched_group_barrier), the eight waves
+// in lockstep phases: 2.67 - 2.9, 2.75, 2.75, 3.4 ms.  With every load served from cache and no store: 2.59 ms; one wave per
+// SIMD instead of two: 2.85 ms.  The parts ADD: 1.0 ms of loads + 0.65 of softmax / stores + 1.1 of MFMA.  Why -- tools/probe/
+// mfma_valu_overlap.hip: v_mfma_f32_16x16x4_f32 issues every 33 cycles alone, every 44 / 46 / 54 / 63 cycles with 2 / 4 / 8 / 12
+// independent v_fma_f32 behind each MFMA in the same wave, and a VALU-only partner wave on the SIMD slows an MFMA-only wave the
+// same way (54 / 67 / 76 cycles per MFMA at 4 / 8 / 12 VALU per MFMA): the exact-fp32 matrix instruction runs at the fp32
+// VECTOR rate (64 FLOP / clock / SIMD) and vector work does not hide under it, from the same wave or from another.  The
+// kernel's floor is therefore its MFMA time PLUS its vector time: 784 MFMAs x 32 cycles + ~1 900 vector instructions per
+// (window, head) = 25 k + >= 6 k cycles per SIMD = 2.2 ms at the 2.1 GHz the chip holds here; both forms sit at 2.7.
+template <int NKT, int MODE>
+__global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float* __restrict__ OUT,
+                                                               const int* __restrict__ off) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int head = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t0 = off[b];
+    const int L = off[b + 1] - t0;
+    const int li = lane & 15, lg = lane >> 4;
+    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
+    if (MODE != ATTN_PACKED) { lv = a.vlen[b]; pbase = lv * (lv - 1) / 2; }
+    if (MODE == ATTN_GATHER) { vr0 = a.vrow0[b]; tr0 = a.trow0[b]; }
+    auto rows_of = [&](int tok, const float*& q, const float*& k, const float*& v, const float*& add) {
+        add = (MODE != ATTN_PACKED && tok < lv) ? a.pos_qk + (size_t)(pbase + tok) * 512 : nullptr;
+        if (MODE == ATTN_GATHER) {
+            const float* r = tok < lv ? a.qkv_vid + (size_t)(vr0 + tok) * 768 : a.qkv_txt + (size_t)(tr0 + tok - lv) * 768;
+            q = r; k = r + 256; v = r + 512;
+        } else {
+            q = a.Q + (size_t)(t0 + tok) * a.ldq; k = a.K + (size_t)(t0 + tok) * a.ldk; v = a.V + (size_t)(t0 + tok) * a.ldv;
+        }
+    };
+    const int hc = head * 32;
+    // query values of a tile: 8 per lane (query = li, channels 8 lg ..), position row added for clip tokens, scaled
+    float4 qx[2], qt[2];
+    bool q_add = false;
+    auto load_q = [&](int q0) {
+        int qrow = q0 + li;
+        qrow = qrow < L ? qrow : L - 1;
+        const float *qp, *kp_, *vp_, *qadd;
+        rows_of(qrow, qp, kp_, vp_, qadd);
+        qp += hc + 8 * lg;
+        q_add = MODE != ATTN_PACKED && qadd != nullptr;
+        const float* ap = q_add ? qadd + hc + 8 * lg : qp;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            qx[u] = reinterpret_cast<const float4*>(qp)[u];
+            if (MODE != ATTN_PACKED) qt[u] = reinterpret_cast<const float4*>(ap)[u];
+        }
+    };
+    load_q(0);
+    // keys: kreg[kt][st] = K[key 16 kt + li][8 lg + st] (zero past the window)
+    float kreg[NKT][8];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int key = 16 * kt + li;
+        const bool ok = key < L;
+        const float *qp, *kp_, *vp_, *add;
+        rows_of(ok ? key : L - 1, qp, kp_, vp_, add);
+        const bool k_add = MODE != ATTN_PACKED && add != nullptr;
+        const float4* kp4 = reinterpret_cast<const float4*>(kp_ + hc + 8 * lg);
+        const float4* ap4 = reinterpret_cast<const float4*>((k_add ? add + 256 : kp_) + hc + 8 * lg);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 k4 = kp4[u];
+            if (MODE != ATTN_PACKED) {
+                const float4 t4 = ap4[u];
+                if (k_add) { k4.x += t4.x; k4.y += t4.y; k4.z += t4.z; k4.w += t4.w; }
+            }
+            if (!ok) k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            kreg[kt][4 * u] = k4.x; kreg[kt][4 * u + 1] = k4.y; kreg[kt][4 * u + 2] = k4.z; kreg[kt][4 * u + 3] = k4.w;
+        }
+    }
+    // values: vreg[kt][r][dt] = V[key 16 kt + 4 lg + r][16 dt + li] (zero past the window)
+    float vreg[NKT][4][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * lg + r;
+            const bool ok = key < L;
+            const float *qp, *kp_, *vp_, *add;
+            rows_of(ok ? key : L - 1, qp, kp_, vp_, add);
+            const float v0 = vp_[hc + li], v1 = vp_[hc + 16 + li];
+            vreg[kt][r][0] = ok ? v0 : 0.f;
+            vreg[kt][r][1] = ok ? v1 : 0.f;
+        }
+    const int lim = L - 4 * lg;                     // key 16 kt + 4 lg + r is real iff 16 kt + r < lim
+    for (int q0 = 0; q0 < L; q0 += 16) {
+        float qv[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 x = qx[u];
+            if (MODE != ATTN_PACKED && q_add) { x.x += qt[u].x; x.y += qt[u].y; x.z += qt[u].z; x.w += qt[u].w; }
+            qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
+            qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+        }
+        load_q(q0 + 16 < L ? q0 + 16 : q0);         // the next tile's query rows under this tile's MFMAs
+        f32x4m sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) sc[kt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][st], qv[st], sc[kt], 0, 0, 0);
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] = (16 * kt + r < lim) ? sc[kt][r] : -INFINITY;
+                m = fmaxf(m, sc[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m2 = m * 1.4426950408889634f;
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
+                sc[kt][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = sc[kt][r] * inv;
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vreg[kt][r][0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vreg[kt][r][1], o1, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = q0 + 4 * lg + r;
+            if (qrow < L) {
+                float* dst = OUT + (size_t)(t0 + qrow) * 256 + hc + li;
+                dst[0] = o0[r];
+                dst[16] = o1[r];
+            }
+        }
+    }
+}
+
 template <int MODE>
 static int launch_enc_attn_t(const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
-    dim3 grid(8, B);
     const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
+    if (a.form == 2 && nkt <= 9) {                // the register-resident cross-check form (same bits), on request
+        dim3 wgrid(2, B);
+#define CONE_ATTNW(N) case N: hipLaunchKernelGGL((enc_attn_wave_kernel<N, MODE>), wgrid, dim3(256), 0, s, a, OUT, off); break;
+        switch (nkt) { CONE_ATTNW(6) CONE_ATTNW(7) CONE_ATTNW(8) CONE_ATTNW(9) }
+#undef CONE_ATTNW
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
+    dim3 grid(8, B);
 #define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, MODE>), grid, dim3(64 * N), 0, s, a, OUT, off); break;
     switch (nkt) {
         CONE_ATTN16(6)

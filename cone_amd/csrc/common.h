@@ -204,6 +204,7 @@ struct AttnSrc {
     const float* Q; const float* K; const float* V; int ldq, ldk, ldv;
     const float* qkv_vid; const float* qkv_txt; const float* pos_qk;    // pos_qk (R, 512), row lv (lv - 1) / 2 + p
     const int* vrow0; const int* vlen; const int* trow0;
+    int form;                                     // 0: the workgroup-per-(window, head) kernel; 2: one wave per (window, head), K / V in registers (same bits; <= 144 tokens)
 };
 int launch_enc_attn(int mode, const AttnSrc& src, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
 int launch_tile_rows(float* x, int period, int64_t n_rows, hipStream_t s);

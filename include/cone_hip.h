@@ -376,7 +376,9 @@ int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, c
 /* Encoder self-attention core (cone/transformer.py:239, 8 heads x 32) over windows of packed tokens off[b] .. off[b+1]:
  * mode 0: QKV (M, 768) = q | k | v rows that already carry the position term; mode 2: the same without it, the kernel adds
  * pos_qk[(vlen[b], p)] (R, 512) to q | k of clip token p; mode 1: q | k | v gathered from per-clip rows qkv_vid[vrow0[b] + p]
- * and per-text-token rows qkv_txt[trow0[b] + t] (+ the pos_qk row for clips).  OUT (M, 256) ahead of out_proj. */
+ * and per-text-token rows qkv_txt[trow0[b] + t] (+ the pos_qk row for clips).  OUT (M, 256) ahead of out_proj.
+ * mode | 0x200 (windows of <= 144 tokens) runs the second formulation -- one wave per (window, head), K / V resident in
+ * registers, no LDS: the same bits as the default workgroup-per-(window, head) kernel. */
 int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt, const float* pos_qk,
                        const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0, const int32_t* off, float* OUT,
                        int B, int Lmax, void* stream);

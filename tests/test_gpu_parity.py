@@ -1727,6 +1727,42 @@ def test_fused_decoder_cross_attention_matches_float64(variant, shared):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
+def test_encoder_attention_wave_form_is_bit_identical(mode):
+    """attention.hip holds two independent formulations of the encoder attention core: a workgroup per (window, head) with
+    K / V staged in LDS and one wave per query tile (the product path), and one wave per (window, head) with K / V resident in
+    registers (mode | 0x200).  Same MFMA operand assignment, same order of every sum: the outputs must be equal bit for bit,
+    on ragged windows up to the 144 tokens the register form holds (1 token, text only, clips only, 16-multiples)."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(23 + mode)
+    vl = [90, 1, 0, 48, 90, 17, 119, 64, 16, 101]
+    tl = [20, 0, 9, 0, 6, 3, 25, 32, 0, 11]
+    B = len(vl)
+    L = [a + b for a, b in zip(vl, tl)]
+    off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
+    M = int(off[-1])
+    Wmax = 125
+    d = lambda t: t.to(dev).contiguous()
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    pos = d(torch.randn(Wmax * (Wmax + 1) // 2, 512, generator=g))
+    qkv_vid, qkv_txt = d(torch.randn(400, 768, generator=g)), d(torch.randn(120, 768, generator=g))
+    vr, tr = i32([0, 399, 5, 100, 200, 30, 250, 7, 120, 299]), i32([0, 50, 100, 0, 30, 117, 60, 80, 10, 40])
+    QKV = d(torch.randn(M, 768, generator=g))
+    vlv, offd = i32(vl), torch.from_numpy(off).to(dev)
+    lib = _lib.load()
+    outs = []
+    for form in (0, 0x200):
+        out = torch.full((M + 1, 256), float("nan"), device=dev)
+        _lib.check(lib.cone_test_enc_attn(mode | form, _lib.ptr(QKV), _lib.ptr(qkv_vid), _lib.ptr(qkv_txt), _lib.ptr(pos),
+                                          _lib.ptr(vr), _lib.ptr(vlv), _lib.ptr(tr), _lib.ptr(offd), _lib.ptr(out), B, max(L),
+                                          _lib.stream()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0][:M]).any() and bool(torch.isnan(outs[1][M:]).all())
+    assert torch.equal(outs[0][:M], outs[1][:M])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_encoder_attention_kernel_matches_float64(mode):
     """attention.hip called directly in its three source modes (packed q|k|v; gathered from the per-clip / per-token
     layer-0 caches + position table; packed + position table) against softmax(q k^T / sqrt(32)) v per head in float64, on

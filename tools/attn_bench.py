@@ -38,7 +38,12 @@ def run(mode):
 
 
 flops = float((4.0 * L.double() ** 2 * 256).sum())
-for name, mode in (("packed", 0), ("gather", 1), ("pos-add", 2), ("packed", 0), ("gather", 1), ("pos-add", 2)):
+ref = {}
+CASES = (("packed", 0), ("gather", 1), ("pos-add", 2), ("packed/wave", 0x200), ("gather/wave", 0x201), ("pos-add/wave", 0x202),
+         ("packed", 0), ("gather", 1), ("pos-add", 2))
+if os.environ.get("ATTN_CASES"):                  # e.g. ATTN_CASES=0,2,256
+    CASES = tuple((f"mode {int(c):#x}", int(c)) for c in os.environ["ATTN_CASES"].split(","))
+for name, mode in CASES:
     for _ in range(2):
         run(mode)
     torch.cuda.synchronize()
@@ -49,4 +54,8 @@ for name, mode in (("packed", 0), ("gather", 1), ("pos-add", 2), ("packed", 0), 
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{name:8s} B={B} M={M}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s algorithmic")
+    same = ""
+    if mode & 0xff in ref:
+        same = "  same bits as the other form" if torch.equal(ref[mode & 0xff], OUT) else "  DIFFERENT from the other form"
+    ref.setdefault(mode & 0xff, OUT.clone())
+    print(f"{name:10s} B={B} M={M}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s algorithmic{same}")
