@@ -42,6 +42,14 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_
     -d $out/pmc_mfma_pf -o m -- $P > $out/pmc_mfma_pf.log 2>&1
 python3 tools/pmc_summary.py $out $out/${tag}_pmc_prefilter _pf > $out/${tag}_pmc_prefilter.log 2>&1
 tail -8 $out/${tag}_pmc_prefilter.log
+# (6) instruction counts by class + MFMA / vector co-execution over the step: the issue-time model (tools/pmc_issue.py)
+rm -rf $out/pmc_inst $out/pmc_coexec
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM \
+    --output-format csv -d $out/pmc_inst -o i -- $B > $out/pmc_inst.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
+    --output-format csv -d $out/pmc_coexec -o c -- $B > $out/pmc_coexec.log 2>&1
+python3 tools/pmc_issue.py $out $out/${tag}_pmc_issue.csv > $out/${tag}_pmc_issue.log 2>&1
+cat $out/${tag}_pmc_issue.log
 # the bench line last: roofline.traffic is read from profiles/<tag>_pmc_*.json of THIS collection
 cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv $out/${tag}_pmc_prefilter.json $out/${tag}_pmc_prefilter_counters.csv profiles/
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
@@ -50,4 +58,4 @@ cat $out/${tag}_bench_line.json
 mkdir -p $out/${tag}_profiles
 cp $out/${tag}_*.csv $out/${tag}_*.json $out/${tag}_step_gaps.txt $out/${tag}_profiles/ 2>/dev/null
 rm -rf $out/prof_$tag $out/prof_${tag}_step $out/prof_${tag}_split $out/pmc_fetch $out/pmc_write $out/pmc_mfma \
-       $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf
+       $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf $out/pmc_inst $out/pmc_coexec
