@@ -183,13 +183,14 @@ def test_fused_ffn_matches_float64(M, ff):
 @pytest.mark.parametrize("M,N,K,flags", [(100, 256, 256, 0), (777, 768, 256, 1), (37, 256, 1024, 2 | 4), (4096, 512, 256, 2),
                                          (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0),
                                          (20_000, 256, 256, 2 | 4), (33_000, 256, 512, 1 | 2), (33_000, 768, 256, 2),
-                                         (100_000, 256, 256, 1 | 2 | 4)])
+                                         (100_000, 256, 256, 1 | 2 | 4), (64, 256, 2048, 1), (300, 512, 1536, 2)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     """gemm.hip: launches of at most 1 280 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel)
     instead of one 128 x 256 tile per 128 rows, and the rows past the last full round of 128-row tiles (33 000 rows = 258
     tiles on 256 CUs; 100 000 = 782) are launched as that small form too; same fma chains, same per-row epilogue -- the same
     bits as the 128-row tile (forced here with the tile-family test hook), so a row's result does not depend on the size of
-    the batch it is computed in."""
+    the batch it is computed in.  (K = 2 048: the staged activation slabs would not fit the LDS -- the launcher keeps the
+    128-row tile; K = 1 536: they fit with one workgroup per CU.)"""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(M * 7 + N + K + flags)
@@ -208,14 +209,15 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("ff", [1024, 384])
+@pytest.mark.parametrize("ff", [1024, 384, 2048])
 def test_fused_tail_small_m_form_is_bit_identical(ff):
     """The fused layer tail has three forms: 128-row tiles on 8 waves, 64-row tiles on 4 waves (one per SIMD: half the
     time per tile, twice the grid) when the 128-row tiles would leave half of the CUs idle, and -- for at most
     CONE_FFN_WIDE_GROUPS = 768 groups of 16 rows -- the wide form of ffn_wide.hip (one workgroup per 16 rows, its waves
     sharing the block's OUTPUT elements).  Every output element goes through the same fma chain in all three, so a row's
     result must not depend on which form -- i.e. on how many rows -- it was computed with.  (ff = 384: an odd number of
-    chunk groups per wave in the wide form.)"""
+    chunk groups per wave in the wide form; ff = 2 048: the wide form's hidden tile does not fit the LDS -- the launcher keeps
+    the row-owning forms at every size.)"""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(11)
