@@ -407,12 +407,13 @@ def main():
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--pipeline_chunks", type=int, default=None,
-                    help="query chunks of the host/GPU software pipeline (default: automatic = 1 at this size)")
+                    help="query chunks of the host/GPU software pipeline (default: automatic, see --pipeline_tail)")
     ap.add_argument("--set_option", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostics: flip an A/B switch of the model handle (cone_model_set_option), e.g. pos_tables=0")
     ap.add_argument("--window_batch", type=int, default=32768)
     ap.add_argument("--pipeline_tail", type=float, default=None,
-                    help="fraction of the queries in the tail chunk of the host/GPU pipeline (default: none = one chunk)")
+                    help="fraction of the queries in the tail chunk of the host/GPU pipeline (default: automatic = 1/16 from 32 "
+                         "reference batches on, i.e. at this size; 0 = one chunk)")
     ap.add_argument("--need_saliency", action="store_true",
                     help="A/B: the headline step also runs the saliency head and the intermediate decoder layers' heads "
                          "(the reference computes them and never reads them); the default line reports that figure as "
@@ -524,6 +525,7 @@ def main():
                                    f"{args.queries} queries x {args.videos} videos per GPU, window_len=90, d=256, "
                                    f"topk_window=20, NMS 0.5, {n_windows} windows per GPU per step",
                        "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture",
+                       "query_chunks": [list(c) for c in dp.get("chunks", [(0, args.queries)])],
                        "outputs": "per window pred_logits, pred_spans, matching scores -> rows [st, ed, proposal, "
                                   "matching]; per query fused / proposal / matching top-5 after NMS as JSON rows"
                                   + ("; saliency head and the intermediate decoder layer's heads (aux_outputs) computed too"
@@ -565,11 +567,15 @@ def main():
     # ---- the reference's full CONE.forward in the eval path (cone/model.py:112-127): saliency_scores + aux_outputs too
     if not args.need_saliency and not args.no_extras:
         def full_forward():
-            opt.need_saliency = opt.need_aux = True
+            tail0 = opt.pipeline_tail
+            if tail0 is None and len(inf.query_chunks(args.queries, opt)) > 1:
+                opt.pipeline_tail = 1.0 / 16.0      # the headline's automatic chunking (a caller who wants the per-window
+            opt.need_saliency = opt.need_aux = True  # outputs of the whole split gets one chunk by default; the bench does not)
             try:
                 fdt, _, (_, fdp) = timed_region(step)
             finally:
                 opt.need_saliency = opt.need_aux = False
+                opt.pipeline_tail = tail0
             note("ms_per_step_full_forward", round(fdt / args.steps * 1e3, 2))
             note("value_full_forward", round(world * fdp["n_windows"] * args.steps / fdt, 1))
         guarded("full_forward_error", full_forward)
@@ -579,12 +585,18 @@ def main():
         # each fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation (ffn_split.hip)
         def split_path():
             try:
-                outs = dp.get("outputs")        # (absent when the step ran as several pipeline chunks)
-                ref_out = {k: v.clone() for k, v in outs.items() if k in ("pred_logits", "pred_spans")} if outs else {}
+                def one_chunk_outputs():            # per-window outputs of the whole split: one untimed unchunked step
+                    tail0, opt.pipeline_tail = opt.pipeline_tail, 0.0
+                    try:
+                        return step()[1].get("outputs") or {}
+                    finally:
+                        opt.pipeline_tail = tail0
+                ref_out = {k: v.clone() for k, v in one_chunk_outputs().items() if k in ("pred_logits", "pred_spans")}
                 model.set_option("split_bf16", 1)
                 sdt, srec, (_, sdp) = timed_region(step)
                 sroof, _ = roofline_from_profile(srec)
-                diffs = {k: float((sdp["outputs"][k] - v).abs().max()) for k, v in ref_out.items()} if sdp.get("outputs") else None
+                souts = one_chunk_outputs()
+                diffs = {k: float((souts[k] - v).abs().max()) for k, v in ref_out.items()} if souts else None
                 return {"note": "opt-in model option split_bf16=1 (NOT the headline): fp32 products of the fused layer tails as "
                                 "six bf16 MFMA partial products of three-piece operands (x = xh + xm + xl exactly), fp32 "
                                 "accumulation; error against float64 equal to the fp32 MFMA chain's (tools/probe/"

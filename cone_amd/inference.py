@@ -684,13 +684,21 @@ def query_chunks(nq: int, opt):
     """Query ranges for the software pipeline of predict_split, cut at multiples of eval_bsz (every reference batch
     stays inside one chunk).  ``opt.pipeline_chunks = n``: n near-equal chunks; ``opt.pipeline_tail = f``: one head
     chunk and a tail of fraction f of the queries (the host builds the head's submission rows while the GPU runs
-    the tail).  Default: ONE chunk.  Measured on MI355X (config 2, 20 000 windows, round 2): tails of 1/16, 1/8,
-    1/4 give 60.3 / 60.1 / 60.0 ms per step against 60.1 unchunked -- every extra chunk replays the ~110-launch
-    sequence whose small dependent kernels cost about as much GPU time as the host's list building it hides."""
+    the tail; 0: one chunk).  Default (neither set): a tail of 1/16 for splits of at least 32 reference batches,
+    one chunk otherwise -- and one chunk whenever the caller wants the per-window outputs of the whole split
+    (saliency / aux heads) or the hipGraph replay.  Measured on MI355X (config 2, 1 000 queries = 32 batches,
+    20 000 windows, round 3, one box, 10 steps each): one chunk 54.3 / 54.2 / 54.9 ms per step, tail 1/16 53.9 /
+    53.95 / 54.0, tail 1/32 55.0, tail 3/32 54.4 -- the tail's replay of the launch sequence costs ~0.6 ms of GPU time
+    (small-M kernel forms) and hides ~1.1 ms of list building.  (Round 2, before the small-M forms: no gain.)"""
     nb = -(-nq // opt.eval_bsz)
     want = getattr(opt, "pipeline_chunks", None)
     if want is None:
-        tail = float(getattr(opt, "pipeline_tail", None) or 0.0)
+        tail = getattr(opt, "pipeline_tail", None)
+        if tail is None:
+            whole = (getattr(opt, "hip_graph", False) or getattr(opt, "need_saliency", False)
+                     or getattr(opt, "need_aux", False))
+            tail = 1.0 / 16.0 if nb >= 32 and not whole else 0.0
+        tail = float(tail)
         if tail <= 0 or nb < 8:
             return [(0, nq)]
         tb = max(1, int(round(nb * tail)))

@@ -1207,8 +1207,14 @@ def test_predict_split_pipeline_is_chunk_invariant():
             outs.append(lists)
         assert outs[0] == outs[1] == outs[2]
         assert len(inf.query_chunks(nq, opt)) == 5
+    # default: a 1/16 tail from 32 reference batches on; one chunk for small splits, on request (tail 0), under hipGraph replay
+    # and when the caller wants the per-window outputs of the whole split
     auto = make_opt("ego4d", topk_window=20, eval_bsz=32)
-    assert inf.query_chunks(1000, auto) == [(0, 1000)] and inf.query_chunks(20000, auto) == [(0, 20000)]
+    assert inf.query_chunks(1000, auto) == [(0, 960), (960, 1000)] and inf.query_chunks(20000, auto) == [(0, 18752), (18752, 20000)]
+    assert inf.query_chunks(500, auto) == [(0, 500)]
+    assert inf.query_chunks(1000, make_opt("ego4d", topk_window=20, eval_bsz=32, pipeline_tail=0.0)) == [(0, 1000)]
+    assert inf.query_chunks(1000, make_opt("ego4d", topk_window=20, eval_bsz=32, hip_graph=True)) == [(0, 1000)]
+    assert inf.query_chunks(1000, make_opt("ego4d", topk_window=20, eval_bsz=32, need_saliency=True)) == [(0, 1000)]
     tail = make_opt("ego4d", topk_window=20, eval_bsz=32, pipeline_tail=0.125)
     assert inf.query_chunks(1000, tail) == [(0, 896), (896, 1000)]         # head + 1/8 tail, cut at eval_bsz
     assert inf.query_chunks(100, tail) == [(0, 100)]

@@ -269,3 +269,22 @@ def test_three_piece_bf16_split_is_exact_and_six_products_carry_fp32():
     # two pieces / three products would not do: ~2^-16
     three = xh.double() * wm + xm.double() * wh + xh.double() * wh
     assert float(((three - exact).abs() / exact.abs().clamp_min(1e-300))[exact != 0].max()) > 2.0 ** -18
+
+
+def test_query_chunks_of_the_host_gpu_pipeline():
+    """cone_amd.inference.query_chunks (host logic of predict_split's software pipeline): chunks are cut at multiples of
+    eval_bsz (every reference batch -- hazard H3's padding unit -- stays inside one chunk); default = a 1/16 tail from 32
+    reference batches on, one chunk for smaller splits, on request, under hipGraph replay and when the caller wants the
+    per-window outputs of the whole split."""
+    from cone_amd import inference as inf
+    mk = lambda **kw: make_opt("ego4d", topk_window=20, eval_bsz=32, **kw)
+    assert inf.query_chunks(1000, mk()) == [(0, 960), (960, 1000)]
+    assert inf.query_chunks(20000, mk()) == [(0, 18752), (18752, 20000)]
+    assert inf.query_chunks(500, mk()) == [(0, 500)]
+    for kw in (dict(pipeline_tail=0.0), dict(hip_graph=True), dict(need_saliency=True), dict(need_aux=True)):
+        assert inf.query_chunks(1000, mk(**kw)) == [(0, 1000)], kw
+    assert inf.query_chunks(1000, mk(pipeline_tail=0.125)) == [(0, 896), (896, 1000)]
+    assert inf.query_chunks(100, mk(pipeline_tail=0.125)) == [(0, 100)]
+    five = inf.query_chunks(41, make_opt("ego4d", topk_window=6, eval_bsz=4, pipeline_chunks=5))
+    assert len(five) == 5 and five[0][0] == 0 and five[-1][1] == 41
+    assert all(a % 4 == 0 for a, _ in five) and all(b == five[i + 1][0] for i, (_, b) in enumerate(five[:-1]))
