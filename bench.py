@@ -152,8 +152,12 @@ def roofline_from_profile(rec):
         # algorithmic HBM bytes of a fused layer tail over M rows: its (M, 256) fp32 input rows (kind 9: attention rows +
         # residual rows), the (M, 256) output rows; the weights (<= 1.3 MB) are served by the L2 / Infinity Cache
         rows_io = 3 if dom == 9 else 2
-        alg = rows_io * 1024.0 * sum(a for kind, a, b, c, ms in rec if int(kind) == dom) / d["launches"]
+        # per launch of THAT kernel, like `traffic`: records of at most 12 288 rows (768 groups of 16) ran as the wide form
+        # (ffn_wide_kernel, its own row in the PMC table), not as a launch of the dominant kernel
+        big = [a for kind, a, b, c, ms in rec if int(kind) == dom and a > 12288]
+        alg = rows_io * 1024.0 * sum(big) / max(1, len(big))
         roof["algorithmic_bytes"] = round(alg)
+        roof["algorithmic_bytes_launches"] = len(big)
         if roof.get("traffic"):
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 3)
     shapes = {}
