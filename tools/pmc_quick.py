@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""MFMA-busy % and effective clock of the attention kernels from ONE rocprofv3 PMC pass over tools/attn_bench.py:
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d /tmp/pm -o m -- python3 tools/attn_bench.py 20000 3
+    python3 tools/pmc_quick.py /tmp/pm/.../m_counter_collection.csv"""
 import csv, sys
 from collections import defaultdict
 per = defaultdict(lambda: defaultdict(list))
