@@ -209,15 +209,16 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("ff", [1024, 384, 2048])
+@pytest.mark.parametrize("ff", [1024, 384, 2048, 128])
 def test_fused_tail_small_m_form_is_bit_identical(ff):
     """The fused layer tail has three forms: 128-row tiles on 8 waves, 64-row tiles on 4 waves (one per SIMD: half the
     time per tile, twice the grid) when the 128-row tiles would leave half of the CUs idle, and -- for at most
     CONE_FFN_WIDE_GROUPS = 768 groups of 16 rows -- the wide form of ffn_wide.hip (one workgroup per 16 rows, its waves
     sharing the block's OUTPUT elements).  Every output element goes through the same fma chain in all three, so a row's
     result must not depend on which form -- i.e. on how many rows -- it was computed with.  (ff = 384: an odd number of
-    chunk groups per wave in the wide form; ff = 2 048: the wide form's hidden tile does not fit the LDS -- the launcher keeps
-    the row-owning forms at every size.)"""
+    chunk groups per wave in the wide form; ff = 128: one hidden chunk per wave -- the weight ring runs from the first layer's
+    slabs straight into the second's; ff = 2 048: the wide form's hidden tile does not fit the LDS -- the launcher keeps the
+    row-owning forms at every size.)"""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(11)
