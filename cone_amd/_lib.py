@@ -216,5 +216,11 @@ def ptr(t, dtype=None):
 
 
 def stream():
+    """The current HIP stream of the current device as a void*.  (The raw-stream getter is what torch's own compiled
+    code paths call; it skips the Stream object that torch.cuda.current_stream() builds on every call -- the front of a
+    step is ~30 launches issued while the GPU waits for the host.)"""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
