@@ -2,6 +2,7 @@
 """Benchmark of the CONE coarse-to-fine inference hot path on MI355X.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1         # starts its own 8 ranks (torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -21,8 +22,10 @@ rows of all shards are all-gathered over RCCL.  Extra objects on the same line:
                        sharded along ctx_l, window model sharded by window;
   * `shard_proxy_8` (N = 1) -- rank 0's share of the 8-rank window-sharded split replayed on one GPU (no collective)
                        and the strong-scaling efficiency it projects;
-  * `ms_per_step_full_forward` -- the headline step with the saliency head and the intermediate decoder layer's heads
-                       computed too, as the reference's CONE.forward does (and never reads);
+  * `ms_per_step_dead_work_elided` -- the headline step WITHOUT the saliency head and the intermediate decoder layer's heads
+                       (the headline computes both, as the reference's CONE.forward does -- and never reads them);
+  * `config2_ragged` (N = 1) -- the headline workload on a ragged split (ctx_l ~ U[200, 1500)): per-window cost against the
+                       dense split's, on the same sync-free path;
   * `prefilter_mad`, `latency_config1`, `config5` (N = 1) -- BASELINE configs[2], [0] and [4] on one GPU: the
                        MAD-scale pre-filter against the HBM roofline (1 and 64 queries), the single-query latency,
                        64 queries x one MAD-length video end to end;
@@ -51,22 +54,38 @@ HBM_PEAK_GBS = 8000.0           # same guide: HBM3E peak BW (spec); 6.29 TB/s me
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn16_kernel", 4: "frame_score_kernel",
                 5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_mfma_kernel", 8: "ffn_fused_kernel<false, false, 8>",
-                9: "ffn_fused_kernel<true, false, 8>"}
-GEMM_KINDS = (0, 1, 2, 5, 6, 8, 9)   # records (kind, M, N, K, ms): 2*M*N*K FLOPs; kinds 8 / 9 (N = ff, K = 256): the
-#                                      feed-forward block = two such GEMMs, kind 9 + the 256 x 256 output projection
+                9: "ffn_fused_kernel<true, false, 8>", 10: "ffn_wide_kernel<false>", 11: "ffn_wide_kernel<true>",
+                12: "ffn_fused_kernel<false, false, 4>", 13: "ffn_fused_kernel<true, false, 4>", 14: "gemm_rows_small_kernel"}
+# one kind per KERNEL (include/cone_hip.h, cone_prof_collect): a record is one launch of that kernel and its own rows
+GEMM_KINDS = (0, 1, 2, 5, 6, 8, 9, 10, 11, 12, 13, 14)   # records (kind, M, N, K, ms): 2*M*N*K FLOPs; the layer-tail kinds
+#                                      (N = ff, K = 256): the feed-forward block = two such GEMMs, + the 256 x 256 output
+#                                      projection for the kinds that start at the attention output
+FFN_KINDS, FFN_PROJ_KINDS = (8, 9, 10, 11, 12, 13), (9, 11, 13)
+# where each priced kernel is defined: the committed counter tables carry the hashes of these sources (tools/pmc_summary.py)
+KERNEL_SOURCES = {"ffn_fused_kernel": ("ffn.hip", "common.h"), "frame_score_kernel": ("prefilter.hip", "common.h"),
+                  "frame_score_mq_kernel": ("prefilter.hip", "common.h"), "gemm_rows16_kernel": ("gemm.hip", "common.h"),
+                  "frame_score_mq3_kernel": ("prefilter.hip", "common.h")}
 
 
 def rec_flops(kind, a, b, c):
     f = 2.0 * a * b * c
-    if kind in (8, 9):
+    if kind in FFN_KINDS:
         f *= 2.0
-    if kind == 9:
+    if kind in FFN_PROJ_KINDS:
         f += 2.0 * a * 256 * 256
     return f
 
 
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-PMC_PREFILTER_FILES = ("r03_pmc_prefilter.json",)
+def csrc_hashes():
+    """sha1 of every kernel source (cone_amd/csrc/*.hip, common.h): what a counter table was collected on."""
+    import hashlib
+    d = os.path.join(ROOT, "cone_amd", "csrc")
+    return {f: hashlib.sha1(open(os.path.join(d, f), "rb").read()).hexdigest()[:12]
+            for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".c"))}
+
+
+PMC_FILES = ("r04_pmc_traffic.json",)
+PMC_PREFILTER_FILES = ("r04_pmc_prefilter.json",)
 
 
 def collect_profile():
@@ -98,6 +117,20 @@ def reference_window_flops(lv, lq, dv, dt, d=256, ff=1024, nq=5, enc=2, dec=2):
     return proj + enc_f + dec_f + rest
 
 
+def executed_mfma_flops(rec, lv, lq, opt, steps, d=256, nq=5, heads=8):
+    """FLOPs the MFMA kernels of `steps` steps executed: every dense layer from its launch record (2 M N K with the M the
+    launch processed), the encoder attention cores as 4 L^2 d per window and layer, the folded decoder cross-attention as
+    (fold W_k into the nq x heads queries) + scores + P.memory + W_v per window and layer."""
+    lv, lq = np.asarray(lv, dtype=np.float64), np.asarray(lq, dtype=np.float64)
+    L = lv + lq
+    dense = sum(rec_flops(int(k), a, b, c) for k, a, b, c, ms in rec if int(k) in GEMM_KINDS)
+    hd = d // heads
+    enc = steps * opt.enc_layers * float((4.0 * L * L * d).sum())
+    per_win = 2.0 * nq * heads * hd * d + 2.0 * nq * heads * L * d * 2 + 2.0 * nq * heads * d * hd
+    dec = steps * opt.dec_layers * float(per_win.sum())
+    return {"dense_layers": dense, "encoder_attention": enc, "decoder_cross_attention": dec, "total": dense + enc + dec}
+
+
 def pmc_traffic(kernel, files=PMC_FILES):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/
     rNN_pmc_*.json, written by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE -- the guide's gfx950 read
@@ -113,14 +146,24 @@ def pmc_traffic(kernel, files=PMC_FILES):
         t = tab.get("cone::" + kernel)
         if t is None:       # template arguments may have been added since: same kernel name and first argument
             stem = "cone::" + kernel.split(",")[0].rstrip(">")
-            cands = [v for k, v in tab.items() if k.startswith(stem)]
+            cands = [v for k, v in tab.items() if k.startswith(stem) and isinstance(v, dict)]
             if not cands:
                 continue
             t = max(cands, key=lambda v: v.get("launches", 0))
+        # the table is only this kernel's traffic if it was collected on this kernel's source: the collection stamps the
+        # sha1 of every file under cone_amd/csrc (key "_csrc"); another ffn.hip / prefilter.hip than today's => null
+        stamp, now = tab.get("_csrc") or {}, csrc_hashes()
+        files = KERNEL_SOURCES.get(kernel.split("<")[0], ())
+        stale = [f for f in files if stamp.get(f) != now.get(f)]
+        if not stamp or stale:
+            return {"traffic": None,
+                    "traffic_source": f"profiles/{name} was collected on another revision of "
+                                      f"{', '.join(stale) or 'cone_amd/csrc (no stamp)'}: not this kernel's traffic"}
         return {"traffic": round(t["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                 "traffic_read": round(t["read_bytes_per_launch"]), "traffic_write": round(t["write_bytes_per_launch"]),
                 "traffic_source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; reads = 2 x "
-                                  "FETCH_SIZE, the guide's gfx950 correction)"}
+                                  f"FETCH_SIZE, the guide's gfx950 correction); collected on csrc "
+                                  + " ".join(f"{f}@{stamp[f]}" for f in files)}
     return {"traffic": None}
 
 
@@ -137,19 +180,8 @@ def roofline_from_profile(rec):
     if not per:
         return None, {}
     dom = max(per, key=lambda k: per[k]["ms"])
-    d = per[dom]
-    if dom in (8, 9):
-        # the dominant KERNEL's launches: layer-tail records of at most 12 288 rows (768 groups of 16) ran as the wide form
-        # (ffn_wide_kernel: another kernel, its own rows in profiles/*kernel_stats*.csv and in the PMC tables); they stay in
-        # `kernels` / `all_gemm_tflops`
-        d = dict(ms=0.0, flops=0.0, launches=0)
-        for kind, a, b, c, ms in rec:
-            if int(kind) == dom and a > 12288:
-                d["ms"] += ms
-                d["flops"] += rec_flops(dom, a, b, c)
-                d["launches"] += 1
-        if not d["launches"]:
-            d = per[dom]
+    d = per[dom]        # every record of a kind is one launch of THAT kernel over its own rows (wide / 64-row / small forms
+    #                     have their own kinds): no row-count filter
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     all_ms = sum(v["ms"] for v in per.values())
     all_fl = sum(v["flops"] for v in per.values())
@@ -160,13 +192,11 @@ def roofline_from_profile(rec):
             "flops_per_launch": round(d["flops"] / d["launches"]),
             "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2)}
     roof.update(pmc_traffic(KERNEL_NAMES[dom]))
-    if dom in (8, 9):
-        # algorithmic HBM bytes of a fused layer tail over M rows: its (M, 256) fp32 input rows (kind 9: attention rows +
-        # residual rows), the (M, 256) output rows; the weights (<= 1.3 MB) are served by the L2 / Infinity Cache
-        rows_io = 3 if dom == 9 else 2
-        # per launch of THAT kernel, like `traffic`: records of at most 12 288 rows (768 groups of 16) ran as the wide form
-        # (ffn_wide_kernel, its own row in the PMC table), not as a launch of the dominant kernel
-        big = [a for kind, a, b, c, ms in rec if int(kind) == dom and a > 12288]
+    if dom in FFN_KINDS:
+        # algorithmic HBM bytes of a fused layer tail over M rows: its (M, 256) fp32 input rows (with the projection: attention
+        # rows + residual rows), the (M, 256) output rows; the weights (<= 1.3 MB) are served by the L2 / Infinity Cache
+        rows_io = 3 if dom in FFN_PROJ_KINDS else 2
+        big = [a for kind, a, b, c, ms in rec if int(kind) == dom]        # per launch of THAT kernel, like `traffic`
         alg = rows_io * 1024.0 * sum(big) / max(1, len(big))
         roof["algorithmic_bytes"] = round(alg)
         roof["algorithmic_bytes_launches"] = len(big)
@@ -332,6 +362,37 @@ def bench_config5(ctx_l=33_000, queries=64, steps=10):
             "ms_per_step_split_bf16": None if dts is None else round(dts * 1e3, 3)}
 
 
+def bench_config2_ragged(model, opt, queries, videos, us_per_window_dense, steps=5, warmup=2):
+    """BASELINE configs[1] on a RAGGED split: the same 1 000 queries x 50 videos with ctx_l ~ U[200, 1500) -- videos of fewer
+    than top-20 windows (ctx_l <= 810) next to long ones, as real Ego4D-NLQ clips are.  The shape of the window list is host
+    metadata (cone_amd.inference.Selection), so this split runs the very path of the dense one: one window-table launch, the
+    per-window rows as the candidate lists, two pipeline chunks, no host sync (`sync_free`: the whole step also replays as
+    one hipGraph, which cannot contain one, with the same rows)."""
+    ann, vf, qf = synth.make_dataset(opt, queries, videos, seed=11, ctx_range=(200, 1500))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    sel = inf.selection(store, opt)
+    dt, (lists, dp) = _timed(lambda: inf.predict_split(model, store, opt), steps, warmup)
+    nw = dp["n_windows"]
+    out = {"workload": f"BASELINE.json configs[1], ragged: {queries} queries x {videos} videos, ctx_l ~ U[200, 1500), "
+                       f"window_len=90, d=256, topk_window=20, NMS 0.5: {nw} windows "
+                       f"({int((sel.n_q < sel.K).sum())} queries own fewer than {sel.K})",
+           "ms_per_step": round(dt * 1e3, 3), "n_windows": nw, "windows_per_s": round(nw / dt, 1),
+           "queries_per_s": round(queries / dt, 1), "us_per_window": round(dt * 1e6 / nw, 4),
+           "us_per_window_dense_split": round(us_per_window_dense, 4),
+           "per_window_cost_vs_dense": round(dt * 1e6 / nw / us_per_window_dense, 4),
+           "query_chunks": [list(c) for c in dp.get("chunks", [(0, queries)])]}
+    saved = (opt.hip_graph if hasattr(opt, "hip_graph") else False, opt.pipeline_tail)
+    try:
+        opt.hip_graph, opt.pipeline_tail = True, 0.0
+        gdt, (glists, _) = _timed(lambda: inf.predict_split(model, store, opt), steps, 2)
+        out["sync_free"] = {"hip_graph_ms_per_step": round(gdt * 1e3, 3), "same_rows_as_eager": glists == lists}
+    except Exception as e:      # noqa: BLE001
+        out["sync_free"] = {"error": repr(e)[:300]}
+    finally:
+        opt.hip_graph, opt.pipeline_tail = saved
+    return out
+
+
 def bench_shard_proxy(model, store, opt, ms_1gpu, steps=5, warmup=2, world=8):
     """ONE GPU's share of BASELINE configs[3] at `world` ranks, measured on this GPU without a process group: what rank 0
     of predict_split_distributed(mode="window") executes -- replicated stage A, project + window model + matching on its
@@ -415,6 +476,54 @@ def bench_config5_sharded(dist, world, timed_region, ctx_l=33_000, queries=64):
             "ranks_seen": dist.get_world_size(), "collectives_per_step": 2}
 
 
+def self_launch(n_gpus):
+    """`python3 bench.py --gpus N` with N > 1 and no RANK in the environment: this process touches no GPU -- it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (never an exec),
+    relays the child's stdout (rank 0's one JSON line) and stderr, and exits with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def rccl_preflight(dist, world, rank, nq, max_after, backend, device="cuda"):
+    """One all_gather_into_tensor of the message the step's exchange sends -- the fp64 kept rows (3, nq, max_after, 5) + the
+    int32 counts (3, nq) -- at this world size, before anything is timed.  A failure (xGMI / IPC / RCCL set-up) becomes a
+    one-line reason on stderr and a non-zero exit instead of a hang or a stack of C++ frames in the middle of the bench."""
+    try:
+        t0 = time.perf_counter()
+        rows = torch.full((3, nq, max_after, 5), float(rank), dtype=torch.float64, device=device)
+        n = torch.full((3, nq), rank, dtype=torch.int32, device=device)
+        rows_all = torch.empty((world * 3, nq, max_after, 5), dtype=torch.float64, device=device)
+        n_all = torch.empty((world * 3, nq), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(rows_all, rows)
+        dist.all_gather_into_tensor(n_all, n)
+        if device == "cuda":
+            torch.cuda.synchronize()
+        want = torch.arange(world, dtype=torch.float64, device=device).repeat_interleave(3)
+        ok = bool((rows_all[:, 0, 0, 0] == want).all()) and bool((n_all[:, 0].to(torch.float64) == want).all())
+        if not ok:
+            raise RuntimeError("gathered shards are not in rank order / not the values the ranks sent")
+        return {"ok": True, "backend": backend, "world": world, "bytes_per_rank": int(rows.numel() * 8 + n.numel() * 4),
+                "first_collective_ms": round((time.perf_counter() - t0) * 1e3, 2)}
+    except Exception as e:          # noqa: BLE001
+        sys.stderr.write(f"bench.py: collective preflight failed on rank {rank} of {world} ({backend}): "
+                         f"{type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,10 +539,11 @@ def main():
     ap.add_argument("--pipeline_tail", type=float, default=None,
                     help="fraction of the queries in the tail chunk of the host/GPU pipeline (default: automatic = 1/16 from 32 "
                          "reference batches on, i.e. at this size; 0 = one chunk)")
-    ap.add_argument("--need_saliency", action="store_true",
-                    help="A/B: the headline step also runs the saliency head and the intermediate decoder layers' heads "
-                         "(the reference computes them and never reads them); the default line reports that figure as "
-                         "ms_per_step_full_forward next to the headline")
+    ap.add_argument("--elide_dead_work", action="store_true",
+                    help="A/B: the headline step WITHOUT the saliency head and the intermediate decoder layer's heads "
+                         "(CONE.forward computes them, cone/inference.py never reads them); the default headline computes "
+                         "both and reports the elided step beside it as ms_per_step_dead_work_elided")
+    ap.add_argument("--need_saliency", action="store_true", help="accepted for older command lines: now the default")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_extras", action="store_true",
                     help="only the headline timed region (profiling runs): skip the full-forward region, the split_bf16 "
@@ -443,10 +553,27 @@ def main():
                     help="clips of the MAD-scale stress video of prefilter_mad_ctx_sharded (N > 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python3 bench.py --gpus N`: become the launcher (no GPU call has happened in this process)
+        sys.exit(self_launch(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
+    if os.environ.get("CONE_BENCH_LAUNCH_CHECK") == "1":
+        # launcher + rendezvous + preflight only, on CPU tensors over gloo (tests/test_host_cpu.py: no GPU in the build
+        # container): the ranks the plain entry started find each other and exchange the step's message shape
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        pf = rccl_preflight(dist, world, rank, min(args.queries, 1000), 5, "gloo", device="cpu")
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": dist.get_world_size(),
+                              "collective_preflight": pf}))
+        dist.destroy_process_group()
+        return
     # test-only overrides so that the N > 1 code path can be exercised on a one-GPU box (tests/test_gpu_parity.py):
     # CONE_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, CONE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks
     # on one device).  Neither is set by the driver's launch.
@@ -465,10 +592,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        preflight = rccl_preflight(dist, world, rank, min(args.queries, 1000), 5, backend)
 
+    # the headline step computes everything CONE.forward returns (cone/model.py:112-127): saliency_scores and aux_outputs too
+    full = not args.elide_dead_work
     opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32,
                    window_batch=args.window_batch, pipeline_chunks=args.pipeline_chunks, pipeline_tail=args.pipeline_tail,
-                   need_saliency=args.need_saliency, need_aux=args.need_saliency)
+                   need_saliency=full, need_aux=full)
+    if full and args.pipeline_tail is None and args.pipeline_chunks is None \
+            and -(-args.queries // opt.eval_bsz) >= 32:
+        # the product's automatic chunking keeps a split whole when the caller asked for the per-window outputs of the whole
+        # split; the bench reads none of them (it measures that they are COMPUTED), so it keeps the pipeline's two chunks
+        opt.pipeline_tail = 1.0 / 16.0
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -514,10 +649,13 @@ def main():
         dt = time.perf_counter() - t0
         rec = collect_profile()
         lib.cone_prof_enable(0)
+        timed_region.per_rank = [dt]
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            allt = torch.empty(world, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allt, t)
+            timed_region.per_rank = [float(x) for x in allt.tolist()]
+            dt = max(timed_region.per_rank)            # MAX over ranks
         return dt, rec, res
 
     timed_region.steps = args.steps
@@ -535,6 +673,9 @@ def main():
             "queries_per_s": round(world * args.queries * args.steps / dt, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "ranks_seen": dist.get_world_size() if use_dist else 1,
+            "ms_per_step_rank_max": round(max(timed_region.per_rank) / args.steps * 1e3, 3),
+            "ms_per_step_rank_min": round(min(timed_region.per_rank) / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic, "
@@ -544,24 +685,34 @@ def main():
                        "query_chunks": [list(c) for c in dp.get("chunks", [(0, args.queries)])],
                        "outputs": "per window pred_logits, pred_spans, matching scores -> rows [st, ed, proposal, "
                                   "matching]; per query fused / proposal / matching top-5 after NMS as JSON rows"
-                                  + ("; saliency head and the intermediate decoder layer's heads (aux_outputs) computed too"
-                                     if args.need_saliency else
-                                     "; saliency and aux (intermediate-layer) heads not computed in the headline step -- the "
-                                     "reference computes them and never reads them (cone/inference.py:54-59); "
-                                     "ms_per_step_full_forward is the same step with both computed, as CONE.forward does"),
+                                  + ("; saliency_scores and the intermediate decoder layer's heads (aux_outputs) computed too, "
+                                     "as CONE.forward does (cone/model.py:112-127) -- cone/inference.py never reads them (:54-59); "
+                                     "ms_per_step_dead_work_elided is the same step without them"
+                                     if full else
+                                     "; --elide_dead_work: saliency and aux (intermediate-layer) heads NOT computed"),
                        "ranks_seen": dist.get_world_size() if use_dist else 1},
             "roofline": roof, "kernels": kern,
         }
+        if use_dist:
+            res["collective_preflight"] = preflight
         wt = dp.get("windows")
         if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
             fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),
                                         opt.v_appear_feat_dim, opt.t_feat_dim)
             tf = world * float(fl.sum()) * args.steps / dt / 1e12
+            ex = executed_mfma_flops(rec, wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(), opt, args.steps)
+            etf = world * ex["total"] / dt / 1e12
             res["window_model"] = {"reference_mflop_per_window": round(float(fl.mean()) / 1e6, 1),
                                    "reference_algorithmic_tflops": round(tf, 1),
-                                   "frac_of_fp32_mfma_peak": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
-                                   "note": "reference FLOPs (padding excluded) over the whole step time; the build "
-                                           "executes fewer (de-duplicated projections, folded decoder K/V)"}
+                                   "reference_equivalent_frac": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
+                                   "executed_tflops": round(etf, 1),
+                                   "executed_frac": round(etf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
+                                   "executed_gflop_per_step": {k: round(v / args.steps / 1e9, 1) for k, v in ex.items()},
+                                   "note": "reference_*: the REFERENCE's algorithmic FLOPs (padding excluded) over the whole step "
+                                           "time -- what the reference would have to sustain for this throughput, not what this "
+                                           "build executes; executed_*: the FLOPs the MFMA kernels of the step actually ran "
+                                           "(dense layers from the launch records, attention cores from the window lengths: "
+                                           "de-duplicated projections, folded decoder K/V) over the same time and the fp32-MFMA peak"}
 
     def note(name, value):
         if res is not None:
@@ -580,21 +731,17 @@ def main():
         if v is not None:
             note(name, v)
 
-    # ---- the reference's full CONE.forward in the eval path (cone/model.py:112-127): saliency_scores + aux_outputs too
-    if not args.need_saliency and not args.no_extras:
-        def full_forward():
-            tail0 = opt.pipeline_tail
-            if tail0 is None and len(inf.query_chunks(args.queries, opt)) > 1:
-                opt.pipeline_tail = 1.0 / 16.0      # the headline's automatic chunking (a caller who wants the per-window
-            opt.need_saliency = opt.need_aux = True  # outputs of the whole split gets one chunk by default; the bench does not)
+    # ---- the eval pipeline's own default (cone_amd.inference): the outputs cone/inference.py never reads are not computed
+    if full and not args.no_extras:
+        def elided():
+            opt.need_saliency = opt.need_aux = False
             try:
                 fdt, _, (_, fdp) = timed_region(step)
             finally:
-                opt.need_saliency = opt.need_aux = False
-                opt.pipeline_tail = tail0
-            note("ms_per_step_full_forward", round(fdt / args.steps * 1e3, 2))
-            note("value_full_forward", round(world * fdp["n_windows"] * args.steps / fdt, 1))
-        guarded("full_forward_error", full_forward)
+                opt.need_saliency = opt.need_aux = True
+            note("ms_per_step_dead_work_elided", round(fdt / args.steps * 1e3, 2))
+            note("value_dead_work_elided", round(world * fdp["n_windows"] * args.steps / fdt, 1))
+        guarded("dead_work_elided_error", elided)
 
     if world == 1 and not args.no_extras and not any(kv.startswith("split_bf16") for kv in args.set_option):
         # OPT-IN path, reported beside the headline (which stays exact fp32): every layer tail on the bf16 matrix cores,
@@ -654,6 +801,8 @@ def main():
 
     if world == 1 and not args.no_extras:
         guarded("shard_proxy_8", lambda: bench_shard_proxy(model, store, opt, dt / args.steps * 1e3))
+        guarded("config2_ragged", lambda: bench_config2_ragged(model, opt, args.queries, args.videos,
+                                                               dt / args.steps * 1e6 / n_windows))
         del store, dp, out
         model._ws.buf = None
         torch.cuda.empty_cache()

@@ -104,13 +104,13 @@ _SIGNATURES = {
                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_clip_matching": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cone_window_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3
+    "cone_window_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3
                           + [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]),
     "cone_compose_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "cone_fuse_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+    "cone_fuse_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "cone_fuse_nms_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+    "cone_fuse_nms_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_temporal_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
@@ -140,7 +140,7 @@ _SIGNATURES = {
     "cone_test_rows_split": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "cone_test_proj_split_image_bytes": (C.c_size_t, []),
     "cone_test_proj_ffn_split": (C.c_int, [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "cone_test_enc_attn": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_void_p]),
+    "cone_test_enc_attn": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cone_test_dec_cross": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "cone_test_dec_cross_slab_floats": (C.c_size_t, []),
     "cone_test_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -172,7 +172,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 3:
+    if lib.cone_abi_version() != 4:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -30,15 +30,24 @@ def _deps_mtime():
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    path = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
-        return obj
+    stamp = obj + ".flags"          # the exact flag list the object was compiled with: an A/B build with other
+    path = os.path.join(CSRC, src)  # CONE_HIPCC_FLAGS (thresholds are -D macros) never reuses a stale object
     extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
     extra += os.environ.get("CONE_HIPCC_FLAGS", "").split()     # A/B builds on the GPU box (tools/ab_variants.sh)
+    flags = " ".join([*FLAGS, *extra])
+    try:
+        with open(stamp) as f:
+            same_flags = f.read() == flags
+    except OSError:
+        same_flags = False
+    if same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime()):
+        return obj
     cmd = ["hipcc", *FLAGS, *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(flags)
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
     return obj
@@ -56,7 +65,11 @@ def build(force: bool = False) -> str:
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    build_pylists()
+    try:
+        build_pylists()
+    except (RuntimeError, OSError) as e:    # no gcc / no Python.h on the box: the HIP library is complete without it,
+        sys.stderr.write(f"cone_amd.build: _cone_pylists.so not built ({str(e).splitlines()[0]}); "      # the host falls
+                         "submission lists will be built by the Python loop\n")                         # back (slower)
     return LIB
 
 

@@ -418,7 +418,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     if (!c.ok) { set_error("forward: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     const int Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
     const int* Mdev = f.off + B;
-    const size_t pos_rows_n = l0 ? (size_t)l0->max_v_l * (l0->max_v_l + 1) / 2 : 0;
+    const size_t pos_rows_n = l0 ? (size_t)cone_pos_table_rows(l0->max_v_l) : 0;
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
     const bool gather0 = l0 && m->opt_l0_gather;
@@ -448,7 +448,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (l == 0 && gather0) {
             mode = ATTN_GATHER;
             src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.pos_qk = l0->pos_qk;
-            src.vrow0 = vrow0; src.vlen = vlen; src.trow0 = trow0;
+            src.vrow0 = vrow0; src.vlen = vlen; src.trow0 = trow0; src.pos_zero_row = (int)pos_rows_n - 1;
         } else if (l == 0 && l0) {                         // packed by pack_l0: (M, 512) q|k then (M, 256) v
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + (size_t)Mmax * 512;
             src.ldq = src.ldk = 512; src.ldv = 256;
@@ -463,7 +463,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                 RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
             mode = ATTN_POSADD;
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + 512; src.ldq = src.ldk = src.ldv = 768;
-            src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512; src.vlen = vlen;
+            src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512; src.vlen = vlen; src.pos_zero_row = (int)pos_rows_n - 1;
         } else {
             float* QK = f.QKV; float* V = f.QKV + (size_t)Mmax * 512;
             RUN(launch_gemm(G(m, f.XP, 256, e.sa.in_w, 256, e.sa.in_b, QK, 512, Mmax, Mdev, 512, 256), s));  // q | k = (x+pos) W^T
@@ -690,14 +690,17 @@ extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, cons
                           saliency, taps, ws, ws_bytes, (hipStream_t)stream, l0);
 }
 
-extern "C" int64_t cone_pos_table_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2; }
+// rows (lv, p), p < lv <= max_v_l, then ONE all-zero row: the position term of a text token (cone/model.py:106), which the
+// encoder attention adds unconditionally instead of branching on the token kind
+extern "C" int64_t cone_pos_table_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2 + 1; }
 
 extern "C" int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream) {
     CONE_REQUIRE(m && pos_rows && pos_qk && max_v_l >= 1 && max_v_l <= 192, "pos_tables: bad argument");
     const int64_t rows = cone_pos_table_rows(max_v_l);
     hipStream_t s = (hipStream_t)stream;
     RUN(launch_pos_rows(m->dim_t, max_v_l, pos_rows, s));
-    // pos W_q^T | pos W_k^T of every encoder layer, no bias (the bias travels with the clip / token rows)
+    CONE_CHECK_HIP(hipMemsetAsync(pos_rows + (size_t)(rows - 1) * 256, 0, 256 * sizeof(float), s));    // the zero row
+    // pos W_q^T | pos W_k^T of every encoder layer, no bias (the bias travels with the clip / token rows): zero row -> zeros
     for (int l = 0; l < m->n_enc; ++l)
         RUN(launch_gemm(G(m, pos_rows, 256, m->enc[l].sa.in_w, 256, nullptr, pos_qk + (size_t)l * rows * 512, 512,
                           (int)rows, nullptr, 512, 256), s));
@@ -884,8 +887,9 @@ extern "C" int cone_test_proj_ffn_split(const float* A, const float* Wo, const f
 }
 extern "C" int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt,
                                   const float* pos_qk, const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0,
-                                  const int32_t* off, float* OUT, int B, int Lmax, void* stream) {
+                                  const int32_t* off, float* OUT, int B, int Lmax, int pos_zero_row, void* stream) {
     AttnSrc a{};
+    a.pos_zero_row = pos_zero_row;
     a.Q = QKV; a.K = QKV ? QKV + 256 : nullptr; a.V = QKV ? QKV + 512 : nullptr; a.ldq = a.ldk = a.ldv = 768;
     a.qkv_vid = qkv_vid; a.qkv_txt = qkv_txt; a.pos_qk = pos_qk; a.vrow0 = vrow0; a.vlen = vlen; a.trow0 = trow0;
     a.form = (mode >> 8) & 3;                     // mode | 0x200: the wave-per-(window, head) form (enc_attn_wave_kernel)

@@ -31,114 +31,33 @@
 namespace cone {
 
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
+// the encoder kernels carry their scores in the log2 domain: q is scaled by sqrt(1/32) * log2(e), the softmax uses exp2
+constexpr float kQScaleLog2 = 0.17677669529663687f * 1.4426950408889634f;
 
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
+typedef float f32x2m __attribute__((ext_vector_type(2)));
 
-// MODE: ATTN_PACKED / ATTN_GATHER / ATTN_POSADD (common.h).  In the two table modes the q | k rows of a clip token
-// get the static row pos_qk[(lv, p)] added in the staging loads -- the adds the reference performs as
-// ``q = k = src + pos`` ahead of in_proj (cone/transformer.py:237), moved behind the (linear) projection.
-template <int NKT, int MODE>
-__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
-                                                                 const int* __restrict__ off) {
-    constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
-    __shared__ float KsT[32 * LDK];
-    __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
-    const int b = blockIdx.y, head = blockIdx.x;        // the 8 heads of a window are dispatched together
-    const int t0 = off[b];
-    const int L = off[b + 1] - t0;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
-    if (MODE != ATTN_PACKED) { lv = a.vlen[b]; pbase = lv * (lv - 1) / 2; }
-    if (MODE == ATTN_GATHER) { vr0 = a.vrow0[b]; tr0 = a.trow0[b]; }
-    // row pointers of token `tok`: q, k, v (each at column 0 of its 256-wide block) and the additive pos row (or null)
-    auto rows_of = [&](int tok, const float*& q, const float*& k, const float*& v, const float*& add) {
-        add = (MODE != ATTN_PACKED && tok < lv) ? a.pos_qk + (size_t)(pbase + tok) * 512 : nullptr;
-        if (MODE == ATTN_GATHER) {
-            const float* r = tok < lv ? a.qkv_vid + (size_t)(vr0 + tok) * 768 : a.qkv_txt + (size_t)(tr0 + tok - lv) * 768;
-            q = r; k = r + 256; v = r + 512;
-        } else {
-            q = a.Q + (size_t)(t0 + tok) * a.ldq; k = a.K + (size_t)(t0 + tok) * a.ldk; v = a.V + (size_t)(t0 + tok) * a.ldv;
-        }
-    };
+// Row softmax of one query column held as NKT x 4 score registers per lane (key 16 kt + 4 lg + r), shared by both kernel
+// forms (same operations in the same order: identical bits).  Vector instructions do not hide under the exact-fp32 MFMA on
+// this part (tools/probe/mfma_valu_overlap.hip), so every one of them is on the critical path -- the count is what matters:
+//   * the scores arrive in the log2 domain (log2(e) is folded into the q scale): exp2(s - m) is ONE packed subtract per two
+//     scores (v_pk_add_f32) + the exponential, instead of an fma per score;
+//   * the row sum runs on two-wide registers (v_pk_add_f32): 14 adds instead of 28;
+//   * the probabilities are NOT normalised (28 multiplies): P.V runs on the raw exponentials and the 8 OUTPUT registers are
+//     scaled by 1 / sum afterwards (the sum of output row 4 lg + r lives in the lane whose query is that row: one
+//     ds_bpermute per r) -- attn_normalise().
+// Only a tile that reaches past the window's last key is masked (wave-uniform test on the scalar L).  Leaves exp2(s - m) in
+// sc, returns 1 / sum.
+// lane ^ 16 / lane ^ 32 exchanges as ds_bpermute with the byte address computed from the lane id the caller already holds
+// (__shfl_xor re-derives the lane id and bounds-checks it: ~10 vector instructions per call).
+__device__ __forceinline__ float lane_xor(float v, int lane, int mask) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __float_as_int(v)));
+}
 
-    // ONE memory round trip per workgroup: the query values, both staging passes (key rows kr and kr + NT/8: KP = 2 NT/8
-    // exactly) and their position rows are all requested before anything is waited for.  Rows past the window re-read its
-    // last row and are zeroed by a mask, the position row of a text token re-reads the token's own row and is masked, so no
-    // load sits behind a branch (the compiler otherwise waits out every conditional load where it stands: four serial
-    // round trips -- q, q's position row, and the two staging passes -- in front of the first MFMA).
-    const int q0 = wave * 16;
-    const int kr = tid >> 3, c = tid & 7;
-    float4 qx[2], qt[2], kv[2], vv[2], kt_[2];
-    bool q_add = false, k_ok[2], k_add[2];
-    {
-        int qrow = q0 + li;
-        qrow = qrow < L ? qrow : L - 1;
-        const float *qp, *kp_, *vp_, *qadd;
-        rows_of(qrow, qp, kp_, vp_, qadd);
-        qp += head * 32 + 8 * lg;
-        q_add = MODE != ATTN_PACKED && qadd != nullptr;
-        const float* ap = q_add ? qadd + head * 32 + 8 * lg : qp;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            qx[u] = reinterpret_cast<const float4*>(qp)[u];
-            if (MODE != ATTN_PACKED) qt[u] = reinterpret_cast<const float4*>(ap)[u];
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int key = kr + it * (NT / 8);
-        k_ok[it] = key < L;
-        const int row = k_ok[it] ? key : L - 1;
-        const float *qp, *kp_, *vp_, *add;
-        rows_of(row, qp, kp_, vp_, add);
-        k_add[it] = MODE != ATTN_PACKED && add != nullptr;
-        kv[it] = *reinterpret_cast<const float4*>(kp_ + head * 32 + c * 4);
-        vv[it] = *reinterpret_cast<const float4*>(vp_ + head * 32 + c * 4);
-        if (MODE != ATTN_PACKED)
-            kt_[it] = *reinterpret_cast<const float4*>((k_add[it] ? add + 256 : kp_) + head * 32 + c * 4);
-    }
-    float qv[8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        float4 x = qx[u];
-        if (MODE != ATTN_PACKED && q_add) { x.x += qt[u].x; x.y += qt[u].y; x.z += qt[u].z; x.w += qt[u].w; }
-        qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
-        qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int key = kr + it * (NT / 8);
-        float4 k4 = kv[it], v4 = vv[it];
-        if (MODE != ATTN_PACKED && k_add[it]) { k4.x += kt_[it].x; k4.y += kt_[it].y; k4.z += kt_[it].z; k4.w += kt_[it].w; }
-        if (!k_ok[it]) { k4 = make_float4(0.f, 0.f, 0.f, 0.f); v4 = k4; }
-        KsT[(4 * c + 0) * LDK + key] = k4.x; KsT[(4 * c + 1) * LDK + key] = k4.y;
-        KsT[(4 * c + 2) * LDK + key] = k4.z; KsT[(4 * c + 3) * LDK + key] = k4.w;
-        *reinterpret_cast<float4*>(Vs + key * LDV + c * 4) = v4;
-    }
-    __syncthreads();
-    if (q0 >= L) return;
-
-    // All NKT key tiles are always walked: the rows past the window's last key are staged as zeros, their scores masked
-    // to -inf (probability exactly 0), so the extra MFMAs add exact zeros -- and the per-tile "does this tile exist"
-    // branches (7 x 4 loops of scalar compare + branch around every MFMA group: 200 branches per wave, the SALU port the
-    // most loaded issue port of the SIMD) are gone.  A batch pads to its own longest window (the launcher picks NKT).
-    f32x4m sc[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) sc[kt] = f32x4m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        const float* kp = KsT + (8 * lg + st) * LDK + li;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
-    }
+template <int NKT>
+__device__ __forceinline__ float attn_softmax(f32x4m (&sc)[NKT], int L, int lane, int lg) {
     const int lim = L - 4 * lg;                     // key 16 kt + 4 lg + r is real iff 16 kt + r < lim
-    // Only a tile that reaches past the window's last key needs the mask (a wave-uniform test on the scalar L): vector
-    // instructions do not hide under the fp32 MFMA on this part (tools/probe/mfma_valu_overlap.hip) -- a 98 .. 110-token
-    // window has ONE such tile of seven, 48 compare / select instructions fewer per wave: 2.74 -> 2.69 ms (same box).
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -149,39 +68,164 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
 #pragma unroll
         for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float m2 = m * 1.4426950408889634f;
-    float l = 0.f;
+    m = fmaxf(m, lane_xor(m, lane, 16));
+    m = fmaxf(m, lane_xor(m, lane, 32));
+    const f32x2m m2 = {m, m};
+    f32x2m l2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x2m a = sc[kt].xy - m2, b = sc[kt].zw - m2;
+        a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
+        b.x = __builtin_amdgcn_exp2f(b.x); b.y = __builtin_amdgcn_exp2f(b.y);
+        sc[kt].xy = a; sc[kt].zw = b;
+        l2 += a;
+        l2 += b;
+    }
+    float l = l2.x + l2.y;
+    l += lane_xor(l, lane, 16);
+    l += lane_xor(l, lane, 32);
+    return 1.0f / l;
+}
+
+// o0 / o1 register r = output row (query) 4 lg + r of the tile; its 1 / sum sits in every lane whose li is that row.
+__device__ __forceinline__ void attn_normalise(f32x4m& o0, f32x4m& o1, float inv, int lane, int lg) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
-            sc[kt][r] = e;
-            l += e;
+    for (int r = 0; r < 4; ++r) {
+        const float s = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 48) + 4 * lg + r) << 2, __float_as_int(inv)));
+        o0[r] *= s;
+        o1[r] *= s;
+    }
+}
+
+// MODE: ATTN_PACKED / ATTN_GATHER / ATTN_POSADD (common.h).  In the two table modes the q | k rows of a clip token
+// get the static row pos_qk[(lv, p)] added in the staging loads -- the adds the reference performs as
+// ``q = k = src + pos`` ahead of in_proj (cone/transformer.py:237), moved behind the (linear) projection.
+// Addressing: every load is `uniform base (SGPR pair) + 32-bit lane offset` (global_load ... saddr): the window's row bases
+// are scalars (t0, vrow0[b], trow0[b], the table row of (lv, 0)), a lane contributes token * stride + column.  A text token
+// reads the table's ZERO row (AttnSrc::pos_zero_row: the last row of cone_pos_tables) instead of skipping the add, so the
+// adds are unconditional and no 64-bit pointer is ever selected per lane except the gather mode's clip / text source.
+template <int NKT, int MODE>
+__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
+                                                                 const int* __restrict__ off) {
+    constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
+    __shared__ float KsT[32 * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
+    const int b = blockIdx.y, head = blockIdx.x;        // the 8 heads of a window are dispatched together
+    const int t0 = off[b];
+    const int L = off[b + 1] - t0;
+    if (L <= 0) return;                                 // an empty window owns no row (and L - 1 would index before the buffer)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned hc = head * 32;
+    int lv = 0;
+    // rows of token `tok`: q at qrow(tok), k at krow(tok), v at vrow(tok) (column hc of each), all as base + unsigned offset
+    const float *qb = nullptr, *kb = nullptr, *vb = nullptr, *tb = nullptr, *pb = nullptr;
+    unsigned sq = 768, sk = 768, sv = 768;
+    int pbase = 0;
+    if (MODE != ATTN_PACKED) {
+        lv = a.vlen[b];
+        pbase = lv * (lv - 1) / 2;
+        pb = a.pos_qk + hc;
+    }
+    if (MODE == ATTN_GATHER) {
+        // token tok is row tok of `qb` (a clip: tok < lv) or of `tb` (a text token; tb is biased by -lv rows)
+        qb = a.qkv_vid + (size_t)a.vrow0[b] * 768 + hc;
+        tb = a.qkv_txt + ((ptrdiff_t)a.trow0[b] - lv) * 768 + hc;
+    } else {
+        sq = a.ldq; sk = a.ldk; sv = a.ldv;
+        qb = a.Q + (size_t)t0 * sq + hc; kb = a.K + (size_t)t0 * sk + hc; vb = a.V + (size_t)t0 * sv + hc;
+    }
+    const int zrow = a.pos_zero_row;
+
+    // ONE memory round trip per workgroup: the query values, both staging passes (key rows kr and kr + NT/8: KP = 2 NT/8
+    // exactly) and their position rows are all requested before anything is waited for.  Rows past the window re-read its
+    // last row (their scores are masked, their probabilities exactly 0), a text token's position row is the table's zero
+    // row: no load sits behind a branch.
+    const int q0 = wave * 16;
+    const int kr = tid >> 3;
+    const unsigned c4 = (tid & 7) * 4;
+    f32x4m qx[2], qt[2], kv[2], vv[2], kt_[2];
+    {
+        const int qrow = min(q0 + li, L - 1);
+        const float* qp;
+        if (MODE == ATTN_GATHER) qp = (qrow < lv ? qb : tb) + (unsigned)qrow * 768u + 8u * lg;
+        else qp = qb + (unsigned)qrow * sq + 8u * lg;
+        qx[0] = *reinterpret_cast<const f32x4m*>(qp);
+        qx[1] = *reinterpret_cast<const f32x4m*>(qp + 4);
+        if (MODE != ATTN_PACKED) {
+            const unsigned pr = (unsigned)(qrow < lv ? pbase + qrow : zrow) * 512u + 8u * lg;
+            qt[0] = *reinterpret_cast<const f32x4m*>(pb + pr);
+            qt[1] = *reinterpret_cast<const f32x4m*>(pb + pr + 4);
         }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = min(kr + it * (NT / 8), L - 1);
+        if (MODE == ATTN_GATHER) {
+            const float* rp = (row < lv ? qb : tb) + (unsigned)row * 768u + c4;
+            kv[it] = *reinterpret_cast<const f32x4m*>(rp + 256);
+            vv[it] = *reinterpret_cast<const f32x4m*>(rp + 512);
+        } else {
+            kv[it] = *reinterpret_cast<const f32x4m*>(kb + (unsigned)row * sk + c4);
+            vv[it] = *reinterpret_cast<const f32x4m*>(vb + (unsigned)row * sv + c4);
+        }
+        if (MODE != ATTN_PACKED)
+            kt_[it] = *reinterpret_cast<const f32x4m*>(pb + (unsigned)(row < lv ? pbase + row : zrow) * 512u + 256u + c4);
+    }
+    float qv[8];
+    {
+        f32x4m x0 = qx[0], x1 = qx[1];
+        if (MODE != ATTN_PACKED) { x0 += qt[0]; x1 += qt[1]; }
+        x0 *= kQScaleLog2; x1 *= kQScaleLog2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qv[j] = x0[j]; qv[4 + j] = x1[j]; }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int key = kr + it * (NT / 8);
+        f32x4m k4 = kv[it];
+        if (MODE != ATTN_PACKED) k4 += kt_[it];
+        float* kd = KsT + c4 * LDK + key;
+        kd[0] = k4[0]; kd[LDK] = k4[1]; kd[2 * LDK] = k4[2]; kd[3 * LDK] = k4[3];
+        *reinterpret_cast<f32x4m*>(Vs + key * LDV + c4) = vv[it];
+    }
+    __syncthreads();
+    if (q0 >= L) return;
+
+    // All NKT key tiles are always walked: the rows past the window's last key hold finite copies of its last row, their
+    // scores are masked to -inf (probability exactly 0), so the extra MFMAs add exact zeros -- and the per-tile "does this
+    // tile exist" branches are gone.  A batch pads to its own longest window (the launcher picks NKT).
+    f32x4m sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) sc[kt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const float* kp = KsT + (8 * lg + st) * LDK + li;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16], qv[st], sc[kt], 0, 0, 0);
+    }
+    const float inv = attn_softmax<NKT>(sc, L, lane, lg);
     f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pr = sc[kt][r] * inv;
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vp[r * LDV + 16], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV + 16], o1, 0, 0, 0);
         }
     }
+    attn_normalise(o0, o1, inv, lane, lg);
+    float* ob = OUT + (size_t)t0 * 256 + hc;
+    const int qr0 = q0 + 4 * lg;
+    const unsigned oo = (unsigned)qr0 * 256u + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * lg + r;
-        if (qrow < L) {
-            float* dst = OUT + (size_t)(t0 + qrow) * 256 + head * 32 + li;
-            dst[0] = o0[r];
-            dst[16] = o1[r];
+        if (qr0 + r < L) {
+            ob[oo + 256u * r] = o0[r];
+            ob[oo + 256u * r + 16u] = o1[r];
         }
     }
 }
@@ -213,83 +257,72 @@ __global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float*
     const int head = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t0 = off[b];
     const int L = off[b + 1] - t0;
+    if (L <= 0) return;
     const int li = lane & 15, lg = lane >> 4;
-    int lv = 0, vr0 = 0, tr0 = 0, pbase = 0;
-    if (MODE != ATTN_PACKED) { lv = a.vlen[b]; pbase = lv * (lv - 1) / 2; }
-    if (MODE == ATTN_GATHER) { vr0 = a.vrow0[b]; tr0 = a.trow0[b]; }
-    auto rows_of = [&](int tok, const float*& q, const float*& k, const float*& v, const float*& add) {
-        add = (MODE != ATTN_PACKED && tok < lv) ? a.pos_qk + (size_t)(pbase + tok) * 512 : nullptr;
-        if (MODE == ATTN_GATHER) {
-            const float* r = tok < lv ? a.qkv_vid + (size_t)(vr0 + tok) * 768 : a.qkv_txt + (size_t)(tr0 + tok - lv) * 768;
-            q = r; k = r + 256; v = r + 512;
-        } else {
-            q = a.Q + (size_t)(t0 + tok) * a.ldq; k = a.K + (size_t)(t0 + tok) * a.ldk; v = a.V + (size_t)(t0 + tok) * a.ldv;
-        }
-    };
-    const int hc = head * 32;
-    // query values of a tile: 8 per lane (query = li, channels 8 lg ..), position row added for clip tokens, scaled
-    float4 qx[2], qt[2];
-    bool q_add = false;
+    const unsigned hc = head * 32;
+    // the addressing of enc_attn16_kernel: uniform bases + 32-bit lane offsets, a text token adds the table's zero row
+    int lv = 0, pbase = 0;
+    const float *qb = nullptr, *kb = nullptr, *vb = nullptr, *tb = nullptr, *pb = nullptr;
+    unsigned sq = 768, sk = 768, sv = 768;
+    if (MODE != ATTN_PACKED) { lv = a.vlen[b]; pbase = lv * (lv - 1) / 2; pb = a.pos_qk + hc; }
+    if (MODE == ATTN_GATHER) {
+        qb = a.qkv_vid + (size_t)a.vrow0[b] * 768 + hc;
+        tb = a.qkv_txt + ((ptrdiff_t)a.trow0[b] - lv) * 768 + hc;
+    } else {
+        sq = a.ldq; sk = a.ldk; sv = a.ldv;
+        qb = a.Q + (size_t)t0 * sq + hc; kb = a.K + (size_t)t0 * sk + hc; vb = a.V + (size_t)t0 * sv + hc;
+    }
+    const int zrow = a.pos_zero_row;
+    auto qptr = [&](int tok) { return MODE == ATTN_GATHER ? (tok < lv ? qb : tb) + (unsigned)tok * 768u : qb + (unsigned)tok * sq; };
+    auto kptr = [&](int tok) { return MODE == ATTN_GATHER ? (tok < lv ? qb : tb) + (unsigned)tok * 768u + 256 : kb + (unsigned)tok * sk; };
+    auto vptr = [&](int tok) { return MODE == ATTN_GATHER ? (tok < lv ? qb : tb) + (unsigned)tok * 768u + 512 : vb + (unsigned)tok * sv; };
+    auto pptr = [&](int tok) { return pb + (unsigned)(tok < lv ? pbase + tok : zrow) * 512u; };
+    // query values of a tile: 8 per lane (query = li, channels 8 lg ..), position row added, scaled
+    f32x4m qx[2], qt[2];
     auto load_q = [&](int q0) {
-        int qrow = q0 + li;
-        qrow = qrow < L ? qrow : L - 1;
-        const float *qp, *kp_, *vp_, *qadd;
-        rows_of(qrow, qp, kp_, vp_, qadd);
-        qp += hc + 8 * lg;
-        q_add = MODE != ATTN_PACKED && qadd != nullptr;
-        const float* ap = q_add ? qadd + hc + 8 * lg : qp;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            qx[u] = reinterpret_cast<const float4*>(qp)[u];
-            if (MODE != ATTN_PACKED) qt[u] = reinterpret_cast<const float4*>(ap)[u];
+        const int qrow = min(q0 + li, L - 1);
+        const float* qp = qptr(qrow) + 8 * lg;
+        qx[0] = *reinterpret_cast<const f32x4m*>(qp);
+        qx[1] = *reinterpret_cast<const f32x4m*>(qp + 4);
+        if (MODE != ATTN_PACKED) {
+            const float* ap = pptr(qrow) + 8 * lg;
+            qt[0] = *reinterpret_cast<const f32x4m*>(ap);
+            qt[1] = *reinterpret_cast<const f32x4m*>(ap + 4);
         }
     };
     load_q(0);
-    // keys: kreg[kt][st] = K[key 16 kt + li][8 lg + st] (zero past the window)
+    // keys: kreg[kt][st] = K[key 16 kt + li][8 lg + st] (rows past the window: a copy of its last row, masked below)
     float kreg[NKT][8];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const int key = 16 * kt + li;
-        const bool ok = key < L;
-        const float *qp, *kp_, *vp_, *add;
-        rows_of(ok ? key : L - 1, qp, kp_, vp_, add);
-        const bool k_add = MODE != ATTN_PACKED && add != nullptr;
-        const float4* kp4 = reinterpret_cast<const float4*>(kp_ + hc + 8 * lg);
-        const float4* ap4 = reinterpret_cast<const float4*>((k_add ? add + 256 : kp_) + hc + 8 * lg);
+        const int key = min(16 * kt + li, L - 1);
+        const float* kp_ = kptr(key) + 8 * lg;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float4 k4 = kp4[u];
-            if (MODE != ATTN_PACKED) {
-                const float4 t4 = ap4[u];
-                if (k_add) { k4.x += t4.x; k4.y += t4.y; k4.z += t4.z; k4.w += t4.w; }
-            }
-            if (!ok) k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            kreg[kt][4 * u] = k4.x; kreg[kt][4 * u + 1] = k4.y; kreg[kt][4 * u + 2] = k4.z; kreg[kt][4 * u + 3] = k4.w;
+            f32x4m k4 = *reinterpret_cast<const f32x4m*>(kp_ + 4 * u);
+            if (MODE != ATTN_PACKED) k4 += *reinterpret_cast<const f32x4m*>(pptr(key) + 256 + 8 * lg + 4 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kreg[kt][4 * u + j] = k4[j];
         }
     }
-    // values: vreg[kt][r][dt] = V[key 16 kt + 4 lg + r][16 dt + li] (zero past the window)
+    // values: vreg[kt][r][dt] = V[key 16 kt + 4 lg + r][16 dt + li]
     float vreg[NKT][4][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * lg + r;
-            const bool ok = key < L;
-            const float *qp, *kp_, *vp_, *add;
-            rows_of(ok ? key : L - 1, qp, kp_, vp_, add);
-            const float v0 = vp_[hc + li], v1 = vp_[hc + 16 + li];
-            vreg[kt][r][0] = ok ? v0 : 0.f;
-            vreg[kt][r][1] = ok ? v1 : 0.f;
+            const float* vp_ = vptr(min(16 * kt + 4 * lg + r, L - 1));
+            vreg[kt][r][0] = vp_[li];
+            vreg[kt][r][1] = vp_[16 + li];
         }
-    const int lim = L - 4 * lg;                     // key 16 kt + 4 lg + r is real iff 16 kt + r < lim
     for (int q0 = 0; q0 < L; q0 += 16) {
         float qv[8];
+        {
+            f32x4m x0 = qx[0], x1 = qx[1];
+            if (MODE != ATTN_PACKED) { x0 += qt[0]; x1 += qt[1]; }
+            x0 *= kQScaleLog2; x1 *= kQScaleLog2;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float4 x = qx[u];
-            if (MODE != ATTN_PACKED && q_add) { x.x += qt[u].x; x.y += qt[u].y; x.z += qt[u].z; x.w += qt[u].w; }
-            qv[4 * u] = x.x * kQScale; qv[4 * u + 1] = x.y * kQScale;
-            qv[4 * u + 2] = x.z * kQScale; qv[4 * u + 3] = x.w * kQScale;
+            for (int j = 0; j < 4; ++j) { qv[j] = x0[j]; qv[4 + j] = x1[j]; }
         }
         load_q(q0 + 16 < L ? q0 + 16 : q0);         // the next tile's query rows under this tile's MFMAs
         f32x4m sc[NKT];
@@ -300,38 +333,16 @@ __global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float*
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kreg[kt][st], qv[st], sc[kt], 0, 0, 0);
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll                                      // (masking only the partial tiles, as enc_attn16_kernel does, is slower here)
-            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + r < lim) ? sc[kt][r] : -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float m2 = m * 1.4426950408889634f;
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], 1.4426950408889634f, -m2));
-                sc[kt][r] = e;
-                l += e;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        const float inv = attn_softmax<NKT>(sc, L, lane, lg);
         f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = sc[kt][r] * inv;
-                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vreg[kt][r][0], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, vreg[kt][r][1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vreg[kt][r][0], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vreg[kt][r][1], o1, 0, 0, 0);
             }
+        attn_normalise(o0, o1, inv, lane, lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qrow = q0 + 4 * lg + r;
@@ -375,11 +386,12 @@ int launch_enc_attn(int mode, const AttnSrc& a, float* OUT, const int* off, int 
             CONE_REQUIRE(a.Q && a.K && a.V, "enc attention: packed mode needs Q, K, V");
             return launch_enc_attn_t<ATTN_PACKED>(a, OUT, off, B, Lmax, s);
         case ATTN_GATHER:
-            CONE_REQUIRE(a.qkv_vid && a.qkv_txt && a.pos_qk && a.vrow0 && a.vlen && a.trow0,
+            CONE_REQUIRE(a.qkv_vid && a.qkv_txt && a.pos_qk && a.vrow0 && a.vlen && a.trow0 && a.pos_zero_row >= 0,
                          "enc attention: gather mode needs the layer-0 caches");
             return launch_enc_attn_t<ATTN_GATHER>(a, OUT, off, B, Lmax, s);
         case ATTN_POSADD:
-            CONE_REQUIRE(a.Q && a.K && a.V && a.pos_qk && a.vlen, "enc attention: pos-add mode needs Q, K, V, pos_qk, vlen");
+            CONE_REQUIRE(a.Q && a.K && a.V && a.pos_qk && a.vlen && a.pos_zero_row >= 0,
+                         "enc attention: pos-add mode needs Q, K, V, pos_qk, vlen");
             return launch_enc_attn_t<ATTN_POSADD>(a, OUT, off, B, Lmax, s);
     }
     set_error("enc attention: unknown mode %d", mode);

@@ -89,11 +89,16 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 #endif
 
 // ---------------------------------------------------------------- opt-in launch timing (prof.hip)
+// one kind per KERNEL: a record's time is that kernel's launch and nothing else (the layer tail's wide / 64-row forms and
+// the row GEMM's small form are other kernels than the persistent 128-row forms and have their own kinds)
 enum ProfKind { PK_GEMM_128x128 = 0, PK_GEMM_128x128_A2 = 1, PK_GEMM_64x256 = 2, PK_ENC_ATTN = 3, PK_FRAME_SCORE = 4,
-                PK_GEMM_ROWS = 5, PK_GEMM_ROWS16 = 6, PK_DEC_CROSS = 7, PK_FFN_FUSED = 8, PK_FFN_PROJ = 9 };
+                PK_GEMM_ROWS = 5, PK_GEMM_ROWS16 = 6, PK_DEC_CROSS = 7, PK_FFN_FUSED = 8, PK_FFN_PROJ = 9,
+                PK_FFN_WIDE = 10, PK_FFN_PROJ_WIDE = 11, PK_FFN_FUSED_NW4 = 12, PK_FFN_PROJ_NW4 = 13, PK_GEMM_ROWS_SMALL = 14 };
 bool prof_enabled();
 struct ProfScope {
-    ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s);
+    // a_dev: device-side row count of the whole job (wins over `a` when smaller); a_off: the launch covers rows
+    // a_off .. a_off + a of that job, so its rows are clamp(*a_dev - a_off, 0, a)
+    ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s, int64_t a_off = 0);
     ~ProfScope();
     int idx_; hipStream_t s_; bool counted_;
 };
@@ -203,6 +208,7 @@ enum { ATTN_PACKED = 0, ATTN_GATHER = 1, ATTN_POSADD = 2 };
 struct AttnSrc {
     const float* Q; const float* K; const float* V; int ldq, ldk, ldv;
     const float* qkv_vid; const float* qkv_txt; const float* pos_qk;    // pos_qk (R, 512), row lv (lv - 1) / 2 + p
+    int pos_zero_row;                             // a row of pos_qk that is all zeros (cone_pos_tables: its last row): what a text token adds
     const int* vrow0; const int* vlen; const int* trow0;
     int form;                                     // 0: the workgroup-per-(window, head) kernel; 2: one wave per (window, head), K / V in registers (same bits; <= 144 tokens)
 };

@@ -569,7 +569,8 @@ static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     const int grid = tiles < n_cu ? tiles : n_cu;
     // FLOPs of a record: 4 * M * ff * 256 for the block, + 2 * M * 256 * 256 with the projection
     // (+ 2 * M * n_qkv * 256 with the fused q | k | v projection: booked as n_qkv / 2 extra hidden units)
-    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
+    ProfScope ps(NW == 8 ? (PROJ ? PK_FFN_PROJ : PK_FFN_FUSED) : (PROJ ? PK_FFN_PROJ_NW4 : PK_FFN_FUSED_NW4), a.M,
+                 a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
     hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
@@ -618,7 +619,6 @@ int launch_ffn_fused(const float* X, int ldx, const float* W1, const float* b1, 
     if (int rc = launch_ffn_nw<false, false, 8>(a, s, &n_cu)) return rc;
     const int m1 = ffn_full_round_rows(M, n_cu, ff);
     if (m1 == M) return launch_ffn_t<false, false>(a, s);
-    ProfScope ps(PK_FFN_FUSED, M, ff, 256, M_dev, s);        // one record for the two launches
     a.M = m1;
     if (int rc = launch_ffn_t<false, false>(a, s)) return rc;
     return launch_ffn_wide(X + (size_t)m1 * ldx, ldx, W1, b1, W2, b2, ln_g, ln_b, OUT + (size_t)m1 * ldo, ldo, M - m1, M_dev, ff,
@@ -650,7 +650,6 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
     if (int rc = launch_ffn_nw<true, false, 8>(a, s, &n_cu)) return rc;
     const int m1 = ffn_full_round_rows(M, n_cu, ff);
     if (m1 == M) return launch_ffn_t<true, false>(a, s);
-    ProfScope ps(PK_FFN_PROJ, M, ff, 256, M_dev, s);         // one record for the two launches
     a.M = m1;
     if (int rc = launch_ffn_t<true, false>(a, s)) return rc;
     return launch_proj_ffn_wide(A + (size_t)m1 * lda, lda, Wo, bo, r_idx ? R : R + (size_t)m1 * ldr, ldr, pg, pb, W1, b1, W2, b2,

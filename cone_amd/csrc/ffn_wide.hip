@@ -296,7 +296,7 @@ static int launch_wide_t(const FfnWideArgs& a, hipStream_t s) {
     CONE_CHECK_HIP(device_once(once, [] {
         return hipFuncSetAttribute((const void*)ffn_wide_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }));
-    ProfScope ps(PROJ ? PK_FFN_PROJ : PK_FFN_FUSED, a.M, a.ff, 256, a.M_dev, s);
+    ProfScope ps(PROJ ? PK_FFN_PROJ_WIDE : PK_FFN_WIDE, a.M, a.ff, 256, a.M_dev, s, a.m_off);
     hipLaunchKernelGGL((ffn_wide_kernel<PROJ>), dim3((unsigned)((a.M + 15) / 16)), dim3(512), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;

@@ -773,7 +773,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             const int64_t m1 = G / n_cu * n_cu / nc * RT_BM;          // rows of the full rounds of 128-row tiles
             const int64_t rem = a.M - m1;
             if (m1 > 0 && rem > 0 && (rem + 15) / 16 * nc <= CONE_RS_SPLIT_WGS) {
-                ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);     // one record for the two launches
                 GemmArgs h = a;
                 h.M = (int)m1;
                 h.variant = GEMM_ROWS8;                               // (the full rounds: no further split)
@@ -786,7 +785,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         }
         if (small_ok && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS) {
             // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)
-            ProfScope ps(PK_GEMM_ROWS16, a.M, a.N, a.K, a.M_dev, s);
+            ProfScope ps(PK_GEMM_ROWS_SMALL, a.M, a.N, a.K, a.M_dev, s, a.m_off);
             hipLaunchKernelGGL(gemm_rows_small_kernel, dim3((unsigned)((a.M + 15) / 16), (unsigned)(a.N / RT_BN)), dim3(512),
                                rs_lds_bytes(a.K), s, a);
             CONE_LAUNCH_CHECK();

@@ -60,7 +60,7 @@ __device__ void block_nms(const double* st, const double* ed, const int* sidx, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_nms_kernel(const T* __restrict__ cand,
+__global__ __launch_bounds__(256) void fuse_nms_kernel(const T* __restrict__ cand, const int64_t* __restrict__ cand_off,
                                                        const int* __restrict__ n_valid, int nq, int n_max,
                                                        double thd, int max_before, int max_after,
                                                        double* out_rows, int* out_n, int* out_idx) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void fuse_nms_kernel(const T* __restrict__ can
     __shared__ int s_nu, s_kept_n;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(n_valid[q], n_max);
-    const T* cq = cand + (size_t)q * n_max * 4;
+    const T* cq = cand + (cand_off ? (size_t)cand_off[q] : (size_t)q * n_max) * 4;
 
     // 1. float(f"{e:.4f}")
     for (int i = tid; i < n; i += 256) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(const float* __restri
 }  // namespace cone
 
 template <typename T>
-static int fuse_nms_launch(const T* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
+static int fuse_nms_launch(const T* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max, double nms_thd,
                            int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
                            void* stream) {
     CONE_REQUIRE(cand && n_valid && out_rows && out_n && out_idx, "fuse_nms: null argument");
@@ -246,23 +246,23 @@ static int fuse_nms_launch(const T* cand, const int32_t* n_valid, int nq, int n_
                  cone::kMaxCand);
     CONE_REQUIRE(max_after >= 1 && max_after <= cone::kMaxCand && max_before >= 1, "fuse_nms: bad limits");
     if (nq <= 0) return 0;
-    hipLaunchKernelGGL(cone::fuse_nms_kernel<T>, dim3(nq), dim3(256), 0, (hipStream_t)stream, cand, n_valid, nq,
+    hipLaunchKernelGGL(cone::fuse_nms_kernel<T>, dim3(nq), dim3(256), 0, (hipStream_t)stream, cand, cand_off, n_valid, nq,
                        n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx);
     CONE_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int cone_fuse_nms(const float* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
-                             int max_before, int max_after, double* out_rows, int32_t* out_n,
+extern "C" int cone_fuse_nms(const float* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max,
+                             double nms_thd, int max_before, int max_after, double* out_rows, int32_t* out_n,
                              int32_t* out_idx, void* stream) {
-    return fuse_nms_launch(cand, n_valid, nq, n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx,
+    return fuse_nms_launch(cand, cand_off, n_valid, nq, n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx,
                            stream);
 }
 
-extern "C" int cone_fuse_nms_f64(const double* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
-                                 int max_before, int max_after, double* out_rows, int32_t* out_n,
+extern "C" int cone_fuse_nms_f64(const double* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max,
+                                 double nms_thd, int max_before, int max_after, double* out_rows, int32_t* out_n,
                                  int32_t* out_idx, void* stream) {
-    return fuse_nms_launch(cand, n_valid, nq, n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx,
+    return fuse_nms_launch(cand, cand_off, n_valid, nq, n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx,
                            stream);
 }
 

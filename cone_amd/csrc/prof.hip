@@ -7,7 +7,7 @@
 
 namespace cone {
 
-struct ProfRec { hipEvent_t e0, e1; int kind; int64_t a, b, c; int m_slot; };
+struct ProfRec { hipEvent_t e0, e1; int kind; int64_t a, b, c; int m_slot; int64_t a_off; };
 
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
@@ -31,11 +31,11 @@ static hipEvent_t take_event() {
 // records nothing: the outer record covers both launches.
 static int g_depth = 0;
 
-ProfScope::ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s) : idx_(-1), s_(s), counted_(false) {
+ProfScope::ProfScope(int kind, int64_t a, int64_t b, int64_t c, const int* a_dev, hipStream_t s, int64_t a_off) : idx_(-1), s_(s), counted_(false) {
     if (!g_on) return;
     counted_ = true;
     if (g_depth++ > 0) return;
-    ProfRec r{take_event(), take_event(), kind, a, b, c, -1};
+    ProfRec r{take_event(), take_event(), kind, a, b, c, -1, a_off};
     if (!r.e0 || !r.e1) return;
     if (a_dev && g_host_m && g_host_m_used < g_host_m_cap) {
         r.m_slot = g_host_m_used++;
@@ -75,7 +75,7 @@ extern "C" int64_t cone_prof_collect(double* out, int64_t max_rec) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { set_error("prof_collect: elapsed failed"); return CONE_E_HIP; }
         int64_t a = r.a;
-        if (r.m_slot >= 0) { const int md = g_host_m[r.m_slot]; a = md < a ? md : a; }
+        if (r.m_slot >= 0) { int64_t md = (int64_t)g_host_m[r.m_slot] - r.a_off; md = md < 0 ? 0 : md; a = md < a ? md : a; }
         double* o = out + n * 5;
         o[0] = r.kind; o[1] = (double)a; o[2] = (double)r.b; o[3] = (double)r.c; o[4] = ms;
         ++n;

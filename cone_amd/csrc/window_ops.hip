@@ -394,13 +394,18 @@ extern "C" int cone_compose_rows(const float* logits, const float* spans, const 
     return 0;
 }
 
-// A5 -- eval branch of StartEndDataset.__getitem__ + collate (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-344)
-// for a DENSE window list (every query owns exactly K selected windows, row b = query b / K, rank slot b % K): the
-// window's clip range, its text range and -- hazard H3 -- the zero-padded clip length of its reference batch (the
-// longest window among the eval_bsz consecutive queries of the SPLIT that the query belongs to).
+// A5 -- eval branch of StartEndDataset.__getitem__ + collate (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-344):
+// the window's clip range, its text range and -- hazard H3 -- the zero-padded clip length of its reference batch (the
+// longest window among the eval_bsz consecutive queries of the SPLIT that the query belongs to).  Row b of the window list
+// is (query row_q[b], rank slot row_slot[b]) -- the list's shape is HOST metadata: a query owns min(K, ceil(ctx_l / S) + 1)
+// windows, whatever the pre-filter ranks first (cone/inference.py:286-299 ranks every window of the video, the dataset takes
+// the first K: cone/ego4d_mad_dataloader.py:146) -- or, with the maps null, the dense list (b / K, b % K) of a split whose
+// videos all hold at least K windows.
 namespace cone {
 
 __global__ __launch_bounds__(256) void window_table_kernel(const int* __restrict__ win_idx, int B, int K,
+                                                           const int* __restrict__ row_q,
+                                                           const int* __restrict__ row_slot,
                                                            const int* __restrict__ q_ctx_l,
                                                            const int* __restrict__ q_vid_off,
                                                            const int* __restrict__ tok_off,
@@ -412,8 +417,8 @@ __global__ __launch_bounds__(256) void window_table_kernel(const int* __restrict
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     int vlen = 0, bid = -1;
     if (b < B) {
-        const int q = b / K;
-        const int wi = win_idx[b];
+        const int q = row_q ? row_q[b] : b / K;
+        const int wi = win_idx[row_q ? q * K + row_slot[b] : b];
         int start = (wi - 1) * S;                   // window 0 is the half window ahead of the video (:229-234)
         int end = start + W;
         start = start < 0 ? 0 : start;
@@ -443,15 +448,16 @@ __global__ __launch_bounds__(256) void window_table_kernel(const int* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void window_pad_kernel(int B, int K, int q_base, int eval_bsz,
+__global__ __launch_bounds__(256) void window_pad_kernel(int B, int K, const int* __restrict__ row_q, int q_base, int eval_bsz,
                                                          const int* __restrict__ batch_pad, int* __restrict__ pad_len) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) pad_len[b] = batch_pad[(b / K + q_base) / eval_bsz];
+    if (b < B) pad_len[b] = batch_pad[((row_q ? row_q[b] : b / K) + q_base) / eval_bsz];
 }
 
 }  // namespace cone
 
-extern "C" int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* q_ctx_l,
+extern "C" int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* row_q, const int32_t* row_slot,
+                                 int n_rows, const int32_t* q_ctx_l,
                                  const int32_t* q_vid_off, const int32_t* tok_off, const int32_t* tok_len, int q_base,
                                  int eval_bsz, int max_v_l, int32_t* batch_pad, int derive_pad, int n_batches,
                                  int32_t* vid_row0, int32_t* vid_len, int32_t* video_start, int32_t* pad_len,
@@ -461,15 +467,18 @@ extern "C" int cone_window_table(const int32_t* win_idx, int nq, int K, const in
     CONE_REQUIRE(K >= 1 && eval_bsz >= 1 && max_v_l >= 2 && q_base >= 0, "window_table: bad K / eval_bsz / max_v_l / q_base");
     CONE_REQUIRE((q_base + (nq > 0 ? nq - 1 : 0)) / eval_bsz < n_batches, "window_table: batch_pad holds %d batches, queries reach batch %d",
                  n_batches, (q_base + nq - 1) / eval_bsz);
-    const int B = nq * K;
+    CONE_REQUIRE((row_q == nullptr) == (row_slot == nullptr), "window_table: row_q and row_slot come together");
+    CONE_REQUIRE(row_q ? (n_rows >= 0 && (int64_t)n_rows <= (int64_t)nq * K) : n_rows == nq * K,
+                 "window_table: n_rows=%d does not fit %d queries x %d windows", n_rows, nq, K);
+    const int B = n_rows;
     if (B <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (derive_pad) CONE_CHECK_HIP(hipMemsetAsync(batch_pad, 0, sizeof(int32_t) * (size_t)n_batches, s));
-    hipLaunchKernelGGL(cone::window_table_kernel, dim3((B + 255) / 256), dim3(256), 0, s, win_idx, B, K, q_ctx_l, q_vid_off,
+    hipLaunchKernelGGL(cone::window_table_kernel, dim3((B + 255) / 256), dim3(256), 0, s, win_idx, B, K, row_q, row_slot, q_ctx_l, q_vid_off,
                        tok_off, tok_len, q_base, eval_bsz, max_v_l, max_v_l / 2, derive_pad ? batch_pad : nullptr, vid_row0,
                        vid_len, video_start, txt_row0, txt_len, cls_row);
     CONE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cone::window_pad_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, K, q_base, eval_bsz, batch_pad, pad_len);
+    hipLaunchKernelGGL(cone::window_pad_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, K, row_q, q_base, eval_bsz, batch_pad, pad_len);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -112,6 +112,17 @@ class FeatureStore:
                               tok_off=ix["tok_off"][lo:hi + 1] - t0, tok_len=ix["tok_len"][lo:hi])
         return sub
 
+    def view(self, lo: int, hi: int):
+        """``subset(self, lo, hi)``, cached on this store: a pipeline chunk or a rank's shard is the same view every step,
+        and so are the static index tables it caches on the device (annotation metadata only)."""
+        views = self.__dict__.setdefault("_views", {})
+        v = views.get((lo, hi))
+        if v is None:
+            if len(views) > 32:
+                views.clear()
+            v = views[(lo, hi)] = FeatureStore.subset(self, lo, hi)
+        return v
+
     def index_tensors(self):
         """Static per-query index metadata on the device (depends on the annotation file only)."""
         if getattr(self, "_index", None) is None:
@@ -302,28 +313,83 @@ def prefilter(model, store: FeatureStore, opt, k=None):
     return win_idx
 
 
+class Selection:
+    """Shape of a split's window list, from HOST metadata alone: the pre-filter ranks every window of the query's video
+    (cone/inference.py:286-299) and the dataset takes the first ``topk_window`` of the list (cone/ego4d_mad_dataloader.py:146),
+    so query q owns ``n_q[q] = min(K, ceil(ctx_l / S) + 1)`` rows whatever the scores are -- rows ``row_off[q] ..
+    row_off[q + 1]`` of the list, in rank order.  Nothing downstream of the pre-filter therefore needs to LOOK at its result
+    to size or order anything: no ``nonzero``, no host sync, the launch queue runs ahead of the GPU for any mix of video
+    lengths, and the step captures as a hipGraph.  ``dense``: every query owns exactly K rows (row b = (b // K, b % K)):
+    the kernels compute the map themselves and the device-side maps are never built."""
+
+    def __init__(self, store, K: int, S: int):
+        ctx = np.asarray(store.ctx_l, dtype=np.int64)[np.asarray(store.q_vid, dtype=np.int64)]
+        self.K = int(K)
+        self.n_q = np.minimum(self.K, -(-ctx // S) + 1).astype(np.int64)
+        self.row_off = np.concatenate([[0], np.cumsum(self.n_q)]).astype(np.int64)
+        self.n_rows = int(self.row_off[-1])
+        self.nq = int(self.n_q.shape[0])
+        self.dense = bool((self.n_q == self.K).all())
+        self._dev = {}
+
+    def query_of_row(self, r: int) -> int:
+        """Query that owns row r of the list (host arithmetic; r < n_rows)."""
+        return int(np.searchsorted(self.row_off, r, side="right") - 1)
+
+    def maps(self, device):
+        """(q_of, slot) int64 and (row_q, row_slot) int32 of every row, on ``device`` (uploaded once per selection;
+        the int32 pair is None for a dense list on the GPU: the kernels compute b // K, b % K)."""
+        key = ("maps", str(device))
+        hit = self._dev.get(key)
+        if hit is None:
+            q = np.repeat(np.arange(self.nq, dtype=np.int64), self.n_q)
+            slot = np.arange(self.n_rows, dtype=np.int64) - self.row_off[:-1][q]
+            q_of, sl = torch.from_numpy(q).to(device), torch.from_numpy(slot).to(device)
+            i32 = (None, None) if self.dense else (q_of.to(torch.int32), sl.to(torch.int32))
+            hit = self._dev[key] = (q_of, sl) + i32
+        return hit
+
+    def candidates(self, Nq: int, device):
+        """(cand_off int64 (nq), n_valid int32 (nq)): query q owns rows cand_off[q] .. + n_valid[q] of the flat (n_rows * Nq, 4)
+        candidate matrix -- the per-window rows ARE that matrix (a query's windows are adjacent, in rank order)."""
+        key = ("cand", int(Nq), str(device))
+        hit = self._dev.get(key)
+        if hit is None:
+            hit = self._dev[key] = (torch.from_numpy(self.row_off[:-1] * Nq).to(device),
+                                    torch.from_numpy((self.n_q * Nq).astype(np.int32)).to(device))
+        return hit
+
+
+def selection(store: FeatureStore, opt, K=None) -> Selection:
+    """The Selection of ``store`` for top-K (default opt.topk_window), cached on the store (annotation metadata only)."""
+    K = int(K or opt.topk_window)
+    S = int(opt.max_v_l / 2)
+    cache = store.__dict__.setdefault("_sel", {})
+    sel = cache.get((K, S))
+    if sel is None:
+        if len(cache) > 8:
+            cache.clear()
+        sel = cache[(K, S)] = Selection(store, K, S)
+    return sel
+
+
 def _window_geometry(store: FeatureStore, opt, win_idx):
-    """(q_of, slot, start, vlen) of every selected window, row-major over (query, rank slot)."""
-    dev = win_idx.device
+    """(q_of, slot, start, vlen) of every selected window, row-major over (query, rank slot): torch index arithmetic
+    (CPU tensors of the gloo tests; the GPU path's cross-check ``opt.window_table_torch``).  Row order from the
+    Selection -- host metadata -- never from win_idx."""
     nq, K = win_idx.shape
     W, S = opt.max_v_l, int(opt.max_v_l / 2)
     st = store.index_tensors()
-    if min(store.ctx_l) > (K - 2) * S:
-        # every video has at least K windows (ceil(ctx_l/S)+1 >= K): the table is dense, its row order is known
-        # without looking at win_idx -- no host sync, the launch queue runs ahead of the GPU
-        dense = st.get(("dense", K))
-        if dense is None:
-            ar = torch.arange(nq * K, device=dev)
-            dense = st[("dense", K)] = (ar // K, ar % K)
-        q_of, slot = dense
-        wi = win_idx.reshape(-1).to(torch.int64)
-    else:
-        q_of, slot = (win_idx >= 0).nonzero(as_tuple=True)   # row-major; the one host sync of the table
-        wi = win_idx[q_of, slot].to(torch.int64)
+    q_of, slot, _, _ = selection(store, opt, K).maps(win_idx.device)
+    wi = win_idx[q_of, slot].to(torch.int64)
     ctx_l = st["q_ctx_l"][q_of]
     start = torch.clamp((wi - 1) * S, min=0)
     end = torch.minimum((wi - 1) * S + W, ctx_l)
     return q_of, slot, start, end - start
+
+
+def _use_table_kernel(opt, win_idx):
+    return win_idx.shape[0] > 0 and win_idx.is_cuda and not getattr(opt, "window_table_torch", False)
 
 
 def reference_batch_pad(store: FeatureStore, opt, win_idx):
@@ -333,27 +399,30 @@ def reference_batch_pad(store: FeatureStore, opt, win_idx):
     mean of forward_clip_matching divides by a length clipped to that padding (cone/model.py:186-199, hazard
     H3).  Returns (ceil(nq_split / eval_bsz),) int64; entries of batches this store holds no query of are 0."""
     nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
-    nq, K = win_idx.shape
-    if nq and win_idx.is_cuda and min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2) and not getattr(opt, "window_table_torch", False):
-        return _dense_table(store, opt, win_idx, None, nb)["batch_pad"].to(torch.int64)     # one launch (cone_window_table)
+    if _use_table_kernel(opt, win_idx):
+        return _table_launch(store, opt, win_idx, None, nb)["batch_pad"].to(torch.int64)     # one launch (cone_window_table)
     q_of, _, _, vlen = _window_geometry(store, opt, win_idx)
     bid = (q_of + store.q_base) // opt.eval_bsz
     return torch.zeros(nb, dtype=torch.int64, device=win_idx.device).scatter_reduce_(0, bid, vlen, reduce="amax")
 
 
-def _dense_table(store: FeatureStore, opt, win_idx, batch_pad, nb):
-    """cone_window_table on a dense selection (every query owns exactly K windows): the table columns + ``batch_pad``."""
+def _table_launch(store: FeatureStore, opt, win_idx, batch_pad, nb):
+    """cone_window_table over the Selection's row list: the table columns + ``batch_pad``."""
     st = store.index_tensors()
     i32 = st.get("i32")
     if i32 is None:
         i32 = st["i32"] = tuple(st[k].to(torch.int32).contiguous() for k in ("q_ctx_l", "q_vid_off", "tok_off", "tok_len"))
     bp = None if batch_pad is None else batch_pad.to(torch.int32).contiguous()
-    return ops.window_table_dense(win_idx.contiguous(), *i32, store.q_base, opt.eval_bsz, opt.max_v_l, bp, nb)
+    _, _, row_q, row_slot = selection(store, opt, win_idx.shape[1]).maps(win_idx.device)
+    return ops.window_table_rows(win_idx.contiguous(), *i32, store.q_base, opt.eval_bsz, opt.max_v_l, bp, nb,
+                                 row_q=row_q, row_slot=row_slot)
 
 
 def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
     """Eval branch of StartEndDataset.__getitem__ + collate (dataloader :144-159, 229-234, 305-344)
-    as index arithmetic on the device: one row per (query, selected window), in annotation order.
+    as index arithmetic on the device: one row per (query, selected window), in annotation order -- for ANY mix of video
+    lengths (a video of fewer than K windows contributes all of them; ``win_idx`` holds a query's valid entries first, the
+    -1 tail is never read), with the row order taken from host metadata (``Selection``): nothing synchronises.
 
     ``batch_pad`` = reference_batch_pad() of the whole split.  Without it the padding is derived from the
     windows of ``store`` alone, which is only the reference's when ``store`` holds whole reference batches --
@@ -365,16 +434,11 @@ def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
         if store.q_base % opt.eval_bsz or (hi % opt.eval_bsz and hi != store.nq_split):
             raise ValueError(f"queries [{store.q_base}, {hi}) of a {store.nq_split}-query split cut a reference "
                              f"batch (eval_bsz {opt.eval_bsz}): pass batch_pad=reference_batch_pad(split, ...)")
-    if nq and win_idx.is_cuda and min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2) and not getattr(opt, "window_table_torch", False):
-        # dense selection (every video has at least K windows): the whole table is one launch (cone_window_table)
-        dense = st.get(("dense", K))
-        if dense is None:
-            ar = torch.arange(nq * K, device=win_idx.device)
-            dense = st[("dense", K)] = (ar // K, ar % K)
+    if _use_table_kernel(opt, win_idx):
         nb = (store.nq_split + opt.eval_bsz - 1) // opt.eval_bsz
-        wt = _dense_table(store, opt, win_idx, batch_pad, nb)
+        wt = _table_launch(store, opt, win_idx, batch_pad, nb)          # the whole table is one launch
         wt.pop("batch_pad")
-        wt["q_of"], wt["slot"] = dense
+        wt["q_of"], wt["slot"] = selection(store, opt, K).maps(win_idx.device)[:2]
         return wt
     q_of, slot, start, vlen = _window_geometry(store, opt, win_idx)
     voff = st["q_vid_off"][q_of]
@@ -569,26 +633,18 @@ def write_submissions(opt, fusion, proposal, matching, save_submission_filename)
     return paths
 
 
-def candidate_lists(rows, wt, win_idx, Nq, dense=False):
-    """Per-window rows (Nw, Nq, 4) -> per-query candidate lists (nq, K*Nq, 4) in (window rank, slot) order --
-    the order cone/inference.py:141-149 extends ``predicted_times`` in -- and their valid counts.  ``dense`` (every
-    query owns exactly K windows, host-known): the rows already ARE that layout -- a view, no scatter."""
-    nq, K = win_idx.shape
-    if dense and rows.shape[0] == nq * K:
-        key = ("n_valid", nq, K * Nq, str(rows.device))
-        n_valid = _CONST.get(key)
-        if n_valid is None:
-            if len(_CONST) > 64:
-                _CONST.clear()
-            n_valid = _CONST[key] = torch.full((nq,), K * Nq, dtype=torch.int32, device=rows.device)
-        return rows.reshape(nq, K * Nq, 4), n_valid
-    cand = torch.zeros(nq, K * Nq, 4, dtype=rows.dtype, device=rows.device)
-    cand.view(nq, K, Nq, 4)[wt["q_of"], wt["slot"]] = rows
-    n_valid = ((win_idx >= 0).sum(1) * Nq).to(torch.int32)
-    return cand, n_valid
-
-
-_CONST = {}     # small constant device tensors keyed by shape (valid counts of dense selections)
+def candidate_lists(rows, store: FeatureStore, opt, K: int):
+    """Per-window rows (Nw, Nq, 4) -> the per-query candidate lists in (window rank, slot) order -- the order
+    cone/inference.py:141-149 extends ``predicted_times`` in.  A query's windows are adjacent rows of the list, in rank
+    order, so the rows already ARE the lists: returns ``(cand (Nw * Nq, 4) view, cand_off (nq) int64, n_valid (nq) int32,
+    n_max)`` for ``ops.fuse_nms(cand, n_valid, ..., cand_off=cand_off, n_max=n_max)`` -- no scatter, no padded copy, for any
+    mix of video lengths (offsets and counts are host metadata, uploaded once per store)."""
+    sel = selection(store, opt, K)
+    Nq = int(rows.shape[1])
+    if rows.shape[0] != sel.n_rows:
+        raise ValueError(f"{rows.shape[0]} window rows for a selection of {sel.n_rows}")
+    cand_off, n_valid = sel.candidates(Nq, rows.device)
+    return rows.reshape(-1, 4), cand_off, n_valid, sel.K * Nq
 
 
 @torch.no_grad()
@@ -596,18 +652,18 @@ def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=Non
     """Stages A->C on the device only: returns the kept rows per query as tensors
     (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables.  ``win_idx`` /
     ``batch_pad`` / ``video``: results of prefilter / reference_batch_pad / project_video on the split ``store``
-    was cut from (a view shares them instead of recomputing them over the whole arena)."""
+    was cut from (a view shares them instead of recomputing them over the whole arena).  Nothing in here synchronises
+    with the device or reads a result back, whatever the video lengths (``Selection``)."""
     if win_idx is None:
         win_idx = prefilter(model, store, opt)
     wt = window_table(store, opt, win_idx, batch_pad)
     res = run_windows(model, store, opt, wt, project_features(model, store, video))
     rows = res["rows"]
-    K = win_idx.shape[1]
-    dense = min(store.ctx_l) > (K - 2) * int(opt.max_v_l / 2)            # host metadata: every video holds K windows
-    cand, n_valid = candidate_lists(rows, wt, win_idx, model.num_queries, dense)
-    out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
-    return dict(rows=out_rows, n=out_n, idx=out_idx, win_idx=win_idx, windows=wt, cand=cand,
-                n_windows=int(rows.shape[0]), outputs=res)
+    cand, cand_off, n_valid, n_max = candidate_lists(rows, store, opt, win_idx.shape[1])
+    out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms,
+                                            cand_off=cand_off, n_max=n_max)
+    return dict(rows=out_rows, n=out_n, idx=out_idx, win_idx=win_idx, windows=wt, cand=cand, cand_off=cand_off,
+                n_valid=n_valid, n_windows=int(rows.shape[0]), outputs=res)
 
 
 @contextlib.contextmanager
@@ -661,6 +717,7 @@ def result_skeletons(ann, opt):
 
 
 _PT_KEY = "predicted_times"
+_PYLISTS_WARNED = False
 
 
 def _format_results(ann, opt, rows, n, skeletons=None):
@@ -674,7 +731,20 @@ def _format_results(ann, opt, rows, n, skeletons=None):
         return out
     rows_h = np.ascontiguousarray(rows.detach().cpu().numpy(), dtype=np.float64)
     n_h = np.ascontiguousarray(n.detach().cpu().numpy(), dtype=np.int32)
-    fill = _lib.pylists().cone_fill_predicted_times
+    try:
+        fill = _lib.pylists().cone_fill_predicted_times
+    except (_lib.ConeHipError, OSError, AttributeError) as e:
+        # host-side helper only (plain C against Python.h, no GPU code): without it the same lists come from tolist() +
+        # a Python loop -- slower, same values; the HIP library itself has no fallback anywhere
+        global _PYLISTS_WARNED
+        if not _PYLISTS_WARNED:
+            _PYLISTS_WARNED = True
+            warnings.warn(f"_cone_pylists.so unavailable ({e}); building the submission lists in Python")
+        lists = _rows_to_lists(torch.from_numpy(rows_h), torch.from_numpy(n_h))
+        for t in range(3):
+            for item, pt in zip(out[t], lists[t]):
+                item[_PT_KEY] = pt
+        return out
     for t in range(3):
         fill(out[t], rows_h[t].ctypes.data, n_h[t].ctypes.data, nq, A, _PT_KEY)
     return out
@@ -725,10 +795,8 @@ def _graph_replay(model, store: FeatureStore, opt):
     eager warm-up (allocations, position tables, LDS attributes) the same call runs under stream capture; the store's
     arenas are the graph's inputs (refill them in place -- ``vid_raw.copy_`` / ``tok_raw.copy_`` / ``cls_raw.copy_`` --
     for new features of the same shapes), the returned tensors its outputs (valid until the next replay).
-    Only dense selections (every video holds at least top-k windows: no data-dependent size anywhere)."""
-    K, S = opt.topk_window, int(opt.max_v_l / 2)
-    if min(store.ctx_l) <= (K - 2) * S:
-        raise ValueError("hip_graph needs a dense window selection (every video at least topk_window windows)")
+    Any mix of video lengths: the shape of the window list is host metadata (``Selection``), so there is no data-dependent
+    size anywhere."""
     cache = store.__dict__.setdefault("_graphs", {})
     key = _graph_key(model, opt)
     hit = cache.get(key)
@@ -780,7 +848,7 @@ def predict_split(model, store: FeatureStore, opt):
     video = project_video(model, store)
     pend = []
     for lo, hi in chunks:
-        sub = FeatureStore.subset(store, lo, hi)
+        sub = store.view(lo, hi)        # cached: the view's static index tables are uploaded once, not once per step
         dp = device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi], video=video)
         host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
                 for t in (dp["rows"], dp["n"])]

@@ -87,21 +87,23 @@ def topk_windows(win_scores: torch.Tensor, k: int):
     return idx, val
 
 
-def window_table_dense(win_idx, q_ctx_l, q_vid_off, tok_off, tok_len, q_base: int, eval_bsz: int, max_v_l: int,
-                       batch_pad=None, n_batches: int = 0):
-    """A5 for a dense selection (every query owns exactly K windows), one launch instead of ~50 index operations.
-    win_idx (nq, K) int32; the per-query vectors int32.  batch_pad (n_batches) int32 = the split's padding table, or
-    None: derived from these windows (whole reference batches only).  Returns a dict of (nq * K) int32 columns +
-    ``batch_pad``."""
+def window_table_rows(win_idx, q_ctx_l, q_vid_off, tok_off, tok_len, q_base: int, eval_bsz: int, max_v_l: int,
+                      batch_pad=None, n_batches: int = 0, row_q=None, row_slot=None):
+    """A5 in one launch instead of ~50 index operations.  win_idx (nq, K) int32; the per-query vectors int32.  The window
+    list is (row_q[b], row_slot[b]) (int32 maps from host metadata: a query owns min(K, windows of its video) rows), or the
+    dense list of nq * K rows when both are None.  batch_pad (n_batches) int32 = the split's padding table, or None: derived
+    from these windows (whole reference batches only).  Returns a dict of (n_rows) int32 columns + ``batch_pad``."""
     lib = _lib.load()
     nq, K = win_idx.shape
     dev = win_idx.device
-    out = torch.empty(7, nq * K, dtype=torch.int32, device=dev)
+    n_rows = nq * K if row_q is None else int(row_q.shape[0])
+    out = torch.empty(7, n_rows, dtype=torch.int32, device=dev)
     derive = batch_pad is None
     if derive:
         batch_pad = torch.empty(n_batches, dtype=torch.int32, device=dev)
     p = _lib.ptr
-    _lib.check(lib.cone_window_table(p(win_idx, torch.int32), nq, K, p(q_ctx_l, torch.int32), p(q_vid_off, torch.int32),
+    _lib.check(lib.cone_window_table(p(win_idx, torch.int32), nq, K, p(row_q, torch.int32), p(row_slot, torch.int32), n_rows,
+                                     p(q_ctx_l, torch.int32), p(q_vid_off, torch.int32),
                                      p(tok_off, torch.int32), p(tok_len, torch.int32), int(q_base), int(eval_bsz),
                                      int(max_v_l), p(batch_pad, torch.int32), int(derive), int(batch_pad.numel()),
                                      *(p(out[i]) for i in range(7)), _lib.stream()))
@@ -123,20 +125,27 @@ def compose_rows(logits, spans, match, duration, video_start, clip_length: float
     return rows
 
 
-def fuse_nms(cand: torch.Tensor, n_valid: torch.Tensor, nms_thd: float, max_before: int, max_after: int):
+def fuse_nms(cand: torch.Tensor, n_valid: torch.Tensor, nms_thd: float, max_before: int, max_after: int,
+             cand_off: torch.Tensor = None, n_max: int = None):
     """Rounding + fusion + dict collapse + 3x NMS for nq queries (cone/inference.py:83,103-127,205-217).
 
-    cand (nq, n_max, 4) fp32 (or fp64 rows that are already rounded), n_valid (nq,) int32.  Returns
-      rows (3, nq, max_after, 5) fp64, n (3, nq) int32, idx (3, nq, max_after) int32
+    cand (nq, n_max, 4) fp32 (or fp64 rows that are already rounded), n_valid (nq,) int32 -- or ``cand_off`` (nq,) int64
+    given: cand is ONE (rows, 4) matrix and query q owns rows cand_off[q] .. + n_valid[q] of it (at most ``n_max``).
+    Returns rows (3, nq, max_after, 5) fp64, n (3, nq) int32, idx (3, nq, max_after) int32
     in the order fused / proposal / matching."""
     lib = _lib.load()
-    nq, n_max, _ = cand.shape
+    if cand_off is None:
+        nq, n_max, _ = cand.shape
+    else:
+        nq = int(n_valid.shape[0])
+        if n_max is None or cand.dim() != 2 or cand.shape[1] != 4:
+            raise ValueError("fuse_nms with cand_off takes a (rows, 4) matrix and the bound n_max")
     dev = cand.device
     rows = torch.zeros(3, nq, max_after, 5, dtype=torch.float64, device=dev)
     n = torch.zeros(3, nq, dtype=torch.int32, device=dev)
     idx = torch.full((3, nq, max_after), -1, dtype=torch.int32, device=dev)
     fn = lib.cone_fuse_nms_f64 if cand.dtype == torch.float64 else lib.cone_fuse_nms
-    _lib.check(fn(_lib.ptr(cand), _lib.ptr(n_valid, torch.int32), nq, n_max, float(nms_thd), int(max_before),
+    _lib.check(fn(_lib.ptr(cand), _lib.ptr(cand_off, torch.int64), _lib.ptr(n_valid, torch.int32), nq, int(n_max), float(nms_thd), int(max_before),
                   int(max_after), _lib.ptr(rows), _lib.ptr(n), _lib.ptr(idx), _lib.stream()))
     return rows, n, idx
 

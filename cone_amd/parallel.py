@@ -160,16 +160,6 @@ def run_query_sharded(n_queries: int, compute_kept: Callable[[int, int], Tuple[t
     return unpack_kept(all_gather_fixed(pack_kept(rows, n), n_queries, group, virtual))
 
 
-def assemble_candidates(rows_all: torch.Tensor, q_of: torch.Tensor, slot: torch.Tensor, nq: int, K: int):
-    """Scatter the gathered per-window rows (Nw, Nq, 4) into per-query candidate lists
-    (nq, K*Nq, 4) in (window rank, slot) order -- the order cone/inference.py:141-149 extends
-    ``predicted_times`` in."""
-    Nq = rows_all.shape[1]
-    cand = torch.zeros(nq, K * Nq, 4, dtype=rows_all.dtype, device=rows_all.device)
-    cand.view(nq, K, Nq, 4)[q_of, slot] = rows_all
-    return cand
-
-
 # ---------------------------------------------------------------------------------- ctx-sharded pre-filter
 def ctx_shard(ctx_l: int, max_v_l: int, rank: int, world: int) -> Tuple[int, int, int, int]:
     """Window range [w_lo, w_hi) owned by `rank` and the clip rows [f_lo, f_hi) those windows read
@@ -279,9 +269,12 @@ class HipHooks:
         from . import inference as inf
         return inf.run_windows(self.model, store, opt, wt, inf.project_features(self.model, store, video))["rows"]
 
-    def fuse_nms(self, cand, n_valid, opt):
+    def fuse_nms(self, cand, n_valid, opt, cand_off=None, n_max=None):
+        """cand (nq, n_max, 4), or -- cand_off given -- ONE (rows, 4) matrix of which query q owns rows cand_off[q] .. +
+        n_valid[q] (the gathered per-window rows as they are: inference.candidate_lists)."""
         from . import ops
-        rows, n, _ = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms)
+        rows, n, _ = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms, cand_off=cand_off,
+                                  n_max=n_max)
         return rows, n
 
 
@@ -312,25 +305,20 @@ def prefilter_one_video_ctx_sharded(store, opt, hooks, group=None):
     return idx.contiguous()
 
 
-def _dense_host(store, opt):
-    """Every video holds at least topk_window windows (host metadata only): the window list is (query, rank slot)
-    row-major whatever the pre-filter selects, so shard cuts and candidate layout are known before stage A runs."""
-    return min(store.ctx_l) > (opt.topk_window - 2) * int(opt.max_v_l / 2)
-
-
 @torch.no_grad()
-def _window_sharded_dense(store, opt, hooks, group, virtual, format_shard):
-    """Window-sharded stages A->C for a dense selection (the Ego4D / MAD splits: every video longer than top-k half
-    windows).  NOTHING of stage A or of the window table is replicated: row r of the window list belongs to query r // K, so
-    a rank knows its queries [a, b] from the cut alone and runs the pre-filter, the window table and the reference-batch
-    padding (hazard H3) only for the eval_bsz-ALIGNED hull of that range -- whole reference batches, hence the split's
-    own padding -- then the window model on its slice.  ONE fixed-size all_gather of the proposal rows; the gathered
-    (n_win, Nq, 4) buffer IS the (nq, K Nq, 4) candidate layout (no scatter); fusion + NMS of all queries on every rank."""
+def _window_sharded(store, opt, hooks, group, virtual, format_shard):
+    """Window-sharded stages A->C with the replicated-feature store (an Ego4D / MAD split of many videos), for ANY mix of
+    video lengths.  NOTHING of stage A or of the window table is replicated: the shape of the window list is host metadata
+    (``inference.Selection``: query q owns rows row_off[q] .. row_off[q + 1]), so a rank knows its queries [a, b] from the
+    cut alone and runs the pre-filter, the window table and the reference-batch padding (hazard H3) only for the
+    eval_bsz-ALIGNED hull of that range -- whole reference batches, hence the split's own padding -- then the window model on
+    its slice.  ONE fixed-size all_gather of the proposal rows; the gathered (n_win, Nq, 4) buffer IS the per-query candidate
+    layout (a query's windows are adjacent: offsets + counts, no scatter); fusion + NMS of all queries on every rank."""
     from . import inference as inf
     rank, world = _rank_world(group, virtual)
     nq, K, Nq, bsz = len(store.ann), opt.topk_window, hooks.num_queries, opt.eval_bsz
-    n_win = nq * K
-    lo, hi = shard_range(n_win, rank, world)
+    sel = inf.selection(store, opt, K)
+    n_win = sel.n_rows
     dev = store.vid_raw.device
     win_hull, hull = None, (0, 0)
 
@@ -338,26 +326,20 @@ def _window_sharded_dense(store, opt, hooks, group, virtual, format_shard):
         nonlocal win_hull, hull
         if hi == lo:
             return torch.zeros(0, Nq, 4, device=dev)
-        a, b = lo // K, (hi - 1) // K
+        a, b = sel.query_of_row(lo), sel.query_of_row(hi - 1)
         ha, hb = (a // bsz) * bsz, min(nq, -(-(b + 1) // bsz) * bsz)
         # the two views (and the static index tables they cache on the device) depend on the annotations and the cut
         # only: built once per (store, cut), not once per step
-        views = store.__dict__.setdefault("_shard_views", {})
-        key = (a, b, ha, hb)
-        if key not in views:
-            if len(views) > 16:
-                views.clear()
-            views[key] = (inf.FeatureStore.subset(store, ha, hb), inf.FeatureStore.subset(store, a, b + 1))
-        hull_store, sub = views[key]
+        hull_store, sub = store.view(ha, hb), store.view(a, b + 1)
         win_hull, hull = hooks.prefilter(hull_store, opt), (ha, hb)
         wt = inf.window_table(hull_store, opt, win_hull)            # whole reference batches: the split's padding
         video = hooks.project_video(store, _video_row_range(store, a, b + 1))
-        table = _slice_table(wt, lo - ha * K, hi - ha * K, a - ha, int(store.tok_off[a]) - int(store.tok_off[ha]))
+        r0 = int(sel.row_off[ha])                                   # first row of the hull's table in the split's list
+        table = _slice_table(wt, lo - r0, hi - r0, a - ha, int(store.tok_off[a]) - int(store.tok_off[ha]))
         return hooks.window_rows(sub, opt, table, video)
     rows_all = run_window_sharded(n_win, rows_of, group, virtual)
-    cand = rows_all.reshape(nq, K * Nq, 4)
-    n_valid = torch.full((nq,), K * Nq, dtype=torch.int32, device=cand.device)
-    rows, n = hooks.fuse_nms(cand, n_valid, opt)        # every rank, all queries: cheaper than a second collective
+    cand, cand_off, n_valid, n_max = inf.candidate_lists(rows_all, store, opt, K)
+    rows, n = hooks.fuse_nms(cand, n_valid, opt, cand_off, n_max)   # every rank, all queries: cheaper than a second collective
     q_lo, q_hi = shard_range(nq, rank, world)
     info = dict(rows=rows, n=n, win_idx=win_hull, win_idx_range=hull, n_windows=n_win, shard=(q_lo, q_hi), world=world)
     if format_shard:
@@ -381,9 +363,10 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     ``virtual=(rank, world)``: replay what that rank of a `world`-rank run computes, on one GPU and without a process
     group -- the gathers are filled with copies of the local shard (bench.py's ``shard_proxy_8``; replicated stage A only).
 
-    Window mode on a dense selection with the replicated pre-filter takes ``_window_sharded_dense``: stage A and the
-    window table run only for the rank's own (batch-aligned) query range -- ``info['win_idx']`` then holds the window table
-    of queries ``info['win_idx_range']`` instead of the whole split's.
+    Window mode with the replicated pre-filter takes ``_window_sharded``: stage A and the window table run only for the
+    rank's own (batch-aligned) query range -- ``info['win_idx']`` then holds the window table of queries
+    ``info['win_idx_range']`` instead of the whole split's.  Every cut point comes from host metadata (the shape of the
+    window list does not depend on the scores): no rank ever reads a device result back to find its share.
 
     Returns ``(lists, info)``: ``info['rows'] / info['n']`` = the kept rows of ALL queries, on every rank (tensors);
     ``lists`` = the three submission lists -- of all queries on rank 0 and ``None`` elsewhere, or, with
@@ -394,8 +377,8 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     rank, world = _rank_world(group, virtual)
     nq = len(store.ann)
     Nq = hooks.num_queries
-    if mode == "window" and prefilter == "replicated" and _dense_host(store, opt):
-        return _window_sharded_dense(store, opt, hooks, group, virtual, format_shard)
+    if mode == "window" and prefilter == "replicated":
+        return _window_sharded(store, opt, hooks, group, virtual, format_shard)
     if prefilter == "ctx":
         if virtual is not None:
             raise ValueError("virtual ranks replay the replicated pre-filter only")
@@ -405,6 +388,7 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     else:
         raise ValueError(f"unknown pre-filter mode {prefilter!r}")
     batch_pad = inf.reference_batch_pad(store, opt, win_idx)
+    sel = inf.selection(store, opt, win_idx.shape[1])       # the list's shape: host metadata, whatever win_idx holds
     q_lo, q_hi = shard_range(nq, rank, world)
     if mode == "query":
         def kept(lo, hi):
@@ -412,31 +396,33 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
                 A = opt.max_after_nms
                 return (torch.zeros(3, 0, A, 5, dtype=torch.float64, device=win_idx.device),
                         torch.zeros(3, 0, dtype=torch.int32, device=win_idx.device))
-            sub = inf.FeatureStore.subset(store, lo, hi)
+            sub = store.view(lo, hi)
             wi = win_idx[lo:hi].contiguous()
             wt = inf.window_table(sub, opt, wi, batch_pad)
             vid_rows = _video_row_range(store, lo, hi)
             rows = hooks.window_rows(sub, opt, wt, hooks.project_video(store, vid_rows))
-            cand, n_valid = inf.candidate_lists(rows, wt, wi, Nq)
-            return hooks.fuse_nms(cand, n_valid, opt)
+            cand, cand_off, n_valid, n_max = inf.candidate_lists(rows, sub, opt, wi.shape[1])
+            return hooks.fuse_nms(cand, n_valid, opt, cand_off, n_max)
         rows, n = run_query_sharded(nq, kept, group, virtual)
-        n_windows = int((win_idx >= 0).sum()) if not _dense(store, opt, win_idx) else nq * win_idx.shape[1]
+        n_windows = sel.n_rows
     elif mode == "window":
         wt = inf.window_table(store, opt, win_idx, batch_pad)
-        n_win = int(wt["vid_row0"].shape[0])
-        lo, hi = shard_range(n_win, rank, world)
+        n_win = sel.n_rows
 
         def rows_of(lo, hi):
             if hi == lo:
                 return torch.zeros(0, Nq, 4, device=win_idx.device)
             # the slice's queries [a, b]: only their text tokens and the clips of their videos are projected
-            a, b = _query_span(store, opt, win_idx, wt, lo, hi)
-            sub = inf.FeatureStore.subset(store, a, b + 1)
-            video = hooks.project_video(store, _window_row_range(store, opt, win_idx, wt, lo, hi, a, b))
+            a, b = sel.query_of_row(lo), sel.query_of_row(hi - 1)       # host arithmetic: no device read
+            sub = store.view(a, b + 1)
+            # the band of the videos of the slice's queries (for ONE long video that is the whole video: its top-k windows
+            # lie anywhere, and 1 / world of the windows of 64 queries already touch most clips -- 33 000 clips: 26 GFLOP of
+            # projection against 163 GFLOP of window model per rank at world 8)
+            video = hooks.project_video(store, _video_row_range(store, a, b + 1))
             return hooks.window_rows(sub, opt, _slice_table(wt, lo, hi, a, int(store.tok_off[a])), video)
         rows_all = run_window_sharded(n_win, rows_of, group, virtual)
-        cand, n_valid = inf.candidate_lists(rows_all, wt, win_idx, Nq)
-        rows, n = hooks.fuse_nms(cand, n_valid, opt)    # every rank, all queries: cheaper than a second collective
+        cand, cand_off, n_valid, n_max = inf.candidate_lists(rows_all, store, opt, win_idx.shape[1])
+        rows, n = hooks.fuse_nms(cand, n_valid, opt, cand_off, n_max)   # every rank, all queries: cheaper than a second collective
         n_windows = n_win
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
@@ -446,28 +432,6 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     if rank != 0:
         return None, info
     return inf.format_results(store.ann, opt, rows, n), info
-
-
-def _dense(store, opt, win_idx):
-    K, S = win_idx.shape[1], int(opt.max_v_l / 2)
-    return min(store.ctx_l) > (K - 2) * S
-
-
-def _query_span(store, opt, win_idx, wt, lo, hi):
-    """First and last query (annotation index) that own a window in rows [lo, hi) of the table."""
-    if _dense(store, opt, win_idx):                     # row r belongs to query r // K: no device read
-        K = win_idx.shape[1]
-        return lo // K, (hi - 1) // K
-    ends = wt["q_of"][[lo, hi - 1]].tolist()
-    return int(ends[0]), int(ends[1])
-
-
-def _window_row_range(store, opt, win_idx, wt, lo, hi, q_a, q_b):
-    """Arena rows whose projections the windows [lo, hi) of the table may read: the band of the videos of their queries
-    (host arithmetic on the annotation order: no device read, no sync).  For ONE long video that is the whole video: its
-    top-k windows lie anywhere, and 1 / world of the windows of 64 queries already touch most clips (33 000 clips: 26
-    GFLOP of projection against 163 GFLOP of window model per rank at world 8)."""
-    return _video_row_range(store, q_a, q_b + 1)
 
 
 def _video_row_range(store, q_lo, q_hi):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 3
+#define CONE_HIP_ABI_VERSION 4
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -133,16 +133,21 @@ int cone_prefilter_batched(const float* arena, int dv, const float* cls, const i
                            int32_t* topk_idx, void* stream);
 
 /* A5, eval branch of StartEndDataset.__getitem__ + collate (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-344) as
- * index arithmetic, for a DENSE selection: win_idx (nq, K) int32 holds K valid window indices per query (row b of every
- * output = query b / K, rank slot b % K).  Per-query metadata: q_ctx_l (clips of the query's video), q_vid_off (first arena
- * row of that video), tok_off / tok_len (the query's text rows).  Outputs (nq * K) int32 each: vid_row0, vid_len,
+ * index arithmetic: win_idx (nq, K) int32 holds the ranked window indices of every query, valid entries first (a video of
+ * fewer than K windows: the tail is -1 and never read).  Row b of every output is (query row_q[b], rank slot row_slot[b])
+ * -- n_rows rows in annotation order, then rank order: the shape of the list is host metadata, a query owns
+ * min(K, ceil(ctx_l / S) + 1) windows (cone/inference.py:286-299, cone/ego4d_mad_dataloader.py:146) -- or, with
+ * row_q == row_slot == NULL and n_rows == nq * K, the dense list (b / K, b % K).  Per-query metadata: q_ctx_l (clips of the
+ * query's video), q_vid_off (first arena
+ * row of that video), tok_off / tok_len (the query's text rows).  Outputs (n_rows) int32 each: vid_row0, vid_len,
  * video_start (window i covers clips [max(0, (i-1) S), min(ctx_l, (i-1) S + max_v_l)), S = max_v_l / 2), txt_row0,
  * txt_len, cls_row, and pad_len = the zero-padded clip length of the window's reference batch -- the longest window among
  * the eval_bsz consecutive queries of the SPLIT it belongs to (hazard H3: cone/model.py:186-199 divides by a length
  * clipped to it).  batch_pad (n_batches) int32 is that table, indexed by (q_base + query) / eval_bsz with q_base = the
  * first query's index in the split: derive_pad != 0 computes it from these windows (only the reference's when the
  * queries are whole reference batches -- the caller's responsibility), derive_pad == 0 reads the split's table. */
-int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* q_ctx_l, const int32_t* q_vid_off,
+int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* row_q, const int32_t* row_slot, int n_rows,
+                      const int32_t* q_ctx_l, const int32_t* q_vid_off,
                       const int32_t* tok_off, const int32_t* tok_len, int q_base, int eval_bsz, int max_v_l,
                       int32_t* batch_pad, int derive_pad, int n_batches, int32_t* vid_row0, int32_t* vid_len,
                       int32_t* video_start, int32_t* pad_len, int32_t* txt_row0, int32_t* txt_len, int32_t* cls_row,
@@ -189,7 +194,8 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
  *   layer's in_proj once per clip / per text token instead of once per window row (two M-row GEMMs, ~10 % of the
  *   FLOPs, become a gather inside the attention kernel);
  * pos_rows (R, d), R = cone_pos_table_rows(max_v_l): row Lv(Lv-1)/2 + p = PositionEmbeddingSine of clip p of a
- *   window with Lv valid clips (cone/position_encoding.py:51-72; text tokens carry no position, cone/model.py:106);
+ *   window with Lv valid clips (cone/position_encoding.py:51-72); the LAST row (R - 1) is all zeros: the position of a
+ *   text token (cone/model.py:106), added like any other row;
  * pos_qk (enc_layers, R, 2d): pos_rows [W_q | W_k]^T of every encoder layer (no bias).
  * With the tables the later encoder layers run ONE N = 3d GEMM on x (the attention kernel adds the pos_qk row to
  * q | k in its staging loads) and the decoder's cross-attention forms its keys memory + pos from pos_rows: no
@@ -239,20 +245,22 @@ int cone_compose_rows(const float* logits, const float* spans, const float* matc
 
 /* A13 rounding + A14 + A15 for nq queries at once (cone/inference.py:83,103-127,205-217;
  * utils/temporal_nms.py:25-74), all in fp64 like the reference's Python floats:
- *   cand (nq,n_max,4) fp32 rows [st,ed,prop,match], n_valid[q] rows used per query;
+ *   cand (nq,n_max,4) fp32 rows [st,ed,prop,match], n_valid[q] rows used per query -- or, cand_off != NULL (nq int64):
+ *   the candidate rows of query q are rows cand_off[q] .. + n_valid[q] of ONE (rows, 4) matrix (the per-window rows of
+ *   cone_compose_rows ARE that matrix: a query's windows are adjacent, no scatter into a padded layout);
  *   every number -> float(f"{x:.4f}"); min-max fusion; dict collapse on (st,ed);
  *   for score_idx in (2 fused, 0 proposal, 1 matching): stable sort desc, [:max_before],
  *   greedy NMS (pseudo-IoU, strict >), stop at max_after; nms_thd == -1 -> top max_after.
  * out_rows (3,nq,max_after,5) fp64 rows [st,ed,prop,match,fused]; out_n (3,nq) int32;
  * out_idx (3,nq,max_after) int32 = index into the query's cand rows (first occurrence of the key). */
-int cone_fuse_nms(const float* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
-                  int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
+int cone_fuse_nms(const float* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max,
+                  double nms_thd, int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
                   void* stream);
 
 /* Same on fp64 candidate rows (e.g. rows that went through Python and are already rounded; the
  * rounding is idempotent on them). */
-int cone_fuse_nms_f64(const double* cand, const int32_t* n_valid, int nq, int n_max, double nms_thd,
-                      int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
+int cone_fuse_nms_f64(const double* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max,
+                      double nms_thd, int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
                       void* stream);
 
 /* temporal_nms (utils/temporal_nms.py:25-74) on one list: pred (n,3) fp64 [st,ed,score];
@@ -308,7 +316,12 @@ int cone_eval_window_recall(const int32_t* win_idx, int nq, int k, const double*
  * stream, cone_prof_collect fills up to max_rec records of 5 doubles {kind, a, b, c, milliseconds}:
  * kind 0/1/2 = GEMM tiles 128x128 / 128x128 with fused addend / 64x256 with fused LayerNorm, (a,b,c) =
  * (M rows actually processed, N, K); kind 3 = encoder attention (B windows, Lmax, source mode); kind 4 = frame-score
- * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 = fused decoder cross-attention (B windows, Lmax, nq); kind 8 = fused feed-forward block (M rows, ff, 256): 4*M*ff*256 FLOPs; kind 9 = the same with the output projection: + 2*M*256*256.  Returns the record count.  Not thread-safe. */
+ * stream (ctx_l, dv, queries in the launch); kind 5/6 = 128x256 row-owning GEMM tile with 4 / 8 waves (M, N, K); kind 7 =
+ * fused decoder cross-attention (B windows, Lmax, nq); kind 8 = fused feed-forward block on the persistent 128-row grid
+ * (M rows, ff, 256): 4*M*ff*256 FLOPs; kind 9 = the same with the output projection: + 2*M*256*256.  One kind per KERNEL:
+ * kinds 10 / 11 = kinds 8 / 9 computed by the wide form (ffn_wide_kernel: launches of a few row groups and the rows past the
+ * last full round of a big launch -- a record of its own, with the rows it covered); 12 / 13 = the 64-row / 4-wave form;
+ * 14 = the row GEMM's small form (16-row tiles).  Returns the record count.  Not thread-safe. */
 int cone_prof_enable(int on);
 int64_t cone_prof_collect(double* out, int64_t max_rec);
 
@@ -381,7 +394,7 @@ int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, c
  * registers, no LDS: the same bits as the default workgroup-per-(window, head) kernel. */
 int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const float* qkv_txt, const float* pos_qk,
                        const int32_t* vrow0, const int32_t* vlen, const int32_t* trow0, const int32_t* off, float* OUT,
-                       int B, int Lmax, void* stream);
+                       int B, int Lmax, int pos_zero_row /* index of an all-zero row of pos_qk (modes 1, 2) */, void* stream);
 /* Fused decoder cross-attention of one layer (cone/transformer.py:308-311) with the memory K / V projections folded in:
  * DQ (B * nq, 256) projected queries (+ bias), X (M, 256) memory rows packed by off (B + 1), pos_rows / vlen = the sine
  * table and the clip count of each window (keys = memory + position row for clip tokens), Wk (256, 256) = rows

@@ -920,7 +920,9 @@ def test_virtual_rank_shards_reproduce_the_full_run(mode):
                 dp = inf.device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi].contiguous(), batch_pad=batch_pad,
                                          video=inf.project_video(model, store, par._video_row_range(store, lo, hi)))
                 assert torch.equal(dp["rows"], full["rows"][:, lo:hi]) and torch.equal(dp["n"], full["n"][:, lo:hi])
-                assert torch.equal(dp["cand"], full["cand"][lo:hi])
+                sel = inf.selection(store, opt)        # the shard's candidate rows = its slice of the split's flat list
+                r_lo, r_hi = int(sel.row_off[lo]) * 5, int(sel.row_off[hi]) * 5
+                assert torch.equal(dp["cand"], full["cand"][r_lo:r_hi])
         else:
             wt = full["windows"]
             n_win = int(wt["vid_row0"].shape[0])
@@ -929,7 +931,9 @@ def test_virtual_rank_shards_reproduce_the_full_run(mode):
                 lo, hi = par.shard_range(n_win, r, world)
                 if hi == lo:
                     continue
-                a, b = par._query_span(store, opt, win_idx, wt, lo, hi)
+                sel = inf.selection(store, opt)
+                a, b = sel.query_of_row(lo), sel.query_of_row(hi - 1)
+                assert (a, b) == tuple(wt["q_of"][[lo, hi - 1]].tolist())       # host arithmetic == the table on the device
                 sub = inf.FeatureStore.subset(store, a, b + 1)
                 video = hooks.project_video(store, par._video_row_range(store, a, b + 1))
                 rows = hooks.window_rows(sub, opt, par._slice_table(wt, lo, hi, a, int(store.tok_off[a])), video)
@@ -1534,6 +1538,81 @@ def test_config2_full_size():
     record_measured("config2_full_size", **{f"{k}.{kk}": vv for k, v in stats.items() for kk, vv in v.items()})
 
 
+def test_config2_ragged_full_size_is_sync_free_and_matches_oracle():
+    """BASELINE configs[1] at full size on a RAGGED split -- 1 000 queries x 50 videos with ctx_l ~ U[200, 1500): videos of
+    fewer than top-20 windows (ctx_l <= 810) sit next to long ones -- through the same sync-free path as the dense split
+    (window list shaped by host metadata: cone_amd.inference.Selection; the reference: cone/inference.py:286-299,
+    cone/ego4d_mad_dataloader.py:144-159, 229-234).  Rank lists of ALL queries against the oracle; window rows and kept
+    moments of the first reference batch and of a range cut MID-batch (split's padding table, hazard H3) against the oracle
+    run on the reference batches that contain them; the whole step equals its own hipGraph replay (which cannot contain a
+    host sync) and its chunked form."""
+    from cone_amd import inference as inf
+    model, _, sd = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32)
+    ann, vf, qf = synth.make_dataset(opt, 1000, 50, seed=11, ctx_range=(200, 1500))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    sel = inf.selection(store, opt)
+    S = int(opt.max_v_l / 2)
+    n_ref = [min(20, -(-store.ctx_l[v] // S) + 1) for v in store.q_vid.tolist()]
+    assert sel.n_q.tolist() == n_ref and not sel.dense and 0 < sum(n < 20 for n in n_ref) < 1000
+    (fusion, prop, match), info = inf.predict_split(model, store, opt)
+    assert info["n_windows"] == sel.n_rows == sum(n_ref) and len(fusion) == 1000
+    with torch.no_grad():
+        ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+    win_idx = info["win_idx"]
+    got = win_idx.cpu().tolist()
+    for qi, row in enumerate(ann):
+        ref = ranks[row["query_id"]][:20]
+        assert got[qi][:len(ref)] == ref and all(g == -1 for g in got[qi][len(ref):]) and len(ref) == n_ref[qi], qi
+    bp = inf.reference_batch_pad(store, opt, win_idx)
+    A = lambda r: np.array(r["pred_relevant_windows"])
+    sec_tol = 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
+    stats = {}
+    for (o_lo, o_hi), (lo, hi), label in (((0, 32), (0, 32), "first_batch"), ((480, 544), (490, 530), "mid_batch_cut")):
+        with torch.no_grad():
+            mr = O.compute_mr_results(sd, opt, ann[o_lo:o_hi], vf, qf, ranks)
+        r0 = int(sel.row_off[o_lo])
+        assert len(mr) == int(sel.row_off[o_hi]) - r0            # the oracle's collate drops the windows a video lacks too
+        mr = mr[int(sel.row_off[lo]) - r0:int(sel.row_off[hi]) - r0]
+        sub = inf.FeatureStore.subset(store, lo, hi)
+        wi = win_idx[lo:hi].contiguous()
+        wt = inf.window_table(sub, opt, wi, bp)
+        raw = inf.run_windows(model, sub, opt, wt)
+        rows = raw["rows"].cpu().tolist()
+        assert len(rows) == len(mr) == int(sel.row_off[hi] - sel.row_off[lo])
+        q_of = wt["q_of"].cpu().tolist()
+        mine = [[[float(f"{e:.4f}") for e in r] for r in w] for w in rows]
+        dp_, ds_, dm_bad = 0.0, 0.0, 0
+        for w, (a, b) in enumerate(zip(mine, mr)):
+            assert sub.ann[q_of[w]]["query_id"] == b["query_id"]
+            ra, rb = np.array(a), A(b)
+            dp_ = max(dp_, np.abs(ra[:, 2] - rb[:, 2]).max())
+            ds_ = max(ds_, np.abs(ra[:, :2] - rb[:, :2]).max())
+            dm_bad += int((np.abs(ra[:, 3] - rb[:, 3]) > 2e-4).sum())
+        assert dp_ <= 2e-4 and ds_ <= sec_tol, (label, dp_, ds_)
+        n_chk, n_bnd, worst_alt = check_matching_vs_own_spans(sd, opt, sub, wt, raw)
+        assert n_chk == len(rows) * 5 and worst_alt <= 1e-4, (label, n_chk, worst_alt)
+        assert dm_bad <= n_bnd, (label, dm_bad, n_bnd)
+        fo, po, mo = O.postprocess(mr, opt)
+        agree = 0
+        for a, b in zip(fusion[lo:hi], fo):
+            ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+            agree += bool(ra.shape == rb.shape and np.abs(ra - rb).max() <= sec_tol + 1e-4)
+        stats[label] = dict(worst_prop=float(dp_), worst_sec=float(ds_), matching_rows_beyond_2e4=dm_bad, boundary_proposals=n_bnd,
+                            kept_moments_agree=agree, queries=hi - lo, windows=len(rows))
+        assert agree >= CONFIG2_FLOOR * (hi - lo), (label, agree)
+        assert inf.postprocessing_format_ego4d(mr, opt) == (fo, po, mo)
+    record_measured("config2_ragged_full_size", **{f"{k}.{kk}": vv for k, v in stats.items() for kk, vv in v.items()})
+    # one chunk == the default two chunks == the hipGraph replay of the whole step (a captured stream cannot hold a sync)
+    opt.pipeline_tail = 0.0
+    one, info1 = inf.predict_split(model, store, opt)
+    assert one == (fusion, prop, match) and torch.equal(info1["rows"], info["rows"])
+    opt.hip_graph = True
+    for _ in range(2):
+        rep, info2 = inf.predict_split(model, store, opt)
+        assert rep == (fusion, prop, match) and torch.equal(info2["rows"], info["rows"]) and torch.equal(info2["n"], info["n"])
+
+
 def test_config5_64_queries_one_mad_length_video():
     """BASELINE configs[4] on one GPU: 64 concurrent queries over ONE MAD-length video (ctx_l 33 000, d 512,
     window_len 125, top-30 => 1 920 windows) end to end; rank lists of all queries and the full pipeline of a sample
@@ -1622,33 +1701,36 @@ def test_criterion_forward_matches_reference_golden(golden_dir):
 
 # ------------------------------------------------------------------------------------ bench.py launched with N > 1
 def test_bench_two_ranks_on_one_device():
-    """The driver launches bench.py for N > 1 through torch.distributed.run; a one-GPU box cannot host two RCCL ranks, so
-    this runs the SAME code path (weak step + all_gather of kept rows, strong-scaling window-sharded split, max-over-ranks
-    timing) with both ranks on cuda:0 over gloo -- the only two lines that differ are the backend name and the device id."""
-    import socket
+    """N > 1 through the PLAIN entry the driver uses for one GPU -- `python3 bench.py --gpus 2 ...`, no RANK in the
+    environment: bench.py starts its own ranks (torch.distributed.run as a child process, before any GPU call) and relays rank
+    0's line.  A one-GPU box cannot host two RCCL ranks, so this runs the SAME code path (collective preflight, weak step +
+    all_gather of kept rows, strong-scaling window-sharded split, max-over-ranks timing) with both ranks on cuda:0 over gloo
+    -- the only two lines that differ are the backend name and the device id."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, CONE_BENCH_ONE_DEVICE="1", CONE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CONE_BENCH_ONE_DEVICE="1", CONE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--queries", "96", "--videos", "6", "--mad_ctx_l", "400000"]
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["scaling"] == "weak"
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["config"]["ranks_seen"] == 2 and res["scaling"] == "weak"
+    assert res["collective_preflight"]["ok"] and res["collective_preflight"]["world"] == 2
+    assert res["ms_per_step_rank_min"] <= res["ms_per_step_rank_max"] and abs(res["ms_per_step_rank_max"] - res["ms_per_step"]) < 0.01
+    assert "aux_outputs" in res["config"]["outputs"]               # the headline computes what CONE.forward computes
     nw = int(res["config"]["workload"].split(",")[-1].split()[0])
     assert abs(res["value"] - 2 * nw * 2 / (res["ms_per_step"] * 2e-3)) < 0.01 * res["value"]       # whole-job aggregate
     st = res["strong_scaling"]
     assert st["ranks_seen"] == 2 and st["scaling"] == "strong" and st["collectives_per_step"] == 1
     assert st["n_windows"] == nw and st["value"] > 0
     assert res["roofline"]["bound"] == "mfma" and 0 < res["roofline"]["frac"] < 1
-    assert res["ms_per_step_full_forward"] > 0
+    assert res["ms_per_step_dead_work_elided"] > 0
+    wm = res["window_model"]
+    assert 0 < wm["executed_frac"] < 1 and wm["executed_tflops"] <= wm["reference_algorithmic_tflops"]
     # BASELINE configs[4] / [2] over the ranks: ctx-sharded pre-filter -> window-sharded model; ctx-sharded MAD-scale stream
     c5 = res["config5_sharded"]
     assert c5["ranks_seen"] == 2 and c5["collectives_per_step"] == 2 and c5["ms_per_step"] > 0, c5
@@ -1753,7 +1835,10 @@ def test_encoder_attention_wave_form_is_bit_identical(mode):
     Wmax = 125
     d = lambda t: t.to(dev).contiguous()
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-    pos = d(torch.randn(Wmax * (Wmax + 1) // 2, 512, generator=g))
+    zrow = Wmax * (Wmax + 1) // 2                  # the table's zero row (cone_pos_tables: the last one): a text token's
+    pos = torch.randn(zrow + 1, 512, generator=g)
+    pos[zrow] = 0
+    pos = d(pos)
     qkv_vid, qkv_txt = d(torch.randn(400, 768, generator=g)), d(torch.randn(120, 768, generator=g))
     vr, tr = i32([0, 399, 5, 100, 200, 30, 250, 7, 120, 299]), i32([0, 50, 100, 0, 30, 117, 60, 80, 10, 40])
     QKV = d(torch.randn(M, 768, generator=g))
@@ -1764,7 +1849,7 @@ def test_encoder_attention_wave_form_is_bit_identical(mode):
         out = torch.full((M + 1, 256), float("nan"), device=dev)
         _lib.check(lib.cone_test_enc_attn(mode | form, _lib.ptr(QKV), _lib.ptr(qkv_vid), _lib.ptr(qkv_txt), _lib.ptr(pos),
                                           _lib.ptr(vr), _lib.ptr(vlv), _lib.ptr(tr), _lib.ptr(offd), _lib.ptr(out), B, max(L),
-                                          _lib.stream()))
+                                          zrow, _lib.stream()))
         outs.append(out)
     torch.cuda.synchronize()
     assert not torch.isnan(outs[0][:M]).any() and bool(torch.isnan(outs[1][M:]).all())
@@ -1786,7 +1871,9 @@ def test_encoder_attention_kernel_matches_float64(mode):
     off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
     M = int(off[-1])
     Wmax = 150
-    pos = torch.randn(Wmax * (Wmax + 1) // 2, 512, generator=g)
+    zrow = Wmax * (Wmax + 1) // 2
+    pos = torch.randn(zrow + 1, 512, generator=g)
+    pos[zrow] = 0
     qkv_vid = torch.randn(400, 768, generator=g)
     qkv_txt = torch.randn(120, 768, generator=g)
     vrow0 = [0, 399, 5, 100, 200, 30, 250, 7, 120]
@@ -1817,7 +1904,7 @@ def test_encoder_attention_kernel_matches_float64(mode):
     vr, vlv, tr, offd = i32(vrow0), i32(vl), i32(trow0), torch.from_numpy(off).to(dev)
     _lib.check(lib.cone_test_enc_attn(mode, _lib.ptr(QKVd), _lib.ptr(vd), _lib.ptr(td), _lib.ptr(pd), _lib.ptr(vr),
                                       _lib.ptr(vlv), _lib.ptr(tr), _lib.ptr(offd), _lib.ptr(out), B, max(L),
-                                      _lib.stream()))
+                                      zrow, _lib.stream()))
     torch.cuda.synchronize()
     assert maxdiff(out[:M], ref) < 2e-5
     assert bool(torch.isnan(out[M:]).all())

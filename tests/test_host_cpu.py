@@ -3,6 +3,7 @@ host logic (options, synthetic data, window geometry) agrees with the oracle.  N
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -27,7 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cone_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-    assert lib.cone_abi_version() == 3
+    assert lib.cone_abi_version() == 4
     assert lib.cone_num_windows(901, 90) == 22 and lib.cone_num_windows(1250, 125) == 22
 
 
@@ -288,3 +289,26 @@ def test_query_chunks_of_the_host_gpu_pipeline():
     five = inf.query_chunks(41, make_opt("ego4d", topk_window=6, eval_bsz=4, pipeline_chunks=5))
     assert len(five) == 5 and five[0][0] == 0 and five[-1][1] == 41
     assert all(a % 4 == 0 for a, _ in five) and all(b == five[i + 1][0] for i, (_, b) in enumerate(five[:-1]))
+
+
+def test_bench_plain_entry_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no RANK in the environment (how the driver calls the one-GPU bench) must not die
+    on a WORLD_SIZE assert: it starts torch.distributed.run as a child process BEFORE any GPU call, the ranks rendezvous
+    on 127.0.0.1 and pass the collective preflight (here: gloo on CPU tensors, CONE_BENCH_LAUNCH_CHECK=1 stops there),
+    rank 0's JSON line and the exit code are relayed.  A wrong --gpus / WORLD_SIZE pair exits non-zero with a reason."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CONE_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--queries", "64"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2
+    pf = res["collective_preflight"]
+    assert pf["ok"] and pf["world"] == 2 and pf["bytes_per_rank"] == 3 * 64 * 5 * 5 * 8 + 3 * 64 * 4
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

@@ -119,13 +119,18 @@ class CheckerHooks:
             self.served += 1
         return torch.stack(out) if out else torch.zeros(0, 5, 4)
 
-    def fuse_nms(self, cand, n_valid, opt):
+    def fuse_nms(self, cand, n_valid, opt, cand_off=None, n_max=None):
         A = opt.max_after_nms
-        nq = cand.shape[0]
+        nq = int(n_valid.shape[0])
         r = torch.zeros(3, nq, A, 5, dtype=torch.float64)
         n = torch.zeros(3, nq, dtype=torch.int32)
         for qi in range(nq):
-            rd = O.score_fusion(O.round4_rows(cand[qi, :int(n_valid[qi])].tolist()))
+            if cand_off is None:
+                mine = cand[qi, :int(n_valid[qi])]
+            else:           # ONE (rows, 4) matrix: query qi owns rows cand_off[qi] .. + n_valid[qi]
+                assert cand.dim() == 2 and int(n_valid[qi]) <= n_max
+                mine = cand[int(cand_off[qi]):int(cand_off[qi]) + int(n_valid[qi])]
+            rd = O.score_fusion(O.round4_rows(mine.tolist()))
             for t, idx in enumerate((2, 0, 1)):
                 keep = O.post_processing_mr_nms(opt, rd, idx)
                 n[t, qi] = len(keep)

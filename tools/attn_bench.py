@@ -20,7 +20,8 @@ off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
 off[1:] = torch.cumsum(L, 0)
 M = int(off[-1])
 QKV = torch.randn(M, 768, device=dev, generator=g)
-pos = torch.randn(4095, 512, device=dev, generator=g)
+pos = torch.randn(4096, 512, device=dev, generator=g)
+pos[4095] = 0          # the table's zero row (a text token's position term)
 OUT = torch.empty(M, 256, device=dev)
 # gather mode: 50 videos of 900 clips, windows at stride 45; 1000 queries' text rows
 qkv_vid = torch.randn(50 * 900, 768, device=dev, generator=g)
@@ -34,7 +35,7 @@ Lmax = int(L.max())
 
 def run(mode):
     _lib.check(lib.cone_test_enc_attn(mode, P(QKV), P(qkv_vid), P(qkv_txt), P(pos), P(vrow0), P(vlen), P(trow0), P(off),
-                                      P(OUT), B, Lmax, s))
+                                      P(OUT), B, Lmax, 4095, s))
 
 
 flops = float((4.0 * L.double() ** 2 * 256).sum())
