@@ -1558,12 +1558,24 @@ def test_config2_ragged_full_size_is_sync_free_and_matches_oracle():
     (fusion, prop, match), info = inf.predict_split(model, store, opt)
     assert info["n_windows"] == sel.n_rows == sum(n_ref) and len(fusion) == 1000
     with torch.no_grad():
-        ranks, _ = O.prefilter(sd, opt, ann, vf, qf)
+        ranks, wscores = O.prefilter(sd, opt, ann, vf, qf)
     win_idx = info["win_idx"]
     got = win_idx.cpu().tolist()
+    near_tied = []
     for qi, row in enumerate(ann):
         ref = ranks[row["query_id"]][:20]
-        assert got[qi][:len(ref)] == ref and all(g == -1 for g in got[qi][len(ref):]) and len(ref) == n_ref[qi], qi
+        assert all(g == -1 for g in got[qi][len(ref):]) and len(ref) == n_ref[qi], qi
+        if got[qi][:len(ref)] != ref:
+            # the one admissible difference: two DIFFERENT frames whose scores lie within a few fp32 ulps of each other (the
+            # adapter GEMM and the 256-term dot product sum in another order than torch's CPU kernels) may swap ranks -- the
+            # device's list must still be a descending order of the ORACLE's scores up to that margin, over the same windows
+            # or windows tied with the cut
+            ws = wscores[row["query_id"]]
+            mine = got[qi][:len(ref)]
+            assert len(set(mine)) == len(mine) and all(abs(float(ws[a]) - float(ws[b])) <= 5e-7 for a, b in zip(mine, ref)), qi
+            near_tied.append(qi)
+    assert len(near_tied) <= 3 and not any(q < 32 or 480 <= q < 544 for q in near_tied), near_tied
+    record_measured("config2_ragged_rank_lists", queries=1000, exact=1000 - len(near_tied), near_tied_swaps=len(near_tied))
     bp = inf.reference_batch_pad(store, opt, win_idx)
     A = lambda r: np.array(r["pred_relevant_windows"])
     sec_tol = 1e-4 * opt.max_v_l * opt.clip_length + 1e-4
