@@ -301,6 +301,346 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dec_cross_res_kernel: the same computation with the window's memory rows read from HBM ONCE.
+//
+// The kernel above reads every memory row twice from beyond the L2 -- by key rows for the scores (stage A: lane = key), by
+// channel columns for ctx = P . mem (stage C: lane = channel) -- 1.94 x the rows' bytes per launch (profiles/r03_pmc_*): the
+// two contractions need the rows in TRANSPOSED register layouts, and two workgroups per CU x 32 CUs x 104 KB of rows do
+// not stay in a 4 MB L2 between the stages.  Here the rows are LDS-resident for stage C: ONE persistent 8-wave workgroup
+// per CU; per window the rows come in twice from the L2's point of view but once from HBM's, back to back -- as stage A's
+// register operand (lane = key, as before) and, by LDS-DMA (global_load_lds_dwordx4: no VGPRs, one 1-KiB row per
+// instruction, the 64-B block of a row swapped by the row's parity so that stage C's ds_read_b32 of lanes (key 4 s + lg,
+// channel li) are conflict-free), into a [110][256] image that stage C reads by channel.  160 KiB of LDS hold that image
+// (110 KiB) + ONE 46-KiB region that is, in turn, the folded-query slabs (stage A's B operand; the third pair tile keeps
+// only its 8 real rows: 40 KiB), the probabilities Pt, the ctx rows + stage D's partial sums; every hand-over is a barrier
+// that the stage boundaries need anyway.  Windows of up to 110 tokens (Ego4D: 90 clips + <= 20 text tokens); longer ones
+// take the kernel above.
+//
+// With one workgroup per CU nothing else hides a window's load latency, so the loop is software-pipelined across windows:
+// window i+1's key rows (+ position rows) are requested into registers right after stage A of window i (they land under its
+// stage C, ~5 us of LDS + MFMA work with no vector-memory instruction), its LDS image is requested when stage 0 of window i+1
+// has consumed its last W_k load and lands under stage A (vmcnt retires in order: a DMA issued any earlier would hold up
+// every ordinary load behind it).
+constexpr int DCR_RMAX = 110;                       // rows of the LDS image
+constexpr int DCR_ROWS = DCR_RMAX * 256;
+constexpr int DCR_QK = 32 * 256 + 16 * 128;         // compact slabs: pair tiles 0, 1 [16 q][16 rows][16], tile 2 [16 q][8 rows][16]
+constexpr int DCR_CTX_LD = 260;
+constexpr int DCR_REGB = 40 * DCR_CTX_LD + 5 * 256 + 96;   // ctx rows + stage D's partial sums (>= DCR_QK, >= Pt 128 x 48)
+constexpr int DCR_LDS_FLOATS = DCR_ROWS + DCR_REGB + 2 * 8 * 48;
+static_assert(DCR_REGB >= DCR_QK && DCR_REGB >= 128 * 48, "region B holds the slabs, then Pt, then ctx");
+static_assert(DCR_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+// Every barrier of the window loop orders LDS traffic only; __syncthreads() would also drain the vector-memory queue
+// (vmcnt(0)) -- i.e. wait out the row DMA and the next window's prefetch at every stage boundary.
+#define DCR_BARRIER()                                          \
+    {                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    }
+#define DCR_GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <bool POSTAB>
+__global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __restrict__ DQ, const float* __restrict__ XP,
+                                                               const float* __restrict__ X,
+                                                               const float* __restrict__ pos_rows,
+                                                               const int* __restrict__ vlen, const int* __restrict__ off,
+                                                               const float* __restrict__ Wk, const float* __restrict__ WvT,
+                                                               const float* __restrict__ bv, float* __restrict__ OUT,
+                                                               const float* __restrict__ QKS, float* __restrict__ QKS_OUT,
+                                                               int B) {
+    constexpr int NQ = 5, NPT = 3, NPP = 48, NP = 40;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rows = smem;                         // [110][256], 64-B block c / 16 swapped with its neighbour on odd rows
+    float* regB = smem + DCR_ROWS;              // slabs -> Pt [128][48] -> ctx [40][260] + stage D partials [5][256]
+    float* smax = regB + DCR_REGB;              // [8][48]
+    float* ssum = smax + 8 * NPP;               // [8][48]
+    const float* __restrict__ KEYS = POSTAB ? X : XP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int col = tid & 255, half = tid >> 8;
+    // this lane's 16-B chunk inside a slab: row = pair li (tiles 0, 1); tile 2 holds rows 0 .. 7 only -- lanes li >= 8 re-read
+    // pairs 32 .. 39 (their score columns are padding: finite, never used)
+    const int rdA = li * 16 + ((lg ^ dcm_swz16(li)) << 2);
+    const int li8 = li & 7;
+    const int rdB = li8 * 16 + ((lg ^ dcm_swz16(li8)) << 2);
+    auto slab = [](int pt, int q) { return pt < 2 ? (pt * 16 + q) * 256 : 32 * 256 + q * 128; };
+
+    // stage 0 of window `bw` into region B: qk[p][c] = sqrt(1/32) sum_d q[p][d] Wk[h 32 + d][c] (as in the kernel above)
+    auto fold_queries = [&](int bw) {
+        const float* __restrict__ qb = DQ + (size_t)bw * NQ * 256;
+        const int h0 = __builtin_amdgcn_readfirstlane(4 * half);
+        for (int h = h0; h < h0 + 4; ++h) {
+            g2v a[NQ];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) a[s] = g2v{0.f, 0.f};
+            const float* wcol = Wk + (size_t)h * 32 * 256 + col;
+            float wn[8], wc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wn[i] = wcol[i * 256];
+#pragma unroll
+            for (int d8 = 0; d8 < 4; ++d8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wc[i] = wn[i];
+                if (d8 < 3) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) wn[i] = wcol[((d8 + 1) * 8 + i) * 256];
+                }
+#pragma unroll
+                for (int s = 0; s < NQ; ++s) {
+                    const float* qp = qb + s * 256 + h * 32 + d8 * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2)
+                        a[s] = __builtin_elementwise_fma(g2v{qp[i], qp[i + 1]}, g2v{wc[i], wc[i + 1]}, a[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                const int p = s * 8 + h, row = p & 15;
+                regB[slab(p >> 4, col >> 4) + row * 16 + ((((col >> 2) & 3) ^ dcm_swz16(row)) << 2) + (col & 3)] =
+                    (a[s].x + a[s].y) * 0.17677669529663687f;
+            }
+        }
+    };
+    if (QKS_OUT) {      // slab-building launch (one workgroup, window 0's queries): publish the compact slabs and stop
+        fold_queries(0);
+        __syncthreads();
+        for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(QKS_OUT)[i] = reinterpret_cast<const g4v*>(regB)[i];
+        return;
+    }
+    int b = blockIdx.x;
+    if (b >= B) return;
+
+    // this wave's key tile of window `bw` -> registers (A operand of stage A: lane = key, float4 = channels 16 q + 4 lg ..);
+    // the position rows ride in their own registers and are added at the top of stage A (an add here would wait for them)
+    g4v xk[16], xp[POSTAB ? 16 : 1];
+    float pmask = 0.f;
+    auto prefetch = [&](int bw) {
+        const int t0 = off[bw];
+        const int L = min(off[bw + 1] - t0, DCR_RMAX);
+        const int key = min(wave * 16 + li, L - 1);
+        const float* kp = KEYS + (size_t)(t0 + key) * 256 + 4 * lg;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xk[q] = *reinterpret_cast<const g4v*>(kp + 16 * q);
+        if (POSTAB) {
+            const int lv = vlen[bw];
+            const int pk = max(min(key, lv - 1), 0);        // a text key re-reads a clip's row and is masked out
+            const float* pp = pos_rows + ((size_t)(lv * (lv - 1) / 2) + pk) * 256 + 4 * lg;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xp[q] = *reinterpret_cast<const g4v*>(pp + 16 * q);
+            pmask = key < lv ? 1.f : 0.f;
+        }
+    };
+    prefetch(b);
+
+    for (; b < B; b += (int)gridDim.x) {
+        const int t0 = off[b];
+        const int L = min(off[b + 1] - t0, DCR_RMAX);
+        const int nkt = (L + 15) >> 4;
+
+        // ---- stage 0: the folded-query slabs into region B (free: the previous window's stage D ended with a barrier)
+        if (QKS) {
+            for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(regB)[i] = reinterpret_cast<const g4v*>(QKS)[i];
+        } else {
+            fold_queries(b);
+        }
+        // the key rows requested a window ago are consumed HERE, ahead of the DMA: whatever wait the compiler places for
+        // them covers loads issued ~5 us ago and not the DMA below (behind it the compiler waits for vmcnt(0))
+        if (POSTAB) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xk[q] += xp[q] * pmask;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(xk[q]) : : "memory");     // (pins the adds ahead of the DMA)
+        // ---- the window's rows -> LDS image (stage C), one row per instruction; wave w: slots w, w + 8, ...  ALWAYS 14
+        // instructions per wave (slots past the window take a copy of its last row, slots past the image repeat slot 109
+        // with the same bytes): a compile-time count keeps the compiler's own vmcnt waits counted -- behind a loop of
+        // unknown length it waits for vmcnt(0), i.e. for this DMA, at the top of stage A
+        {
+            const float* xb = X + (size_t)t0 * 256;
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                const int slot = min(wave + 8 * i, DCR_RMAX - 1);
+                const int r = min(slot, L - 1);
+                DCR_GLDS16(xb + (size_t)r * 256 + 4 * (lane ^ ((slot & 1) << 2)), rows + slot * 256);
+            }
+        }
+        DCR_BARRIER();                                        // slabs complete
+
+        // ---- stage A: scores of this wave's key tile against the 48 pairs
+        g4v sc[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) sc[pt] = g4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (wave < nkt) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                g4v ch[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ch[r] = g4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const g4v w4 = *reinterpret_cast<const g4v*>(regB + slab(pt, q) + (pt < 2 ? rdA : rdB));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ch[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(xk[q][r], w4[r], ch[r], 0, 0, 0);
+                }
+                g4v s4 = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (wave * 16 + 4 * lg + r >= L) s4[r] = -INFINITY;       // key 4 lg + r of the tile is padding
+                sc[pt] = s4;
+            }
+        }
+        // the next window's key rows: in flight under the softmax, stage C and stage D (after the last window: re-read)
+        const int nb = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
+        prefetch(nb);
+
+        // ---- stage B: softmax over the keys of each pair
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            float m = fmaxf(fmaxf(sc[pt][0], sc[pt][1]), fmaxf(sc[pt][2], sc[pt][3]));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (lg == 0) smax[wave * NPP + pt * 16 + li] = m;
+        }
+        DCR_BARRIER();                                        // every wave is past stage A: the slabs are dead
+        float inv[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            float m = smax[pt * 16 + li];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, smax[w * NPP + pt * 16 + li]);
+            const float m2 = m * 1.4426950408889634f;
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[pt][r], 1.4426950408889634f, -m2));   // exp(-inf) = 0
+                sc[pt][r] = e;
+                l += e;
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            if (lg == 0) ssum[wave * NPP + pt * 16 + li] = l;
+        }
+        DCR_BARRIER();
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            float l = ssum[pt * 16 + li];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) l += ssum[w * NPP + pt * 16 + li];
+            inv[pt] = 1.0f / l;
+        }
+        float* Pt = regB;
+        if (wave < nkt) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pt[(wave * 16 + 4 * lg + r) * NPP + pt * 16 + li] = sc[pt][r] * inv[pt];
+        }
+        // this wave's rows of the LDS image have landed: everything but the prefetch loads issued after them
+        if (POSTAB) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        DCR_BARRIER();                                        // Pt complete (rows [L, 16 nkt) are zeros), image complete
+
+        // ---- stage C: ctx[p][c] = sum_j P[p][j] * mem[j][c]; wave = channels [32 w, 32 w + 32) x all pairs, from LDS
+        g4v acc[2][NPT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = g4v{0.f, 0.f, 0.f, 0.f};
+        {
+            // key 4 s + lg: odd keys (lg odd) hold their 64-B blocks swapped pairwise
+            const int c0 = 32 * wave + li + ((lg & 1) << 4), c1 = 32 * wave + li + (((lg & 1) ^ 1) << 4);
+            const int nks = nkt * 4;
+#pragma unroll 4
+            for (int s = 0; s < nks; ++s) {
+                const int key = min(4 * s + lg, L - 1);         // padding keys carry P = 0: any landed row will do
+                const float a0 = rows[key * 256 + c0], a1 = rows[key * 256 + c1];
+                const float* pr = Pt + (4 * s + lg) * NPP + li;
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {
+                    const float pb = pr[pt * 16];
+                    acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, pb, acc[0][pt], 0, 0, 0);
+                    acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, pb, acc[1][pt], 0, 0, 0);
+                }
+            }
+        }
+        DCR_BARRIER();                                        // Pt and the image are dead
+        float* ctxs = regB;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int p = pt * 16 + li;
+                if (p < NP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ctxs[p * DCR_CTX_LD + 32 * wave + 16 * t + 4 * lg + r] = acc[t][pt][r];
+                }
+            }
+        DCR_BARRIER();
+
+        // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o] (as in the kernel above)
+        {
+            g2v o[NQ];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) o[s] = g2v{0.f, 0.f};
+            const int h = col >> 5;
+            const float* wcol = WvT + (size_t)half * 128 * 256 + col;
+            const float* crow = ctxs + h * DCR_CTX_LD + half * 128;
+#pragma unroll 4
+            for (int c4 = 0; c4 < 32; ++c4) {
+                const g2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
+                const g2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
+#pragma unroll
+                for (int s = 0; s < NQ; ++s) {
+                    const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * DCR_CTX_LD + c4 * 4);
+                    o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
+                    o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
+                }
+            }
+            float* red = regB + 40 * DCR_CTX_LD;                // behind the ctx rows
+            if (half == 1) {
+#pragma unroll
+                for (int s = 0; s < NQ; ++s) red[s * 256 + col] = o[s].x + o[s].y;
+            }
+            DCR_BARRIER();
+            if (half == 0) {
+                const float bias = bv[col];
+#pragma unroll
+                for (int s = 0; s < NQ; ++s)
+                    OUT[(size_t)(b * NQ + s) * 256 + col] = ((o[s].x + o[s].y) + red[s * 256 + col]) + bias;
+            }
+        }
+        DCR_BARRIER();                                        // region B is free for the next window's slabs
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup's LDS
+}
+
+template <bool POSTAB>
+static int launch_res_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
+                          const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
+                          float* qk_slabs, hipStream_t s) {
+    static DeviceOnce once;     // the opt-in to > 64 KiB of LDS + the CU count that sizes the persistent grid: once per device
+    int n_cu = 0;
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)dec_cross_res_kernel<POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   DCR_LDS_FLOATS * 4);
+    }, &n_cu));
+    if (qk_slabs) {     // window-independent queries: the (compact) operand slabs once, by one workgroup
+        hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB>), dim3(1), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen,
+                           off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, B);
+        CONE_LAUNCH_CHECK();
+    }
+    const int grid = B < n_cu ? B : n_cu;
+    hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB>), dim3(grid), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen,
+                       off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, B);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KTW, bool POSTAB>
 static int launch_mfma_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                            const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
@@ -326,13 +666,19 @@ size_t dec_cross_mfma_slab_floats() { return DecCrossMfmaCfg<1>::QK_FLOATS; }
 
 // qk_slabs != null: the NQ queries of every window are the SAME rows (DQ holds them for window 0 at least; first decoder
 // layer) -- the folded-key operand is built once into that scratch (dec_cross_mfma_slab_floats() floats).
+bool dec_cross_res_supported(int nq, int Lmax) { return nq == 5 && Lmax <= DCR_RMAX; }
+
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s) {
+                          int Lmax, float* qk_slabs, hipStream_t s, bool resident) {
     CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
     CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
+    if (resident && dec_cross_res_supported(nq, Lmax)) {    // rows LDS-resident: one HBM read per row (<= 110 tokens)
+        if (XP) return launch_res_one<false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
+        return launch_res_one<true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
+    }
     if (XP) {
         if (Lmax <= 128) return launch_mfma_one<1, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
         return launch_mfma_one<2, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);

@@ -1778,20 +1778,30 @@ def test_window_table_kernel_matches_index_arithmetic(q_base):
         assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
 
 
-@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("variant", [2, 3, 1])
 @pytest.mark.parametrize("shared", [False, True])
-def test_fused_decoder_cross_attention_matches_float64(variant, shared):
+@pytest.mark.parametrize("case", ["ragged128", "many110"])
+def test_fused_decoder_cross_attention_matches_float64(variant, shared, case):
     """dec_cross_mfma.hip / dec_cross.hip called directly: attention of the nq query slots over a window's memory rows with
     the K / V projections folded into the queries / the context (cone/transformer.py:308-311), keys = memory + sine row for
-    clip tokens, against nn.MultiheadAttention's arithmetic in float64.  Ragged windows: 1 clip, no text, 128 keys, a
-    window with text only; ``shared``: every window has the same query rows (first decoder layer)."""
+    clip tokens, against nn.MultiheadAttention's arithmetic in float64.  ``ragged128``: 1 clip, no text, 128 keys, a
+    window with text only (longer than 110 tokens: the two-read MFMA form whatever the variant); ``many110``: 700 windows of
+    1 .. 110 tokens -- variant 2 = the LDS-resident PERSISTENT form (one workgroup per CU walks several windows: the
+    cross-window prefetch, the row DMA, the shared LDS region), variant 3 = the two-read form on the same input;
+    ``shared``: every window has the same query rows (first decoder layer)."""
     from cone_amd import _lib
     if shared and variant == 1:
         pytest.skip("the VALU kernel has no shared-query form")
     dev = _gpu()
     g = torch.Generator().manual_seed(7 + variant)
-    vl = [90, 1, 45, 90, 0, 17, 90, 64]
-    tl = [20, 8, 12, 0, 9, 3, 38, 1]
+    if case == "ragged128":
+        vl = [90, 1, 45, 90, 0, 17, 90, 64]
+        tl = [20, 8, 12, 0, 9, 3, 38, 1]
+    else:
+        rng = np.random.default_rng(3)
+        vl = [90, 1, 0, 90, 16, 89] + rng.integers(0, 91, 694).tolist()
+        tl = [20, 0, 7, 0, 0, 20] + rng.integers(1, 21, 694).tolist()
+        assert max(a + b for a, b in zip(vl, tl)) == 110 and min(a + b for a, b in zip(vl, tl)) == 1
     B, nq = len(vl), 5
     L = [a + b for a, b in zip(vl, tl)]
     off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
