@@ -553,7 +553,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (fold && m->opt_dec_fold >= 2)
             RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                       f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax,
-                                      Tq != T ? f.QKS : nullptr, s, m->opt_dec_fold != 3));    // layer 0: the same queries for every window; dec_fold 3: the two-read form
+                                      Tq != T ? f.QKS : nullptr, s, m->opt_dec_fold == 4));    // layer 0: the same queries for every window; dec_fold 4: the LDS-resident form
         else if (fold)
             RUN(launch_dec_cross(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                  f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, s));
@@ -799,7 +799,7 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
 extern "C" int cone_model_set_option(cone_model* m, const char* name, int value) {
     CONE_REQUIRE(m && name, "set_option: null argument");
     if (!strcmp(name, "dec_fold")) {
-        CONE_REQUIRE(value >= 0 && value <= 3, "set_option: dec_fold %d not in [0, 3]", value);
+        CONE_REQUIRE(value >= 0 && value <= 4 && value != 3, "set_option: dec_fold %d not in {0, 1, 2, 4}", value);
         m->opt_dec_fold = value;
         return 0;
     }
@@ -901,7 +901,7 @@ extern "C" int cone_test_dec_cross(const float* DQ, const float* X, const float*
     if (variant == 1)
         return launch_dec_cross(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, (hipStream_t)stream);
     return launch_dec_cross_mfma(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, qk_slabs,
-                                 (hipStream_t)stream, variant != 3);
+                                 (hipStream_t)stream, variant == 4);
 }
 extern "C" size_t cone_test_dec_cross_slab_floats(void) { return dec_cross_mfma_slab_floats(); }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,

@@ -226,12 +226,12 @@ int launch_dec_cross(const float* DQ, const float* XP, const float* X, const flo
 // qk_slabs (dec_cross_mfma_slab_floats() floats of scratch, or null): the queries are the same rows for every window
 // (first decoder layer): the folded-key operand is built once instead of per window
 size_t dec_cross_mfma_slab_floats();
-// resident: windows of at most 110 tokens run the LDS-resident persistent form (dec_cross_res_kernel: every memory row
-// read from HBM once); same arithmetic, stage for stage
+// resident (opt-in): windows of at most 110 tokens run the LDS-resident persistent form (dec_cross_res_kernel: every memory
+// row read from HBM once; measured slower than the two-read form, see the kernel); same arithmetic, stage for stage
 bool dec_cross_res_supported(int nq, int Lmax);
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s, bool resident = true);
+                          int Lmax, float* qk_slabs, hipStream_t s, bool resident = false);
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 

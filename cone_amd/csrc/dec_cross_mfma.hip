@@ -313,37 +313,60 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
 // instruction, the 64-B block of a row swapped by the row's parity so that stage C's ds_read_b32 of lanes (key 4 s + lg,
 // channel li) are conflict-free), into a [110][256] image that stage C reads by channel.  160 KiB of LDS hold that image
 // (110 KiB) + ONE 46-KiB region that is, in turn, the folded-query slabs (stage A's B operand; the third pair tile keeps
-// only its 8 real rows: 40 KiB), the probabilities Pt, the ctx rows + stage D's partial sums; every hand-over is a barrier
+// only its 8 real rows: 40 KiB), the probabilities Pt, the ctx rows, stage D's partial sums; every hand-over is a barrier
 // that the stage boundaries need anyway.  Windows of up to 110 tokens (Ego4D: 90 clips + <= 20 text tokens); longer ones
 // take the kernel above.
 //
-// With one workgroup per CU nothing else hides a window's load latency, so the loop is software-pipelined across windows:
-// window i+1's key rows (+ position rows) are requested into registers right after stage A of window i (they land under its
-// stage C, ~5 us of LDS + MFMA work with no vector-memory instruction), its LDS image is requested when stage 0 of window i+1
-// has consumed its last W_k load and lands under stage A (vmcnt retires in order: a DMA issued any earlier would hold up
-// every ordinary load behind it).
+// STATUS (round 4, tools/dec_cross_bench.py, 20 000 windows): 2.39 / 1.95 ms per launch (per-window / shared queries) against
+// 1.71 / 1.50 ms of the two-read kernel above -- it reads the rows once and is SLOWER, so it is opt-in ("dec_fold" 4) and
+// the two-read kernel stays the default.  Why: one workgroup per CU (the image leaves no LDS for a second one) exposes
+// every latency that two interleaved workgroups hide from each other -- 25 us per window where the matrix pipe needs 10:
+// what is left after the hand pipelining below are the L2 round trips of the fold operands (2 - 2.5 us each under load) and
+// the next window's key rows, which 256 VGPRs cannot hold together with W_v through stage C (26 spills: measured).
+//
+// With one workgroup per CU nothing else hides a stage's load latency (first cut, stages as above: 36 us per window, 10 of
+// them in stage D's eight dependent groups of W_v loads), so the loop is software-pipelined by hand; every vector-memory
+// operand of a stage is requested one or two stages ahead, into registers that are dead in between:
+//   * W_v (stage D) right after stage A -- into the VGPRs that held the key rows -- landing under the softmax and stage C
+//     (LDS + MFMA only);
+//   * the first half of W_k and the next window's key rows at the end of stage D, the second half of W_k when the first has
+//     been consumed (all of it ahead would need 128 + 64 + 20 live registers at the top of the loop: spills), the position
+//     rows eight float4 at a time behind it; the row image when stage 0 has consumed its last load (vmcnt retires in order: a DMA issued any
+//     earlier would hold up every ordinary load behind it) -- it lands under stage A.
+// The two folds run on float4 columns (thread = 4 adjacent channels, wave = head resp. a 32-channel slice of the
+// contraction): 32 coalesced 1-KiB row reads per wave instead of 128 scalar ones -- at most 63 vector-memory operations are
+// outstanding per wave (vmcnt is 6 bits), the whole schedule stays below that.
 constexpr int DCR_RMAX = 110;                       // rows of the LDS image
 constexpr int DCR_ROWS = DCR_RMAX * 256;
 constexpr int DCR_QK = 32 * 256 + 16 * 128;         // compact slabs: pair tiles 0, 1 [16 q][16 rows][16], tile 2 [16 q][8 rows][16]
 constexpr int DCR_CTX_LD = 260;
-constexpr int DCR_REGB = 40 * DCR_CTX_LD + 5 * 256 + 96;   // ctx rows + stage D's partial sums (>= DCR_QK, >= Pt 128 x 48)
+constexpr int DCR_REGB = 40 * DCR_CTX_LD + 5 * 256 + 96;   // >= the slabs, Pt [128][48], ctx [40][260], stage D partials [8][5][256]
 constexpr int DCR_LDS_FLOATS = DCR_ROWS + DCR_REGB + 2 * 8 * 48;
-static_assert(DCR_REGB >= DCR_QK && DCR_REGB >= 128 * 48, "region B holds the slabs, then Pt, then ctx");
+static_assert(DCR_REGB >= DCR_QK && DCR_REGB >= 128 * 48 && DCR_REGB >= 8 * 5 * 256, "region B holds each of its tenants");
 static_assert(DCR_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 // Every barrier of the window loop orders LDS traffic only; __syncthreads() would also drain the vector-memory queue
-// (vmcnt(0)) -- i.e. wait out the row DMA and the next window's prefetch at every stage boundary.
+// (vmcnt(0)) -- i.e. wait out the row DMA and every prefetch at every stage boundary.
 #define DCR_BARRIER()                                          \
     {                                                          \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
         __builtin_amdgcn_s_barrier();                          \
         asm volatile("" ::: "memory");                         \
     }
+#define DCR_PIN() asm volatile("" ::: "memory")     // loads stay on their side of this point
+// a row load as `uniform base (SGPR pair, made opaque right here) + 32-bit lane offset`: without the pin the compiler folds the
+// lane offset into the base, hoists the per-lane 64-bit pointers of every 4-KiB step out of the window loop and spills them
+__device__ __forceinline__ g4v dcr_ldg(const float* ubase, unsigned voff) {
+    asm volatile("" : "+s"(ubase));
+    // (through the asm the pointer has lost its address space: say "global" again, or the load is a flat_load)
+    typedef const __attribute__((address_space(1))) g4v* gptr;
+    return *(gptr)((const __attribute__((address_space(1))) float*)ubase + voff);
+}
 #define DCR_GLDS16(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <bool POSTAB>
+template <bool POSTAB, bool SHARED>
 __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __restrict__ DQ, const float* __restrict__ XP,
                                                                const float* __restrict__ X,
                                                                const float* __restrict__ pos_rows,
@@ -355,14 +378,13 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
     constexpr int NQ = 5, NPT = 3, NPP = 48, NP = 40;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* rows = smem;                         // [110][256], 64-B block c / 16 swapped with its neighbour on odd rows
-    float* regB = smem + DCR_ROWS;              // slabs -> Pt [128][48] -> ctx [40][260] + stage D partials [5][256]
+    float* regB = smem + DCR_ROWS;              // slabs -> Pt [128][48] -> ctx [40][260] -> stage D partials [8][5][256]
     float* smax = regB + DCR_REGB;              // [8][48]
     float* ssum = smax + 8 * NPP;               // [8][48]
     const float* __restrict__ KEYS = POSTAB ? X : XP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int col = tid & 255, half = tid >> 8;
     // this lane's 16-B chunk inside a slab: row = pair li (tiles 0, 1); tile 2 holds rows 0 .. 7 only -- lanes li >= 8 re-read
     // pairs 32 .. 39 (their score columns are padding: finite, never used)
     const int rdA = li * 16 + ((lg ^ dcm_swz16(li)) << 2);
@@ -370,44 +392,48 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
     const int rdB = li8 * 16 + ((lg ^ dcm_swz16(li8)) << 2);
     auto slab = [](int pt, int q) { return pt < 2 ? (pt * 16 + q) * 256 : 32 * 256 + q * 128; };
 
-    // stage 0 of window `bw` into region B: qk[p][c] = sqrt(1/32) sum_d q[p][d] Wk[h 32 + d][c] (as in the kernel above)
-    auto fold_queries = [&](int bw) {
-        const float* __restrict__ qb = DQ + (size_t)bw * NQ * 256;
-        const int h0 = __builtin_amdgcn_readfirstlane(4 * half);
-        for (int h = h0; h < h0 + 4; ++h) {
-            g2v a[NQ];
+    // ---- the two folds on float4 columns.  Stage 0: wave = head h, lane = channels 4 lane .. + 3:
+    //   qk[(s, h)][c] = sqrt(1/32) sum_d q[s][32 h + d] Wk[32 h + d][c]       (q through the scalar cache: wave-uniform)
+    // wk[d] = Wk[32 h + d][4 lane ..]: window-independent, requested ahead in two halves.
+    // (every global address below is a wave-uniform base -- SGPRs -- plus ONE 32-bit lane offset: per-lane 64-bit pointers for
+    // 32 + 32 + 16 + 16 rows would be hoisted out of the window loop and spilled)
+    g4v wk[SHARED ? 1 : 32];
+    const float* wkb = Wk + (size_t)wave * 32 * 256;            // uniform
+    const unsigned l4 = 4u * lane;
+    auto load_wk = [&](int d0) {
+        if (!SHARED) {
 #pragma unroll
-            for (int s = 0; s < NQ; ++s) a[s] = g2v{0.f, 0.f};
-            const float* wcol = Wk + (size_t)h * 32 * 256 + col;
-            float wn[8], wc[8];
+            for (int d = d0; d < d0 + 16; ++d) wk[d] = dcr_ldg(wkb + d * 256, l4);
+        }
+    };
+    g4v fa[SHARED ? 1 : NQ];
+    auto fold_half = [&](int bw, int d0) {      // accumulate d0 .. d0 + 15 of window bw's queries into fa
+        if (!SHARED) {
+            const float* __restrict__ qb = DQ + (size_t)bw * NQ * 256 + wave * 32;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wn[i] = wcol[i * 256];
+            for (int d = d0; d < d0 + 16; ++d) {
 #pragma unroll
-            for (int d8 = 0; d8 < 4; ++d8) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) wc[i] = wn[i];
-                if (d8 < 3) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) wn[i] = wcol[((d8 + 1) * 8 + i) * 256];
-                }
-#pragma unroll
-                for (int s = 0; s < NQ; ++s) {
-                    const float* qp = qb + s * 256 + h * 32 + d8 * 8;
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2)
-                        a[s] = __builtin_elementwise_fma(g2v{qp[i], qp[i + 1]}, g2v{wc[i], wc[i + 1]}, a[s]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < NQ; ++s) {
-                const int p = s * 8 + h, row = p & 15;
-                regB[slab(p >> 4, col >> 4) + row * 16 + ((((col >> 2) & 3) ^ dcm_swz16(row)) << 2) + (col & 3)] =
-                    (a[s].x + a[s].y) * 0.17677669529663687f;
+                for (int s = 0; s < NQ; ++s) fa[s] += wk[d] * qb[s * 256 + d];
             }
         }
     };
-    if (QKS_OUT) {      // slab-building launch (one workgroup, window 0's queries): publish the compact slabs and stop
-        fold_queries(0);
+    auto fold_store = [&]() {
+        if (!SHARED) {
+            const int c = 4 * lane;
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                const int p = s * 8 + wave, row = p & 15;
+                *reinterpret_cast<g4v*>(regB + slab(p >> 4, c >> 4) + row * 16 + ((((c >> 2) & 3) ^ dcm_swz16(row)) << 2)) =
+                    fa[s] * 0.17677669529663687f;
+            }
+        }
+    };
+    if (QKS_OUT) {      // slab-building launch (one workgroup, window 0's queries; instantiated with SHARED = false)
+        load_wk(0); load_wk(16);
+#pragma unroll
+        for (int s = 0; s < (SHARED ? 1 : NQ); ++s) fa[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        fold_half(0, 0); fold_half(0, 16);
+        fold_store();
         __syncthreads();
         for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(QKS_OUT)[i] = reinterpret_cast<const g4v*>(regB)[i];
         return;
@@ -416,26 +442,61 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
     if (b >= B) return;
 
     // this wave's key tile of window `bw` -> registers (A operand of stage A: lane = key, float4 = channels 16 q + 4 lg ..);
-    // the position rows ride in their own registers and are added at the top of stage A (an add here would wait for them)
-    g4v xk[16], xp[POSTAB ? 16 : 1];
+    // the position rows ride in their own registers (requested later: L2-resident table) and are added ahead of stage A
+    g4v xk[16];
     float pmask = 0.f;
-    auto prefetch = [&](int bw) {
+    auto load_keys = [&](int bw) {
         const int t0 = off[bw];
         const int L = min(off[bw + 1] - t0, DCR_RMAX);
         const int key = min(wave * 16 + li, L - 1);
-        const float* kp = KEYS + (size_t)(t0 + key) * 256 + 4 * lg;
+        const float* kb = KEYS + (size_t)t0 * 256;              // uniform
+        const unsigned ko = (unsigned)key * 256u + 4u * lg;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) xk[q] = *reinterpret_cast<const g4v*>(kp + 16 * q);
+        for (int q = 0; q < 16; ++q) xk[q] = dcr_ldg(kb + 16 * q, ko);
+    };
+    // xk += position rows of window bw (clip keys; a text key re-reads a clip's row and is masked out), eight float4 at a time
+    auto add_pos = [&](int bw) {
         if (POSTAB) {
+            const int t0 = off[bw];
+            const int L = min(off[bw + 1] - t0, DCR_RMAX);
+            const int key = min(wave * 16 + li, L - 1);
             const int lv = vlen[bw];
-            const int pk = max(min(key, lv - 1), 0);        // a text key re-reads a clip's row and is masked out
-            const float* pp = pos_rows + ((size_t)(lv * (lv - 1) / 2) + pk) * 256 + 4 * lg;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) xp[q] = *reinterpret_cast<const g4v*>(pp + 16 * q);
+            const int pk = max(min(key, lv - 1), 0);
+            const float* pb = pos_rows + (size_t)(lv * (lv - 1) / 2) * 256;        // uniform
+            const unsigned po = (unsigned)pk * 256u + 4u * lg;
             pmask = key < lv ? 1.f : 0.f;
+            g4v xa[8], xb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xa[q] = dcr_ldg(pb + 16 * q, po);
+            asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xk[q] += xa[q] * pmask;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(xk[q]));
+            DCR_PIN();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xb[q] = dcr_ldg(pb + 16 * (q + 8), po);
+            // all eight are requested before the first is used (near the register limit the scheduler otherwise walks them
+            // one by one: load, wait, fma, load ...)
+            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]), "+v"(xb[7]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xk[q + 8] += xb[q] * pmask;
         }
     };
-    prefetch(b);
+    // stage D's operand: wv[j] = WvT[32 wave + j][4 lane ..] (window-independent), requested right after stage A
+    g4v wv[32];
+    const float* wvb = WvT + (size_t)wave * 32 * 256;           // uniform
+    g4v qs[SHARED ? DCR_QK / 4 / 512 : 1];         // SHARED: the window-independent slabs, 5 float4 per thread
+    auto load_slabs = [&]() {
+        if (SHARED) {
+#pragma unroll
+            for (int i = 0; i < DCR_QK / 4 / 512; ++i) qs[i] = dcr_ldg(QKS + 2048 * i, 4u * tid);
+        }
+    };
+    // prologue: the first window's operands (exposed once per workgroup)
+    load_wk(0);
+    load_slabs();
+    load_keys(b);
 
     for (; b < B; b += (int)gridDim.x) {
         const int t0 = off[b];
@@ -443,33 +504,38 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
         const int nkt = (L + 15) >> 4;
 
         // ---- stage 0: the folded-query slabs into region B (free: the previous window's stage D ended with a barrier)
-        if (QKS) {
-            for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(regB)[i] = reinterpret_cast<const g4v*>(QKS)[i];
-        } else {
-            fold_queries(b);
-        }
-        // the key rows requested a window ago are consumed HERE, ahead of the DMA: whatever wait the compiler places for
-        // them covers loads issued ~5 us ago and not the DMA below (behind it the compiler waits for vmcnt(0))
-        if (POSTAB) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xk[q] += xp[q] * pmask;
-        }
+        for (int s = 0; s < (SHARED ? 1 : NQ); ++s) fa[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        fold_half(b, 0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(xk[q]) : : "memory");     // (pins the adds ahead of the DMA)
+        for (int s = 0; s < (SHARED ? 1 : NQ); ++s) asm volatile("" : "+v"(fa[s]));    // (the first half's FMAs are done HERE)
+        DCR_PIN();
+        load_wk(16);                                            // the second half of W_k into the registers of the first
+        DCR_PIN();
+        fold_half(b, 16);
+        fold_store();
+        if (SHARED) {
+#pragma unroll
+            for (int i = 0; i < DCR_QK / 4 / 512; ++i) reinterpret_cast<g4v*>(regB)[tid + 512 * i] = qs[i];
+        }
+        // the key rows requested a window ago are consumed HERE, ahead of the DMA: the compiler's waits for them cover loads
+        // issued long ago and not the DMA below (a wait placed behind it would be a vmcnt(0))
+        add_pos(b);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(xk[q]) : : "memory");
         // ---- the window's rows -> LDS image (stage C), one row per instruction; wave w: slots w, w + 8, ...  ALWAYS 14
         // instructions per wave (slots past the window take a copy of its last row, slots past the image repeat slot 109
-        // with the same bytes): a compile-time count keeps the compiler's own vmcnt waits counted -- behind a loop of
-        // unknown length it waits for vmcnt(0), i.e. for this DMA, at the top of stage A
+        // with the same bytes): a compile-time count keeps every later vmcnt wait counted
         {
             const float* xb = X + (size_t)t0 * 256;
 #pragma unroll
             for (int i = 0; i < 14; ++i) {
                 const int slot = min(wave + 8 * i, DCR_RMAX - 1);
                 const int r = min(slot, L - 1);
-                DCR_GLDS16(xb + (size_t)r * 256 + 4 * (lane ^ ((slot & 1) << 2)), rows + slot * 256);
+                DCR_GLDS16(xb + (size_t)r * 256 + 4u * (lane ^ ((slot & 1) << 2)), rows + slot * 256);
             }
         }
-        DCR_BARRIER();                                        // slabs complete
+        DCR_BARRIER();                                          // slabs complete
 
         // ---- stage A: scores of this wave's key tile against the 48 pairs
         g4v sc[NPT];
@@ -494,9 +560,12 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
                 sc[pt] = s4;
             }
         }
-        // the next window's key rows: in flight under the softmax, stage C and stage D (after the last window: re-read)
-        const int nb = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
-        prefetch(nb);
+        // stage D's W_v: 32 requests into the registers that held the key rows, in flight under the softmax and stage C
+        // (the next window's key rows as well -- 64 + 128 registers through stage C -- spills: measured)
+        DCR_PIN();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wv[j] = dcr_ldg(wvb + j * 256, l4);
+        DCR_PIN();
 
         // ---- stage B: softmax over the keys of each pair
 #pragma unroll
@@ -506,7 +575,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             if (lg == 0) smax[wave * NPP + pt * 16 + li] = m;
         }
-        DCR_BARRIER();                                        // every wave is past stage A: the slabs are dead
+        DCR_BARRIER();                                          // every wave is past stage A: the slabs are dead
         float inv[NPT];
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
@@ -540,10 +609,9 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Pt[(wave * 16 + 4 * lg + r) * NPP + pt * 16 + li] = sc[pt][r] * inv[pt];
         }
-        // this wave's rows of the LDS image have landed: everything but the prefetch loads issued after them
-        if (POSTAB) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        DCR_BARRIER();                                        // Pt complete (rows [L, 16 nkt) are zeros), image complete
+        // this wave's rows of the LDS image have landed: everything but the requests issued after them (32 W_v)
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        DCR_BARRIER();                                          // Pt complete (rows [L, 16 nkt) are zeros), image complete
 
         // ---- stage C: ctx[p][c] = sum_j P[p][j] * mem[j][c]; wave = channels [32 w, 32 w + 32) x all pairs, from LDS
         g4v acc[2][NPT];
@@ -568,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
                 }
             }
         }
-        DCR_BARRIER();                                        // Pt and the image are dead
+        DCR_BARRIER();                                          // Pt and the image are dead
         float* ctxs = regB;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -582,39 +650,42 @@ __global__ __launch_bounds__(512, 1) void dec_cross_res_kernel(const float* __re
             }
         DCR_BARRIER();
 
-        // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o] (as in the kernel above)
+        // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o / 32)][c] + bv[o]; wave = the slice c in [32 w, 32 w + 32) of
+        // the contraction, lane = outputs 4 lane .. + 3 (one head); the eight partial sums meet in LDS
         {
-            g2v o[NQ];
+            g4v o[NQ];
 #pragma unroll
-            for (int s = 0; s < NQ; ++s) o[s] = g2v{0.f, 0.f};
-            const int h = col >> 5;
-            const float* wcol = WvT + (size_t)half * 128 * 256 + col;
-            const float* crow = ctxs + h * DCR_CTX_LD + half * 128;
-#pragma unroll 4
-            for (int c4 = 0; c4 < 32; ++c4) {
-                const g2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
-                const g2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
+            for (int s = 0; s < NQ; ++s) o[s] = g4v{0.f, 0.f, 0.f, 0.f};
+            const float* crow = ctxs + (lane >> 3) * DCR_CTX_LD + 32 * wave;
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) {
 #pragma unroll
                 for (int s = 0; s < NQ; ++s) {
-                    const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * DCR_CTX_LD + c4 * 4);
-                    o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
-                    o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
+                    const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * DCR_CTX_LD + 4 * j4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[s] += wv[4 * j4 + u] * cx[u];
                 }
             }
-            float* red = regB + 40 * DCR_CTX_LD;                // behind the ctx rows
-            if (half == 1) {
+            DCR_BARRIER();                                      // every wave is done reading ctx
+            float* part = regB;                                 // [8 waves][5][256]
 #pragma unroll
-                for (int s = 0; s < NQ; ++s) red[s * 256 + col] = o[s].x + o[s].y;
-            }
+            for (int s = 0; s < NQ; ++s) *reinterpret_cast<g4v*>(part + (wave * NQ + s) * 256 + 4 * lane) = o[s];
+            // the next window's first half of W_k and its key rows: into the registers W_v and the partial sums have just left
+            DCR_PIN();
+            load_wk(0);
+            load_slabs();
+            const int nb = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;        // (after the last window: a re-read)
+            load_keys(nb);
+            DCR_PIN();
             DCR_BARRIER();
-            if (half == 0) {
-                const float bias = bv[col];
+            for (int i = tid; i < NQ * 256; i += 512) {
+                float v = part[i];
 #pragma unroll
-                for (int s = 0; s < NQ; ++s)
-                    OUT[(size_t)(b * NQ + s) * 256 + col] = ((o[s].x + o[s].y) + red[s * 256 + col]) + bias;
+                for (int w = 1; w < 8; ++w) v += part[w * NQ * 256 + i];
+                OUT[(size_t)b * NQ * 256 + i] = v + bv[i & 255];
             }
         }
-        DCR_BARRIER();                                        // region B is free for the next window's slabs
+        DCR_BARRIER();                                          // region B is free for the next window's slabs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no LDS-DMA may outlive the workgroup's LDS
 }
@@ -626,17 +697,25 @@ static int launch_res_one(const float* DQ, const float* XP, const float* X, cons
     static DeviceOnce once;     // the opt-in to > 64 KiB of LDS + the CU count that sizes the persistent grid: once per device
     int n_cu = 0;
     CONE_CHECK_HIP(device_once(once, [] {
-        return hipFuncSetAttribute((const void*)dec_cross_res_kernel<POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   DCR_LDS_FLOATS * 4);
+        hipError_t rc = hipFuncSetAttribute((const void*)dec_cross_res_kernel<POSTAB, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, DCR_LDS_FLOATS * 4);
+        if (rc == hipSuccess)
+            rc = hipFuncSetAttribute((const void*)dec_cross_res_kernel<POSTAB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     DCR_LDS_FLOATS * 4);
+        return rc;
     }, &n_cu));
-    if (qk_slabs) {     // window-independent queries: the (compact) operand slabs once, by one workgroup
-        hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB>), dim3(1), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen,
-                           off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, B);
-        CONE_LAUNCH_CHECK();
-    }
     const int grid = B < n_cu ? B : n_cu;
-    hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB>), dim3(grid), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen,
-                       off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, B);
+    if (qk_slabs) {     // window-independent queries: the (compact) operand slabs once, by one workgroup
+        hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB, false>), dim3(1), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows,
+                           vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, B);
+        CONE_LAUNCH_CHECK();
+        hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB, true>), dim3(grid), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows,
+                           vlen, off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, B);
+        CONE_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL((dec_cross_res_kernel<POSTAB, false>), dim3(grid), dim3(512), DCR_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows,
+                       vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, (float*)nullptr, B);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -675,7 +754,7 @@ int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, cons
     CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
-    if (resident && dec_cross_res_supported(nq, Lmax)) {    // rows LDS-resident: one HBM read per row (<= 110 tokens)
+    if (resident && dec_cross_res_supported(nq, Lmax)) {    // opt-in: rows LDS-resident, one HBM read per row (<= 110 tokens)
         if (XP) return launch_res_one<false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
         return launch_res_one<true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
     }

@@ -329,9 +329,10 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
 /* A/B switches of ONE model handle for the parity tests (not thread-safe; set them before using the handle).
  * "dec_fold" (default 2): decoder cross-attention with the memory K/V projections folded into one kernel per layer,
- *   2 = its two 256-channel contractions on the matrix cores (dec_cross_mfma.hip) -- windows of at most 110 tokens by the
- *   LDS-resident persistent form that reads every memory row from HBM once, longer ones by the two-read form; 3 = always the
- *   two-read form; 1 = on the VALU (dec_cross.hip); 0 = two stacked K/V GEMMs + per-head attention.
+ *   2 = its two 256-channel contractions on the matrix cores (dec_cross_mfma.hip); 4 (opt-in) = the same with windows of at
+ *   most 110 tokens on the LDS-resident persistent form that reads every memory row from HBM once (half the row traffic,
+ *   measured 1.3 - 1.4 x slower: one workgroup per CU); 1 = on the VALU (dec_cross.hip); 0 = two stacked K/V GEMMs +
+ *   per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
  *   caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
  * "pos_tables" (default 1): later encoder layers and the decoder keys take the position term from the static
@@ -401,8 +402,8 @@ int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const f
  * table and the clip count of each window (keys = memory + position row for clip tokens), Wk (256, 256) = rows
  * 256 .. 511 of in_proj_weight, WvT (256, 256) = W_v transposed, bv (256).  OUT (B * nq, 256) = attention output ahead
  * of out_proj.  variant 2: matrix cores (qk_slabs != NULL: every window has the SAME nq query rows, the folded operand
- * is built once into that scratch of cone_test_dec_cross_slab_floats() floats) -- the LDS-resident form up to 110 tokens;
- * 3: matrix cores, always the two-read form; 1: VALU kernel. */
+ * is built once into that scratch of cone_test_dec_cross_slab_floats() floats); 4: matrix cores, the LDS-resident persistent
+ * form for windows of at most 110 tokens (the two-read form beyond); 1: VALU kernel. */
 int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen, const int32_t* off,
                         const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax,
                         int variant, float* qk_slabs, void* stream);

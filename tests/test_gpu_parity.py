@@ -1778,7 +1778,7 @@ def test_window_table_kernel_matches_index_arithmetic(q_base):
         assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
 
 
-@pytest.mark.parametrize("variant", [2, 3, 1])
+@pytest.mark.parametrize("variant", [2, 4, 1])
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("case", ["ragged128", "many110"])
 def test_fused_decoder_cross_attention_matches_float64(variant, shared, case):
@@ -1786,8 +1786,8 @@ def test_fused_decoder_cross_attention_matches_float64(variant, shared, case):
     the K / V projections folded into the queries / the context (cone/transformer.py:308-311), keys = memory + sine row for
     clip tokens, against nn.MultiheadAttention's arithmetic in float64.  ``ragged128``: 1 clip, no text, 128 keys, a
     window with text only (longer than 110 tokens: the two-read MFMA form whatever the variant); ``many110``: 700 windows of
-    1 .. 110 tokens -- variant 2 = the LDS-resident PERSISTENT form (one workgroup per CU walks several windows: the
-    cross-window prefetch, the row DMA, the shared LDS region), variant 3 = the two-read form on the same input;
+    1 .. 110 tokens -- variant 4 = the opt-in LDS-resident PERSISTENT form (one workgroup per CU walks several windows: the
+    cross-window prefetch, the row DMA, the shared LDS region), variant 2 = the default two-read form on the same input;
     ``shared``: every window has the same query rows (first decoder layer)."""
     from cone_amd import _lib
     if shared and variant == 1:
