@@ -92,7 +92,6 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
         }
     }
 
-    const int col = tid & 255, half = tid >> 8;
     if (QKS) {      // precomputed slabs: 48 KiB from the L2 instead of 256 KiB of W_k
         for (int i = tid; i < C::QK_FLOATS / 4; i += 512)
             reinterpret_cast<g4v*>(qkf)[i] = reinterpret_cast<const g4v*>(QKS)[i];
@@ -102,42 +101,42 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
         const int q = i >> 7, r = 8 + ((i >> 4) & 7), c = i & 15;
         qkf[(2 * 16 + q) * 256 + r * 16 + c] = 0.f;
     }
-    // ---- stage 0: qk[p][c] = sqrt(1/32) sum_d q[p][d] * Wk[h*32+d][c], thread = channel c (two thread groups split the
-    // heads); the window's query values are wave-uniform: they come through the scalar cache (s_load) straight into the
-    // FMAs' scalar operands -- no LDS staging, no LDS read per FMA pair.  Stored in slab (pair tile, c / 16), row
-    // pair % 16, physical chunk ((c / 4) % 4) ^ swz(row)
-    const float* __restrict__ qb = DQ + (size_t)b * NQ * 256;
-    const int h0 = __builtin_amdgcn_readfirstlane(4 * half);
-    for (int h = h0; h < h0 + 4; ++h) {
-        g2v a[NQ];
+    // ---- stage 0: qk[(s, h)][c] = sqrt(1/32) sum_d q[s][32 h + d] * Wk[32 h + d][c]: wave = head h, lane = channels 4 lane ..
+    // + 3 -- a W_k row is ONE coalesced 1-KiB request per wave (a thread per channel made it four 256-B ones: 128 scalar loads
+    // per thread, the L2 request rate of 20 000 windows x 256 KiB).  The window's query values are wave-uniform: they come
+    // through the scalar cache straight into the FMAs' scalar operands.  Rows in groups of four, the next group requested
+    // ahead of this group's FMAs.  Stored in slab (pair tile, c / 16), row pair % 16, physical chunk ((c / 4) % 4) ^ swz(row)
+    {
+        const float* __restrict__ qb = DQ + (size_t)b * NQ * 256 + wave * 32;
+        const float* wb = Wk + (size_t)wave * 32 * 256;
+        const unsigned l4 = 4u * lane;
+        g4v a[NQ];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) a[s] = g2v{0.f, 0.f};
-        const float* wcol = Wk + (size_t)h * 32 * 256 + col;
-        // the head's 32 rows of W_k in four groups of 8, the next group requested ahead of this group's FMAs
-        float wn[8], wc[8];
+        for (int s = 0; s < NQ; ++s) a[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        // (rows two at a time, the next pair requested ahead of this pair's FMAs: the key rows of stage A are live -- 64 of
+        // the 128 VGPRs two workgroups per CU leave a wave)
+        g4v wn[2], wc[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wn[i] = wcol[i * 256];
+        for (int i = 0; i < 2; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + i * 256 + l4);
 #pragma unroll
-        for (int d8 = 0; d8 < 4; ++d8) {
+        for (int g = 0; g < 16; ++g) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wc[i] = wn[i];
-            if (d8 < 3) {
+            for (int i = 0; i < 2; ++i) wc[i] = wn[i];
+            if (g < 15) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wn[i] = wcol[((d8 + 1) * 8 + i) * 256];
+                for (int i = 0; i < 2; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + ((g + 1) * 2 + i) * 256 + l4);
             }
 #pragma unroll
-            for (int s = 0; s < NQ; ++s) {
-                const float* qp = qb + s * 256 + h * 32 + d8 * 8;
+            for (int s = 0; s < NQ; ++s)
 #pragma unroll
-                for (int i = 0; i < 8; i += 2)
-                    a[s] = __builtin_elementwise_fma(g2v{qp[i], qp[i + 1]}, g2v{wc[i], wc[i + 1]}, a[s]);
-            }
+                for (int i = 0; i < 2; ++i) a[s] += wc[i] * qb[s * 256 + g * 2 + i];
         }
+        const int c = 4 * lane;
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
-            const int p = s * 8 + h, row = p & 15;
-            qkf[((p >> 4) * 16 + (col >> 4)) * 256 + row * 16 + ((((col >> 2) & 3) ^ dcm_swz16(row)) << 2) + (col & 3)] =
-                (a[s].x + a[s].y) * 0.17677669529663687f;
+            const int p = s * 8 + wave, row = p & 15;
+            *reinterpret_cast<g4v*>(qkf + ((p >> 4) * 16 + (c >> 4)) * 256 + row * 16 + ((((c >> 2) & 3) ^ dcm_swz16(row)) << 2)) =
+                a[s] * 0.17677669529663687f;
         }
     }
     }
@@ -266,37 +265,44 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
         }
     __syncthreads();
 
-    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o/32)][c] + bv[o], thread = output column o; the two thread
-    // groups split the c range (each W_v^T element is loaded once per window), partial sums meet in LDS
+    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o / 32)][c] + bv[o]: wave = the slice c in [32 w, 32 w + 32) of the
+    // contraction, lane = outputs 4 lane .. + 3 (one head: a W_v^T row is one coalesced 1-KiB request per wave); the eight
+    // partial sums meet in LDS
     {
-        g2v o[NQ];
+        g4v o[NQ];
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) o[s] = g2v{0.f, 0.f};
-        const int h = col >> 5;
-        const float* wcol = WvT + (size_t)half * 128 * 256 + col;
-        const float* crow = ctxs + h * C::CTX_LD + half * 128;
-#pragma unroll 4
-        for (int c4 = 0; c4 < 32; ++c4) {
-            const g2v w01 = {wcol[(c4 * 4 + 0) * 256], wcol[(c4 * 4 + 1) * 256]};
-            const g2v w23 = {wcol[(c4 * 4 + 2) * 256], wcol[(c4 * 4 + 3) * 256]};
+        for (int s = 0; s < NQ; ++s) o[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        const float* wb = WvT + (size_t)wave * 32 * 256;
+        const unsigned l4 = 4u * lane;
+        const float* crow = ctxs + (lane >> 3) * C::CTX_LD + 32 * wave;
+        g4v wn[4], wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + i * 256 + l4);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+            if (g < 7) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + ((g + 1) * 4 + i) * 256 + l4);
+            }
 #pragma unroll
             for (int s = 0; s < NQ; ++s) {
-                const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * C::CTX_LD + c4 * 4);
-                o[s] = __builtin_elementwise_fma(cx.xy, w01, o[s]);
-                o[s] = __builtin_elementwise_fma(cx.zw, w23, o[s]);
+                const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * C::CTX_LD + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[s] += wc[i] * cx[i];
             }
         }
-        float* red = Pt;                                    // Pt is dead since the end of stage C (barrier above)
-        if (half == 1) {
+        __syncthreads();                                    // every wave is done reading ctx
+        float* part = qkf;                                  // [8 waves][5][256] over the ctx rows
 #pragma unroll
-            for (int s = 0; s < NQ; ++s) red[s * 256 + col] = o[s].x + o[s].y;
-        }
+        for (int s = 0; s < NQ; ++s) *reinterpret_cast<g4v*>(part + (wave * NQ + s) * 256 + 4 * lane) = o[s];
         __syncthreads();
-        if (half == 0) {
-            const float bias = bv[col];
+        for (int i = tid; i < NQ * 256; i += 512) {
+            float v = part[i];
 #pragma unroll
-            for (int s = 0; s < NQ; ++s)
-                OUT[(size_t)(b * NQ + s) * 256 + col] = ((o[s].x + o[s].y) + red[s * 256 + col]) + bias;
+            for (int w = 1; w < 8; ++w) v += part[w * NQ * 256 + i];
+            OUT[(size_t)b * NQ * 256 + i] = v + bv[i & 255];
         }
     }
 }
