@@ -306,6 +306,39 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
                 "bound": "mfma", "achieved": round(fl / (k_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(fl / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "flop_per_byte": round(fl / alg, 1), "ridge_flop_per_byte": round(FP32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1)}
+        if nq >= 8:
+            # OPT-IN beside it (never the headline form): the same call on the bf16 matrix cores, each fp32 product as six
+            # partial products of three-piece bf16 operands (cone_prefilter_scores_split): fp32 accuracy, HBM-bound
+            def call3():
+                _, ws = ops.prefilter_scores(vid, txt, W, frame_scores=False, split_bf16=True)
+                return ops.topk_windows(ws, topk)
+            try:
+                _, ws_a = ops.prefilter_scores(vid, txt, W, frame_scores=False)
+                _, ws_b = ops.prefilter_scores(vid, txt, W, frame_scores=False, split_bf16=True)
+                diff = float((ws_a - ws_b).abs().max())
+                same = int((ops.topk_windows(ws_a, topk)[0] == ops.topk_windows(ws_b, topk)[0]).all(dim=1).sum())
+                del ws_a, ws_b
+                _timed(call3, 1, 2)
+                lib.cone_prof_enable(1)
+                dt3, _ = _timed(call3, steps, 0)
+                rec3 = collect_profile()
+                lib.cone_prof_enable(0)
+                k3 = float(rec3[np.isin(rec3[:, 0], (0, 4))][:, 4].sum()) / steps
+                roof3 = {"bound": "hbm", "achieved": round(alg / (k3 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg)}
+                roof3.update(pmc_traffic("frame_score_mq3_kernel<2>", PMC_PREFILTER_FILES))
+                if roof3.get("traffic"):
+                    roof3["traffic_over_algorithmic"] = round(roof3["traffic"] / alg, 3)
+                out[f"q{nq}_split_bf16x3"] = {
+                    "note": "opt-in cone_prefilter_scores_split (NOT the default form): three-piece bf16 operands, six partial "
+                            "products per fp32 product, fp32 accumulation; 64 queries = two 32-query workgroups per frame range "
+                            "on one XCD (the second read of a row is an L2 hit)",
+                    "queries": nq, "ms_per_call": round(dt3 * 1e3, 3), "frame_score_kernel_ms": round(k3, 3),
+                    "kernel": "frame_score_mq3_kernel<2>", "roofline": roof3,
+                    "path_frac": round(alg / dt3 / 1e9 / HBM_PEAK_GBS, 4),
+                    "max_abs_diff_of_window_scores_vs_fp32": diff, "queries_with_identical_top_k": same}
+            except Exception as e:      # noqa: BLE001
+                out[f"q{nq}_split_bf16x3"] = {"error": repr(e)[:300]}
         del txt
     del vid
     torch.cuda.empty_cache()

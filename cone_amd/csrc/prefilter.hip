@@ -499,6 +499,190 @@ static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, int S
     return 0;
 }
 
+// ---- OPT-IN: many queries on the bf16 matrix cores, every fp32 product as six partial products of three-piece operands --
+// At 64 queries the exact-fp32 kernel above is bound by the matrix pipe, not by the stream (32 FLOP per byte is past the
+// ridge of 19.7: 3.7 ms where HBM needs 2.1).  gfx950's bf16 MFMA runs 16 x faster, and an fp32 product can ride on it without
+// giving up fp32 accuracy (ffn_split.hip; tools/probe/split_bf16_probe.hip: the error of the six-product form equals the
+// fp32 chain's): x = xh + xm + xl exactly (three bf16 pieces, 24 bits), x w ~= xl wh + xh wl + xm wm + xh wm + xm wh + xh wh.
+//   * D[query][frame] tiles of v_mfma_f32_16x16x32_bf16: B = the frame's 32 channels of a k-step = the two float4 a lane
+//     already streams (k slot (lg, j) <-> channel 32 t + 16 (j / 4) + 4 lg + j % 4), split into pieces in registers ONCE per
+//     frame tile and used for every query tile; A = the query pieces, split once per launch into LDS slabs [16 queries][4
+//     lg][8 bf16] (a lane's ds_read_b128: conflict-free).
+//   * LDS: 3 pieces x 2 B x dv per query = 96 KiB for 32 queries x 512: a workgroup takes 32 queries.  64 queries = TWO
+//     workgroups per frame range, placed on the same XCD (workgroups b and b + 8 share one: consecutive ids go round the
+//     eight XCDs) and walking the same half-blocks in the same order, so the second read of a row is an L2 hit a few
+//     microseconds after the first: the arena still crosses HBM once.
+// The running max per half window, the first-frame scores and the output format are those of the fp32 kernel.
+typedef short pf_s8 __attribute__((ext_vector_type(8)));
+typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned pf_u2 __attribute__((ext_vector_type(2)));
+typedef float pf_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pf_b2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pf_pk(float a, float b) {       // two floats -> packed bf16 pair, round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(pf_f2{a, b}, pf_b2));
+}
+__device__ __forceinline__ void pf_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pf_pk(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pf_pk(ra, rb);
+    l = pf_pk(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ void pf_split8(const pf4& v0, const pf4& v1, pf_s8& h, pf_s8& m, pf_s8& l) {
+    unsigned a[4], b[4], c[4];
+    pf_split2(v0[0], v0[1], a[0], b[0], c[0]);
+    pf_split2(v0[2], v0[3], a[1], b[1], c[1]);
+    pf_split2(v1[0], v1[1], a[2], b[2], c[2]);
+    pf_split2(v1[2], v1[3], a[3], b[3], c[3]);
+    h = __builtin_bit_cast(pf_s8, pf_u4{a[0], a[1], a[2], a[3]});
+    m = __builtin_bit_cast(pf_s8, pf_u4{b[0], b[1], b[2], b[3]});
+    l = __builtin_bit_cast(pf_s8, pf_u4{c[0], c[1], c[2], c[3]});
+}
+#define PF_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+
+template <int QT /* query tiles of 16 per workgroup */>
+__global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* __restrict__ vid, int64_t ctx_l, int dv, int S,
+                                                                 int64_t nh, const float* __restrict__ txt, int q0, int nq,
+                                                                 float* __restrict__ hm, float* __restrict__ fr, int G) {
+    extern __shared__ __attribute__((aligned(16))) char qsb[];          // [piece 3][QT][dv / 32] slabs of 1 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nt = dv >> 5;                                              // k-steps of 32 channels
+    // which queries, which share of the half-blocks: G = 2: workgroups b and b + 8 (one XCD) = the two query groups of one share
+    int grp = 0, share = blockIdx.x, n_share = gridDim.x;
+    if (G == 2) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        grp = slot & 1;
+        share = (slot >> 1) * 8 + xcd;
+        n_share = gridDim.x >> 1;
+    }
+    const int qb = q0 + grp * (QT * 16);
+    for (int i = tid; i < QT * 16 * (dv >> 2); i += MQ_NT) {             // (query, float4 of its vector) -> three pieces
+        const int qi = i / (dv >> 2), c4 = i % (dv >> 2);
+        const int qg = qb + qi;
+        pf4 v = pf4{0.f, 0.f, 0.f, 0.f};
+        if (qg < nq) v = *reinterpret_cast<const pf4*>(txt + (size_t)qg * dv + c4 * 4);
+        unsigned h0, m0, l0, h1, m1, l1;
+        pf_split2(v[0], v[1], h0, m0, l0);
+        pf_split2(v[2], v[3], h1, m1, l1);
+        // channel 4 c4 + j = 32 t + 16 u + 4 lgq + j: k slot (lgq, 4 u + j) of step t
+        const int t = c4 >> 3, u = (c4 >> 2) & 1, lgq = c4 & 3, row = qi & 15;
+        const int off = (((qi >> 4) * nt + t) << 10) + row * 64 + lgq * 16 + u * 8;
+        const int pstride = (QT * nt) << 10;
+        *reinterpret_cast<pf_u2*>(qsb + off) = pf_u2{h0, h1};
+        *reinterpret_cast<pf_u2*>(qsb + pstride + off) = pf_u2{m0, m1};
+        *reinterpret_cast<pf_u2*>(qsb + 2 * pstride + off) = pf_u2{l0, l1};
+    }
+    __syncthreads();
+    const int rd = li * 64 + lg * 16;
+    const int pstride = (QT * nt) << 10;
+    const int nchunk = dv >> 7;                                          // 128-channel chunks (4 k-steps)
+    constexpr int NW = MQ_NT / 64;
+    const int64_t h_step = (int64_t)n_share * NW;
+    int64_t h = (int64_t)share * NW + (tid >> 6);
+    if (h >= nh) return;
+    int64_t r_lo = h * S, r_hi = min(r_lo + S, ctx_l);
+    int64_t f0 = r_lo;
+    const float* fp = vid + min(f0 + li, r_hi - 1) * dv + 4 * lg;
+    pf4 cur[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+    pf4 mx[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mx[qt] = pf4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    while (true) {
+        int64_t h2 = h, f2 = f0 + 16, lo2 = r_lo, hi2 = r_hi;
+        if (f2 >= r_hi) { h2 = h + h_step; lo2 = h2 * S; hi2 = min(lo2 + S, ctx_l); f2 = lo2; }
+        const bool more = h2 < nh;
+        const float* fp2 = more ? vid + min(f2 + li, hi2 - 1) * dv + 4 * lg : fp;
+        pf4 acc[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt] = pf4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; ++c) {
+            const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
+            pf4 nxt[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                pf_s8 fh, fm, fl;
+                pf_split8(cur[2 * tt], cur[2 * tt + 1], fh, fm, fl);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const char* sl = qsb + ((qt * nt + c * 4 + tt) << 10) + rd;
+                    const pf_s8 ah = *reinterpret_cast<const pf_s8*>(sl);
+                    const pf_s8 am = *reinterpret_cast<const pf_s8*>(sl + pstride);
+                    const pf_s8 al = *reinterpret_cast<const pf_s8*>(sl + 2 * pstride);
+                    PF_MFMA(acc[qt], al, fh);                           // small terms first
+                    PF_MFMA(acc[qt], ah, fl);
+                    PF_MFMA(acc[qt], am, fm);
+                    PF_MFMA(acc[qt], am, fh);
+                    PF_MFMA(acc[qt], ah, fm);
+                    PF_MFMA(acc[qt], ah, fh);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+        }
+        const bool valid = f0 + li < r_hi;
+        const bool first = f0 == r_lo && li == 0;       // lane li = 0 of the block's first tile = frame hS
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (valid) mx[qt][r] = fmaxf(mx[qt][r], acc[qt][r]);
+                const int qg = qb + qt * 16 + 4 * lg + r;
+                if (first && qg < nq) fr[(size_t)qg * nh + h] = acc[qt][r];
+            }
+        }
+        if (f0 + 16 >= r_hi) {                          // half-block done: max over its 16 frame lanes, one store per query
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = mx[qt][r];
+                    v = fmaxf(v, __shfl_xor(v, 1, 64));
+                    v = fmaxf(v, __shfl_xor(v, 2, 64));
+                    v = fmaxf(v, __shfl_xor(v, 4, 64));
+                    v = fmaxf(v, __shfl_xor(v, 8, 64));
+                    const int qg = qb + qt * 16 + 4 * lg + r;
+                    if (li == 0 && qg < nq) hm[(size_t)qg * nh + h] = v;
+                    mx[qt][r] = -INFINITY;
+                }
+        }
+        if (!more) break;
+        h = h2; f0 = f2; r_lo = lo2; r_hi = hi2; fp = fp2;
+    }
+}
+
+bool frame_scores_split_supported(int dv, int nq) { return nq >= 8 && dv % 128 == 0 && 3 * 2 * 32 * dv <= 128 * 1024; }
+
+static int launch_frame_scores_mq3(const float* vid, int64_t ctx_l, int dv, int S, int64_t nh, const float* txt, int nq, float* hm,
+                                   float* fr, hipStream_t s) {
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (device_once(once, [] {
+            return hipFuncSetAttribute((const void*)frame_score_mq3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        }, &n_cu) != hipSuccess) {
+        set_error("prefilter: raising the LDS limit of the split many-query kernel failed");
+        return CONE_E_HIP;
+    }
+    const size_t lds = (size_t)3 * 2 * 32 * dv;                           // 3 pieces x 2 B x 32 queries x dv
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int rem = nq - q0;
+        const int G = rem > 32 ? 2 : 1;
+        int64_t shares = (nh + MQ_NT / 64 - 1) / (MQ_NT / 64);
+        const int max_shares = G == 2 ? (n_cu / 16) * 8 : n_cu;          // G = 2: whole XCD rows of pairs (b, b + 8)
+        if (shares > max_shares) shares = max_shares;
+        if (G == 2) shares = (shares + 7) / 8 * 8;                        // the pairing needs complete groups of 16 workgroups
+        ProfScope ps(PK_FRAME_SCORE, ctx_l, dv, rem < 64 ? rem : 64, nullptr, s);
+        hipLaunchKernelGGL((frame_score_mq3_kernel<2>), dim3((unsigned)(shares * G)), dim3(MQ_NT), lds, s, vid, ctx_l, dv, S, nh,
+                           txt, q0, nq, hm, fr, G);
+        CONE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // ---- segmented forms: all queries of a split in three launches --------------------------------
 // A group = one video and up to 4 of its queries (the clip rows are read once per group).
 template <int VPL>
@@ -653,9 +837,8 @@ extern "C" size_t cone_prefilter_scores_workspace(int64_t ctx_l, int nq, int W) 
     return 2 * cone::align_up((size_t)nq * nh * sizeof(float), 256);
 }
 
-extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W,
-                                     int S, float* frame_scores, float* win_scores, void* ws, size_t ws_bytes,
-                                     void* stream) {
+static int prefilter_scores_impl(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W, int S,
+                                 float* frame_scores, float* win_scores, void* ws, size_t ws_bytes, void* stream, bool split) {
     CONE_REQUIRE(vid && txt && win_scores, "prefilter: null argument");
     CONE_REQUIRE(ctx_l > 0 && nq > 0 && W > 0 && S > 0 && S == W / 2, "prefilter: bad sizes ctx_l=%lld nq=%d W=%d S=%d",
                  (long long)ctx_l, nq, W, S);
@@ -668,7 +851,10 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
     float* hm = (float*)ws;
     float* fr = (float*)((char*)ws + need / 2);
     int rc;
-    if (nq >= 8) {
+    if (split && !frame_scores && cone::frame_scores_split_supported(dv, nq)) {
+        // opt-in: the same stream on the bf16 matrix cores (three-piece operands, six partial products: fp32 accuracy)
+        rc = cone::launch_frame_scores_mq3(vid, ctx_l, dv, S, nh, txt, nq, hm, fr, s);
+    } else if (nq >= 8) {
         // Many queries over one video: the clip arena is read once for up to 64 queries by the fp32-MFMA kernel
         // (BASELINE configs 3 / 5) instead of nq / 4 VALU passes over the features.
         rc = cone::launch_frame_scores_mq(vid, ctx_l, dv, S, nh, txt, nq, frame_scores, hm, fr, s);
@@ -685,6 +871,17 @@ extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, co
                        W & 1, win_scores);
     CONE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W,
+                                     int S, float* frame_scores, float* win_scores, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    return prefilter_scores_impl(vid, ctx_l, dv, txt, nq, W, S, frame_scores, win_scores, ws, ws_bytes, stream, false);
+}
+
+extern "C" int cone_prefilter_scores_split(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W,
+                                           int S, float* win_scores, void* ws, size_t ws_bytes, void* stream) {
+    return prefilter_scores_impl(vid, ctx_l, dv, txt, nq, W, S, nullptr, win_scores, ws, ws_bytes, stream, true);
 }
 
 extern "C" int cone_prefilter_batched(const float* arena, int dv, const float* cls, const int64_t* g_row0,

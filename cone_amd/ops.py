@@ -33,13 +33,16 @@ def num_windows(ctx_l: int, max_v_l: int) -> int:
     return math.ceil(ctx_l / int(max_v_l / 2)) + 1
 
 
-def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int, frame_scores: bool = True):
+def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int, frame_scores: bool = True,
+                     split_bf16: bool = False):
     """cone/inference.py:284-296 for all queries of one video.
 
     vid_ctx (ctx_l, dv) adapted+normalised clip features, cls_txt (nq, dv).
     Returns (frame_scores (nq, ctx_l), window_scores (nq, num_window)).  The window max is fused into the
     frame-score stream; ``frame_scores=False`` skips writing the (nq, ctx_l) matrix (returned as None) -- the
-    reference only computes it to take the window max, and so does every caller in this package."""
+    reference only computes it to take the window max, and so does every caller in this package.  ``split_bf16`` (opt-in,
+    with ``frame_scores=False``): 8 or more queries run on the bf16 matrix cores, each fp32 product as six partial products of
+    three-piece bf16 operands (fp32 accuracy, HBM-bound at 64 queries)."""
     lib = _lib.load()
     ctx_l, dv = vid_ctx.shape
     nq = cls_txt.shape[0]
@@ -49,6 +52,13 @@ def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int,
     ws = torch.empty(nq, nw, device=vid_ctx.device)
     nbytes = lib.cone_prefilter_scores_workspace(ctx_l, nq, W)
     scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=vid_ctx.device)
+    if split_bf16:      # opt-in: >= 8 queries on the bf16 matrix cores as three-piece operands (cone_prefilter_scores_split)
+        if frame_scores:
+            raise ValueError("split_bf16 computes the window scores only (frame_scores=False)")
+        _lib.check(lib.cone_prefilter_scores_split(_lib.ptr(vid_ctx, torch.float32), ctx_l, dv,
+                                                   _lib.ptr(cls_txt, torch.float32), nq, W, S, _lib.ptr(ws),
+                                                   _lib.ptr(scratch), scratch.numel(), _lib.stream()))
+        return None, ws
     _lib.check(lib.cone_prefilter_scores(_lib.ptr(vid_ctx, torch.float32), ctx_l, dv,
                                          _lib.ptr(cls_txt, torch.float32), nq, W, S, _lib.ptr(fs), _lib.ptr(ws),
                                          _lib.ptr(scratch), scratch.numel(), _lib.stream()))

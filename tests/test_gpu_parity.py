@@ -569,6 +569,41 @@ def test_prefilter_long_rows_fused_window_max(ctx_l, W, dv, nq):
             assert float(ws[q, i]) == float(f[(i - 1) * S:min((i - 1) * S + W, ctx_l)].max())
 
 
+@pytest.mark.parametrize("ctx_l,W,dv,nq", [(5000, 125, 512, 64), (777, 125, 512, 33), (3001, 90, 256, 8), (2500, 125, 512, 70),
+                                          (130, 125, 512, 64), (9000, 125, 384, 40)])
+def test_prefilter_split_bf16_many_queries(ctx_l, W, dv, nq):
+    """cone_prefilter_scores_split (opt-in: >= 8 queries on the bf16 matrix cores, each fp32 product as six partial products of
+    three-piece bf16 operands; 33 .. 64 queries = two workgroups per frame range on one XCD) against float64 window scores
+    (cone/inference.py:284-296): its error stays within 2 x the exact-fp32 kernel's on the same input (+ 1 ulp), and its top-k
+    lists equal the fp32 kernel's wherever the fp64 scores at the cut are more than 1e-6 apart."""
+    from cone_amd import ops
+    dev = _gpu()
+    g = torch.Generator().manual_seed(ctx_l + nq)
+    vid = torch.nn.functional.normalize(torch.randn(ctx_l, dv, generator=g), dim=1)
+    txt = torch.nn.functional.normalize(torch.randn(nq, dv, generator=g), dim=1)
+    S = int(W / 2)
+    fs64 = txt.double() @ vid.double().t()
+    nw = -(-ctx_l // S) + 1
+    ref = torch.stack([fs64[:, max((i - 1) * S, 0):min((i - 1) * S + W, ctx_l)].max(dim=1).values for i in range(nw)], 1)
+    vd, td = vid.to(dev), txt.to(dev)
+    _, ws32 = ops.prefilter_scores(vd, td, W, frame_scores=False)
+    none, ws3 = ops.prefilter_scores(vd, td, W, frame_scores=False, split_bf16=True)
+    torch.cuda.synchronize()
+    assert none is None and ws3.shape == ws32.shape == (nq, nw)
+    e32, e3 = maxdiff(ws32, ref), maxdiff(ws3, ref)
+    assert e3 <= 2.0 * e32 + 6e-8 and e3 < 5e-7, (e3, e32)
+    k = min(30, nw)
+    i32, _ = ops.topk_windows(ws32, k)
+    i3, _ = ops.topk_windows(ws3, k)
+    srt = torch.sort(ref, dim=1, descending=True).values
+    for q in range(nq):
+        if not torch.equal(i32[q], i3[q]):
+            a, b = i32[q].cpu().tolist(), i3[q].cpu().tolist()
+            for x, y in zip(a, b):      # a swap only between windows whose float64 scores are within a few fp32 ulps
+                assert abs(float(ref[q, x]) - float(ref[q, y])) <= 1e-6, (q, x, y)
+    record_measured("prefilter_split_bf16", shape=f"{ctx_l}x{dv}x{nq}", err_fp32_mfma=e32, err_split_bf16x3=e3)
+
+
 def test_prefilter_batched_equals_per_video_path():
     """The three-launch segmented pre-filter is bit-identical to the per-video entry points, including
     videos with fewer windows than topk (padded with -1)."""
@@ -1472,6 +1507,21 @@ def test_mad_scale_prefilter_full_size(nq):
     # the product form (what bench.py times): no (nq, ctx_l) matrix is written -- identical window scores
     none, ws_fused = ops.prefilter_scores(vid, txt, W, frame_scores=False)
     assert none is None and torch.equal(ws_fused, ws)
+    if nq >= 8:
+        # the opt-in three-piece bf16 form at full size: window scores within a few ulps of the exact-fp32 kernel's, top-30
+        # lists equal except between windows whose scores are that close
+        _, ws3 = ops.prefilter_scores(vid, txt, W, frame_scores=False, split_bf16=True)
+        d = float((ws3 - ws).abs().max())
+        assert d <= 4e-7, d
+        i3, _ = ops.topk_windows(ws3, k)
+        differ = 0
+        for q in range(nq):
+            if not torch.equal(i3[q], idx[q]):
+                differ += 1
+                for x, y in zip(i3[q].tolist(), idx[q].tolist()):
+                    assert abs(float(ws[q, x]) - float(ws[q, y])) <= 1e-6, (q, x, y)
+        record_measured("mad_scale_prefilter_split_bf16", queries=nq, max_abs_diff_vs_fp32=d, rank_lists_with_a_near_tied_swap=differ)
+        del ws3
     del vid, ws, ws_fused
     torch.cuda.empty_cache()
 
