@@ -326,15 +326,15 @@ def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
                 k3 = float(rec3[np.isin(rec3[:, 0], (0, 4))][:, 4].sum()) / steps
                 roof3 = {"bound": "hbm", "achieved": round(alg / (k3 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg)}
-                roof3.update(pmc_traffic("frame_score_mq3_kernel<2>", PMC_PREFILTER_FILES))
+                roof3.update(pmc_traffic("frame_score_mq3_kernel", PMC_PREFILTER_FILES))
                 if roof3.get("traffic"):
                     roof3["traffic_over_algorithmic"] = round(roof3["traffic"] / alg, 3)
                 out[f"q{nq}_split_bf16x3"] = {
                     "note": "opt-in cone_prefilter_scores_split (NOT the default form): three-piece bf16 operands, six partial "
-                            "products per fp32 product, fp32 accumulation; 64 queries = two 32-query workgroups per frame range "
-                            "on one XCD (the second read of a row is an L2 hit)",
+                            "products per fp32 product, fp32 accumulation; the 192 KiB of query pieces stream through a 3-stage "
+                            "LDS ring by LDS-DMA, the twelve waves of a workgroup in lock-step on the 128-channel chunk",
                     "queries": nq, "ms_per_call": round(dt3 * 1e3, 3), "frame_score_kernel_ms": round(k3, 3),
-                    "kernel": "frame_score_mq3_kernel<2>", "roofline": roof3,
+                    "kernel": "frame_score_mq3_kernel", "roofline": roof3,
                     "path_frac": round(alg / dt3 / 1e9 / HBM_PEAK_GBS, 4),
                     "max_abs_diff_of_window_scores_vs_fp32": diff, "queries_with_identical_top_k": same}
             except Exception as e:      # noqa: BLE001

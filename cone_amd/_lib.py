@@ -77,6 +77,7 @@ _SIGNATURES = {
     "cone_prefilter_scores_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "cone_prefilter_scores": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_prefilter_scores_split_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "cone_prefilter_scores_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_prefilter_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -506,12 +506,15 @@ static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, int S
 // fp32 chain's): x = xh + xm + xl exactly (three bf16 pieces, 24 bits), x w ~= xl wh + xh wl + xm wm + xh wm + xm wh + xh wh.
 //   * D[query][frame] tiles of v_mfma_f32_16x16x32_bf16: B = the frame's 32 channels of a k-step = the two float4 a lane
 //     already streams (k slot (lg, j) <-> channel 32 t + 16 (j / 4) + 4 lg + j % 4), split into pieces in registers ONCE per
-//     frame tile and used for every query tile; A = the query pieces, split once per launch into LDS slabs [16 queries][4
-//     lg][8 bf16] (a lane's ds_read_b128: conflict-free).
-//   * LDS: 3 pieces x 2 B x dv per query = 96 KiB for 32 queries x 512: a workgroup takes 32 queries.  64 queries = TWO
-//     workgroups per frame range, placed on the same XCD (workgroups b and b + 8 share one: consecutive ids go round the
-//     eight XCDs) and walking the same half-blocks in the same order, so the second read of a row is an L2 hit a few
-//     microseconds after the first: the arena still crosses HBM once.
+//     frame tile and used for all four query tiles; A = the query pieces as 1-KiB slabs [16 queries][4 lg][8 bf16] (a
+//     lane's ds_read_b128: conflict-free).
+//   * The query pieces of 64 queries x 512 channels are 192 KiB -- more than the LDS.  They are split ONCE per launch into an
+//     image in the caller's workspace (pf_split_queries_kernel; L2-resident from then on), laid out [128-channel chunk][piece]
+//     [query tile][k-step] in exactly the byte order of the LDS slabs, and the workgroup's twelve waves walk their frame tiles
+//     in LOCK-STEP on the chunk index: the 48 KiB of chunk c + 2 stream in by LDS-DMA (four 1-KiB pieces per wave: no VGPRs,
+//     no addressing) into a three-stage ring while chunk c is multiplied -- one raw barrier per chunk step.  (First cut: 32
+//     queries per workgroup and two workgroups on one XCD per frame range, hoping for L2 hits on the second read: FETCH_SIZE
+//     1.49 x the arena, 3.78 ms -- the waves' positions are megabytes apart and a 4 MB L2 cannot bridge that.)
 // The running max per half window, the first-frame scores and the output format are those of the fp32 kernel.
 typedef short pf_s8 __attribute__((ext_vector_type(8)));
 typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
@@ -539,91 +542,136 @@ __device__ __forceinline__ void pf_split8(const pf4& v0, const pf4& v1, pf_s8& h
     l = __builtin_bit_cast(pf_s8, pf_u4{c[0], c[1], c[2], c[3]});
 }
 #define PF_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+#define PF_GLDS16(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <int QT /* query tiles of 16 per workgroup */>
+constexpr int MQ3_QT = 4;                           // query tiles of 16 per launch
+constexpr int MQ3_CHUNK = 3 * MQ3_QT * 4 * 1024;    // bytes of one 128-channel chunk of the image: [piece][query tile][k-step] slabs
+constexpr int MQ3_NBUF = 3;
+size_t frame_scores_split_image_bytes(int dv) { return (size_t)(dv >> 7) * MQ3_CHUNK; }
+
+// queries q0 .. q0 + 63 (zeros past nq) -> the image: chunk c = channels [128 c, 128 c + 128), slab (piece, qt, tt), inside a
+// slab query row r, lane group lg, half u: 8 B = channels 32 t + 16 u + 4 lg + 0 .. 3 of step t = 4 c + tt
+__global__ __launch_bounds__(256) void pf_split_queries_kernel(const float* __restrict__ txt, int dv, int q0, int nq,
+                                                               char* __restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // (query, float4 of its vector)
+    if (i >= MQ3_QT * 16 * (dv >> 2)) return;
+    const int qi = i / (dv >> 2), c4 = i % (dv >> 2);
+    const int qg = q0 + qi;
+    pf4 v = pf4{0.f, 0.f, 0.f, 0.f};
+    if (qg < nq) v = *reinterpret_cast<const pf4*>(txt + (size_t)qg * dv + c4 * 4);
+    unsigned h0, m0, l0, h1, m1, l1;
+    pf_split2(v[0], v[1], h0, m0, l0);
+    pf_split2(v[2], v[3], h1, m1, l1);
+    const int t = c4 >> 3, u = (c4 >> 2) & 1, lgq = c4 & 3, row = qi & 15;
+    const int c = t >> 2, tt = t & 3, qt = qi >> 4;
+    char* base = img + (size_t)c * MQ3_CHUNK + ((qt * 4 + tt) << 10) + row * 64 + lgq * 16 + u * 8;
+    constexpr int pstride = MQ3_QT * 4 * 1024;
+    *reinterpret_cast<pf_u2*>(base) = pf_u2{h0, h1};
+    *reinterpret_cast<pf_u2*>(base + pstride) = pf_u2{m0, m1};
+    *reinterpret_cast<pf_u2*>(base + 2 * pstride) = pf_u2{l0, l1};
+}
+
 __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* __restrict__ vid, int64_t ctx_l, int dv, int S,
-                                                                 int64_t nh, const float* __restrict__ txt, int q0, int nq,
-                                                                 float* __restrict__ hm, float* __restrict__ fr, int G) {
-    extern __shared__ __attribute__((aligned(16))) char qsb[];          // [piece 3][QT][dv / 32] slabs of 1 KiB
+                                                                 int64_t nh, const char* __restrict__ img, int q0, int nq,
+                                                                 float* __restrict__ hm, float* __restrict__ fr) {
+    constexpr int QT = MQ3_QT;
+    extern __shared__ __attribute__((aligned(16))) char ring[];         // MQ3_NBUF stages of MQ3_CHUNK bytes
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int nt = dv >> 5;                                              // k-steps of 32 channels
-    // which queries, which share of the half-blocks: G = 2: workgroups b and b + 8 (one XCD) = the two query groups of one share
-    int grp = 0, share = blockIdx.x, n_share = gridDim.x;
-    if (G == 2) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        grp = slot & 1;
-        share = (slot >> 1) * 8 + xcd;
-        n_share = gridDim.x >> 1;
-    }
-    const int qb = q0 + grp * (QT * 16);
-    for (int i = tid; i < QT * 16 * (dv >> 2); i += MQ_NT) {             // (query, float4 of its vector) -> three pieces
-        const int qi = i / (dv >> 2), c4 = i % (dv >> 2);
-        const int qg = qb + qi;
-        pf4 v = pf4{0.f, 0.f, 0.f, 0.f};
-        if (qg < nq) v = *reinterpret_cast<const pf4*>(txt + (size_t)qg * dv + c4 * 4);
-        unsigned h0, m0, l0, h1, m1, l1;
-        pf_split2(v[0], v[1], h0, m0, l0);
-        pf_split2(v[2], v[3], h1, m1, l1);
-        // channel 4 c4 + j = 32 t + 16 u + 4 lgq + j: k slot (lgq, 4 u + j) of step t
-        const int t = c4 >> 3, u = (c4 >> 2) & 1, lgq = c4 & 3, row = qi & 15;
-        const int off = (((qi >> 4) * nt + t) << 10) + row * 64 + lgq * 16 + u * 8;
-        const int pstride = (QT * nt) << 10;
-        *reinterpret_cast<pf_u2*>(qsb + off) = pf_u2{h0, h1};
-        *reinterpret_cast<pf_u2*>(qsb + pstride + off) = pf_u2{m0, m1};
-        *reinterpret_cast<pf_u2*>(qsb + 2 * pstride + off) = pf_u2{l0, l1};
-    }
-    __syncthreads();
-    const int rd = li * 64 + lg * 16;
-    const int pstride = (QT * nt) << 10;
-    const int nchunk = dv >> 7;                                          // 128-channel chunks (4 k-steps)
+    const int nchunk = dv >> 7;
     constexpr int NW = MQ_NT / 64;
-    const int64_t h_step = (int64_t)n_share * NW;
-    int64_t h = (int64_t)share * NW + (tid >> 6);
-    if (h >= nh) return;
-    int64_t r_lo = h * S, r_hi = min(r_lo + S, ctx_l);
+    constexpr int pstride = QT * 4 * 1024;
+    const int rd = li * 64 + lg * 16;
+    // tile slots of this workgroup = the tiles of its busiest wave (every wave takes every barrier; a wave out of tiles only
+    // keeps the ring fed).  Half-blocks have ceil(S / 16) tiles, the video's last one possibly fewer.
+    const int64_t h_step = (int64_t)gridDim.x * NW;
+    const int tps = (S + 15) >> 4;
+    const int tps_last = (int)((ctx_l - (nh - 1) * S + 15) >> 4);
+    auto tiles_of = [&](int w) -> int64_t {
+        const int64_t h0 = (int64_t)blockIdx.x * NW + w;
+        if (h0 >= nh) return 0;
+        const int64_t n = (nh - 1 - h0) / h_step + 1;
+        const bool owns_last = (nh - 1 - h0) % h_step == 0;
+        return n * tps - (owns_last ? tps - tps_last : 0);
+    };
+    int64_t slots = 0;
+    for (int w = 0; w < NW; ++w) { const int64_t t = tiles_of(w); slots = t > slots ? t : slots; }
+    if (slots == 0) return;
+    const int64_t n_steps = slots * nchunk;
+    // ring: the wave's four 1-KiB pieces of a chunk
+    auto stream = [&](int64_t g) {                                      // chunk of global step g -> stage g % MQ3_NBUF
+        const char* src = img + (size_t)(g % nchunk) * MQ3_CHUNK + (wave * 4 << 10) + lane * 16;
+        char* dst = ring + (int)(g % MQ3_NBUF) * MQ3_CHUNK + (wave * 4 << 10);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PF_GLDS16(src + (i << 10), dst + (i << 10));
+    };
+    stream(0);
+    if (n_steps > 1) stream(1);
+
+    int64_t h = (int64_t)blockIdx.x * NW + wave;
+    bool live = h < nh;
+    int64_t r_lo = live ? h * S : 0, r_hi = live ? min(r_lo + S, ctx_l) : 1;
     int64_t f0 = r_lo;
     const float* fp = vid + min(f0 + li, r_hi - 1) * dv + 4 * lg;
     pf4 cur[8];
+    if (live) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+        for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+    }
     pf4 mx[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) mx[qt] = pf4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    while (true) {
+    int64_t g = 0;
+    for (int64_t slot = 0; slot < slots; ++slot) {
         int64_t h2 = h, f2 = f0 + 16, lo2 = r_lo, hi2 = r_hi;
         if (f2 >= r_hi) { h2 = h + h_step; lo2 = h2 * S; hi2 = min(lo2 + S, ctx_l); f2 = lo2; }
-        const bool more = h2 < nh;
+        const bool more = live && h2 < nh;
         const float* fp2 = more ? vid + min(f2 + li, hi2 - 1) * dv + 4 * lg : fp;
         pf4 acc[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) acc[qt] = pf4{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nchunk; ++c) {
-            const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
+        for (int c = 0; c < nchunk; ++c, ++g) {
+            // stage g has landed (this wave's pieces: everything but the 4 pieces of stage g + 1 and, with the loads of the
+            // previous step consumed by the compiler's own waits, nothing else); the barrier makes all twelve shares visible
+            // and tells that everybody is done with stage g - 1, which the pieces of stage g + 2 overwrite
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             pf4 nxt[8];
+            if (live) {
+                const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                pf_s8 fh, fm, fl;
-                pf_split8(cur[2 * tt], cur[2 * tt + 1], fh, fm, fl);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const char* sl = qsb + ((qt * nt + c * 4 + tt) << 10) + rd;
-                    const pf_s8 ah = *reinterpret_cast<const pf_s8*>(sl);
-                    const pf_s8 am = *reinterpret_cast<const pf_s8*>(sl + pstride);
-                    const pf_s8 al = *reinterpret_cast<const pf_s8*>(sl + 2 * pstride);
-                    PF_MFMA(acc[qt], al, fh);                           // small terms first
-                    PF_MFMA(acc[qt], ah, fl);
-                    PF_MFMA(acc[qt], am, fm);
-                    PF_MFMA(acc[qt], am, fh);
-                    PF_MFMA(acc[qt], ah, fm);
-                    PF_MFMA(acc[qt], ah, fh);
-                }
+                for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
             }
+            if (g + 2 < n_steps) stream(g + 2);
+            if (live) {
+                const char* st = ring + (int)(g % MQ3_NBUF) * MQ3_CHUNK + rd;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+                for (int tt = 0; tt < 4; ++tt) {
+                    pf_s8 fh, fm, fl;
+                    pf_split8(cur[2 * tt], cur[2 * tt + 1], fh, fm, fl);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const char* sl = st + ((qt * 4 + tt) << 10);
+                        const pf_s8 ah = *reinterpret_cast<const pf_s8*>(sl);
+                        const pf_s8 am = *reinterpret_cast<const pf_s8*>(sl + pstride);
+                        const pf_s8 al = *reinterpret_cast<const pf_s8*>(sl + 2 * pstride);
+                        PF_MFMA(acc[qt], al, fh);                       // small terms first
+                        PF_MFMA(acc[qt], ah, fl);
+                        PF_MFMA(acc[qt], am, fm);
+                        PF_MFMA(acc[qt], am, fh);
+                        PF_MFMA(acc[qt], ah, fm);
+                        PF_MFMA(acc[qt], ah, fh);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+            }
         }
+        if (!live) continue;
         const bool valid = f0 + li < r_hi;
         const bool first = f0 == r_lo && li == 0;       // lane li = 0 of the block's first tile = frame hS
 #pragma unroll
@@ -631,7 +679,7 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (valid) mx[qt][r] = fmaxf(mx[qt][r], acc[qt][r]);
-                const int qg = qb + qt * 16 + 4 * lg + r;
+                const int qg = q0 + qt * 16 + 4 * lg + r;
                 if (first && qg < nq) fr[(size_t)qg * nh + h] = acc[qt][r];
             }
         }
@@ -645,39 +693,40 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* 
                     v = fmaxf(v, __shfl_xor(v, 2, 64));
                     v = fmaxf(v, __shfl_xor(v, 4, 64));
                     v = fmaxf(v, __shfl_xor(v, 8, 64));
-                    const int qg = qb + qt * 16 + 4 * lg + r;
+                    const int qg = q0 + qt * 16 + 4 * lg + r;
                     if (li == 0 && qg < nq) hm[(size_t)qg * nh + h] = v;
                     mx[qt][r] = -INFINITY;
                 }
         }
-        if (!more) break;
+        if (!more) { live = false; continue; }
         h = h2; f0 = f2; r_lo = lo2; r_hi = hi2; fp = fp2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup's LDS
 }
 
-bool frame_scores_split_supported(int dv, int nq) { return nq >= 8 && dv % 128 == 0 && 3 * 2 * 32 * dv <= 128 * 1024; }
+bool frame_scores_split_supported(int dv, int nq) { return nq >= 8 && dv % 128 == 0; }
 
 static int launch_frame_scores_mq3(const float* vid, int64_t ctx_l, int dv, int S, int64_t nh, const float* txt, int nq, float* hm,
-                                   float* fr, hipStream_t s) {
+                                   float* fr, char* img, hipStream_t s) {
     static DeviceOnce once;
     int n_cu = 0;
     if (device_once(once, [] {
-            return hipFuncSetAttribute((const void*)frame_score_mq3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            return hipFuncSetAttribute((const void*)frame_score_mq3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MQ3_NBUF * MQ3_CHUNK);
         }, &n_cu) != hipSuccess) {
         set_error("prefilter: raising the LDS limit of the split many-query kernel failed");
         return CONE_E_HIP;
     }
-    const size_t lds = (size_t)3 * 2 * 32 * dv;                           // 3 pieces x 2 B x 32 queries x dv
+    int64_t blocks = (nh + MQ_NT / 64 - 1) / (MQ_NT / 64);
+    if (blocks > n_cu) blocks = n_cu;                                  // one workgroup per CU, grid-stride over half-blocks
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int rem = nq - q0;
-        const int G = rem > 32 ? 2 : 1;
-        int64_t shares = (nh + MQ_NT / 64 - 1) / (MQ_NT / 64);
-        const int max_shares = G == 2 ? (n_cu / 16) * 8 : n_cu;          // G = 2: whole XCD rows of pairs (b, b + 8)
-        if (shares > max_shares) shares = max_shares;
-        if (G == 2) shares = (shares + 7) / 8 * 8;                        // the pairing needs complete groups of 16 workgroups
+        hipLaunchKernelGGL(pf_split_queries_kernel, dim3((unsigned)((MQ3_QT * 16 * (dv >> 2) + 255) / 256)), dim3(256), 0, s, txt, dv,
+                           q0, nq, img);
+        CONE_LAUNCH_CHECK();
         ProfScope ps(PK_FRAME_SCORE, ctx_l, dv, rem < 64 ? rem : 64, nullptr, s);
-        hipLaunchKernelGGL((frame_score_mq3_kernel<2>), dim3((unsigned)(shares * G)), dim3(MQ_NT), lds, s, vid, ctx_l, dv, S, nh,
-                           txt, q0, nq, hm, fr, G);
+        hipLaunchKernelGGL(frame_score_mq3_kernel, dim3((unsigned)blocks), dim3(MQ_NT), MQ3_NBUF * MQ3_CHUNK, s, vid, ctx_l, dv, S, nh,
+                           (const char*)img, q0, nq, hm, fr);
         CONE_LAUNCH_CHECK();
     }
     return 0;
@@ -837,6 +886,11 @@ extern "C" size_t cone_prefilter_scores_workspace(int64_t ctx_l, int nq, int W) 
     return 2 * cone::align_up((size_t)nq * nh * sizeof(float), 256);
 }
 
+extern "C" size_t cone_prefilter_scores_split_workspace(int64_t ctx_l, int nq, int W, int dv) {
+    const size_t base = cone_prefilter_scores_workspace(ctx_l, nq, W);
+    return base ? base + cone::frame_scores_split_image_bytes(dv) : 0;
+}
+
 static int prefilter_scores_impl(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W, int S,
                                  float* frame_scores, float* win_scores, void* ws, size_t ws_bytes, void* stream, bool split) {
     CONE_REQUIRE(vid && txt && win_scores, "prefilter: null argument");
@@ -852,8 +906,11 @@ static int prefilter_scores_impl(const float* vid, int64_t ctx_l, int dv, const 
     float* fr = (float*)((char*)ws + need / 2);
     int rc;
     if (split && !frame_scores && cone::frame_scores_split_supported(dv, nq)) {
-        // opt-in: the same stream on the bf16 matrix cores (three-piece operands, six partial products: fp32 accuracy)
-        rc = cone::launch_frame_scores_mq3(vid, ctx_l, dv, S, nh, txt, nq, hm, fr, s);
+        // opt-in: the same stream on the bf16 matrix cores (three-piece operands, six partial products: fp32 accuracy); the
+        // split query image lives behind the two score planes of the workspace
+        CONE_REQUIRE(ws_bytes >= need + cone::frame_scores_split_image_bytes(dv), "prefilter (split): workspace too small (%zu < %zu)",
+                     ws_bytes, need + cone::frame_scores_split_image_bytes(dv));
+        rc = cone::launch_frame_scores_mq3(vid, ctx_l, dv, S, nh, txt, nq, hm, fr, (char*)ws + need, s);
     } else if (nq >= 8) {
         // Many queries over one video: the clip arena is read once for up to 64 queries by the fp32-MFMA kernel
         // (BASELINE configs 3 / 5) instead of nq / 4 VALU passes over the features.

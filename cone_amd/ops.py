@@ -50,7 +50,8 @@ def prefilter_scores(vid_ctx: torch.Tensor, cls_txt: torch.Tensor, max_v_l: int,
     nw = num_windows(ctx_l, max_v_l)
     fs = torch.empty(nq, ctx_l, device=vid_ctx.device) if frame_scores else None
     ws = torch.empty(nq, nw, device=vid_ctx.device)
-    nbytes = lib.cone_prefilter_scores_workspace(ctx_l, nq, W)
+    nbytes = (lib.cone_prefilter_scores_split_workspace(ctx_l, nq, W, dv) if split_bf16
+              else lib.cone_prefilter_scores_workspace(ctx_l, nq, W))
     scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=vid_ctx.device)
     if split_bf16:      # opt-in: >= 8 queries on the bf16 matrix cores as three-piece operands (cone_prefilter_scores_split)
         if frame_scores:

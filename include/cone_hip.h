@@ -107,11 +107,13 @@ int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* 
                           int W, int S, float* frame_scores, float* win_scores, void* ws, size_t ws_bytes,
                           void* stream);
 
-/* OPT-IN form of cone_prefilter_scores without the frame-score matrix: 8 or more queries over one video (feature dim a
- * multiple of 128, at most 682) run on the bf16 matrix cores, every fp32 product as six partial products of three-piece bf16
- * operands with fp32 accumulation -- the accuracy of the exact-fp32 MFMA chain (tools/probe/split_bf16_probe.hip) at a rate that
- * leaves the 64-query stream HBM-bound instead of matrix-pipe-bound.  Other shapes take cone_prefilter_scores' kernels.  Same
- * workspace.  The default path (cone_prefilter_scores, cone/inference.py's drop-in) stays exact fp32. */
+/* OPT-IN form of cone_prefilter_scores without the frame-score matrix: 8 or more queries over one video run on the bf16
+ * matrix cores, every fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation -- the
+ * accuracy of the exact-fp32 MFMA chain (tools/probe/split_bf16_probe.hip) at a rate that leaves the 64-query stream
+ * HBM-bound instead of matrix-pipe-bound.  Fewer than 8 queries take cone_prefilter_scores' streaming kernel.
+ * ws >= cone_prefilter_scores_split_workspace(...) bytes (the score planes + the split query image).  The default path
+ * (cone_prefilter_scores, cone/inference.py's drop-in) stays exact fp32. */
+size_t cone_prefilter_scores_split_workspace(int64_t ctx_l, int nq, int W, int dv);
 int cone_prefilter_scores_split(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq, int W, int S,
                                 float* win_scores, void* ws, size_t ws_bytes, void* stream);
 

@@ -570,7 +570,7 @@ def test_prefilter_long_rows_fused_window_max(ctx_l, W, dv, nq):
 
 
 @pytest.mark.parametrize("ctx_l,W,dv,nq", [(5000, 125, 512, 64), (777, 125, 512, 33), (3001, 90, 256, 8), (2500, 125, 512, 70),
-                                          (130, 125, 512, 64), (9000, 125, 384, 40)])
+                                          (130, 125, 512, 64), (9000, 125, 256, 40)])
 def test_prefilter_split_bf16_many_queries(ctx_l, W, dv, nq):
     """cone_prefilter_scores_split (opt-in: >= 8 queries on the bf16 matrix cores, each fp32 product as six partial products of
     three-piece bf16 operands; 33 .. 64 queries = two workgroups per frame range on one XCD) against float64 window scores

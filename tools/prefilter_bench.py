@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--topk", type=int, default=30)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--frame_scores", action="store_true", help="also write the (nq, ctx_l) frame-score matrix")
+    ap.add_argument("--split_bf16", action="store_true",
+                    help="the opt-in three-piece bf16 form (cone_prefilter_scores_split) for >= 8 queries")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -43,7 +45,8 @@ def main():
         txt = ops.l2_normalize(torch.randn(nq, args.dv, device=dev, generator=g), 0.0)
 
         def call():
-            fs, ws = ops.prefilter_scores(vid, txt, args.W, frame_scores=args.frame_scores)
+            fs, ws = ops.prefilter_scores(vid, txt, args.W, frame_scores=args.frame_scores,
+                                          split_bf16=args.split_bf16 and nq >= 8)
             return fs, ws, ops.topk_windows(ws, args.topk)
         for _ in range(2):
             call()
@@ -68,7 +71,8 @@ def main():
         err = float((ws[:, 1:1 + ref_ws.shape[1]] - ref_ws).abs().max())
         print(json.dumps({
             "workload": f"MAD-scale pre-filter: ctx_l={args.ctx_l}, d={args.dv}, window_len={args.W}, {nw} windows, "
-                        f"{nq} query(ies), top-{args.topk}, frame-score matrix {'written' if args.frame_scores else 'not written'}",
+                        f"{nq} query(ies), top-{args.topk}, frame-score matrix {'written' if args.frame_scores else 'not written'}"
+                        + (", split_bf16 (three-piece bf16 operands)" if args.split_bf16 and nq >= 8 else ""),
             "ms_per_query_batch": round(dt * 1e3, 3), "windows_per_s": round(nw * nq / dt, 1),
             "frame_score_ms": round(per_step_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(alg / (per_step_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
