@@ -212,6 +212,18 @@ def roofline_from_profile(rec):
     roof["by_shape_tflops"] = {k: [round(v[0] / (v[1] * 1e-3) / 1e12, 1), v[2]] for k, v in sorted(shapes.items())}
     extra = {KERNEL_NAMES[k]: {"ms": round(v["ms"], 3), "launches": v["launches"],
                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in per.items()}
+    # the row GEMM by shape: its average is dominated by the count of small launches, its time by ONE shape (the later
+    # encoder layers' q | k | v projection, N = 768, K = 256, ~2 M rows)
+    rs = {}
+    for kind, a, b, c, ms in rec:
+        if int(kind) == 6:
+            d3 = rs.setdefault(f"N{int(b)}_K{int(c)}" + ("_big" if a >= 65536 else ""), [0.0, 0.0, 0])
+            d3[0] += rec_flops(6, a, b, c); d3[1] += ms; d3[2] += 1
+    if rs and KERNEL_NAMES[6] in extra:
+        extra[KERNEL_NAMES[6]]["by_shape"] = {k: {"ms": round(v[1], 3), "launches": v[2],
+                                                  "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1),
+                                                  "frac_of_fp32_mfma_peak": round(v[0] / (v[1] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)}
+                                              for k, v in sorted(rs.items(), key=lambda kv: -kv[1][1])[:6]}
     for kind in (3, 4, 7):
         sel = rec[rec[:, 0] == kind]
         if len(sel):
