@@ -589,13 +589,19 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int h0 = want_aux ? 0 : nd - 1;               // first decoder layer whose heads are needed
     const int HT = (nd - h0) * T;
     const size_t hoff = (size_t)h0 * T;
-    RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, f.LG + hoff * 2, 2, HT, 2, 0, s));
+    // only the last layer's heads wanted (the eval pipeline): they write straight into the caller's logits / spans; with the
+    // intermediate layers' too, all layers go to the workspace and the last layer's rows are copied out
+    float* LGo = want_aux ? f.LG + hoff * 2 : logits;
+    float* SPo = want_aux ? f.SP + hoff * 2 : spans;
+    RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, LGo, 2, HT, 2, 0, s));
     RUN(launch_gemm(G(m, f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
     RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
-    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP + hoff * 2, 2, HT, 2, 1, s));
+    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, SPo, 2, HT, 2, 1, s));
     const size_t last = (size_t)(nd - 1) * T * 2;
-    CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (want_aux) {
+        CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     if (taps) {
         if (taps->hs)
             CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)nd * T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -152,9 +152,10 @@ def fuse_nms(cand: torch.Tensor, n_valid: torch.Tensor, nms_thd: float, max_befo
         if n_max is None or cand.dim() != 2 or cand.shape[1] != 4:
             raise ValueError("fuse_nms with cand_off takes a (rows, 4) matrix and the bound n_max")
     dev = cand.device
-    rows = torch.zeros(3, nq, max_after, 5, dtype=torch.float64, device=dev)
-    n = torch.zeros(3, nq, dtype=torch.int32, device=dev)
-    idx = torch.full((3, nq, max_after), -1, dtype=torch.int32, device=dev)
+    # (the kernel writes every element: kept rows, zero rows / -1 past them, the counts -- no fill launches)
+    rows = torch.empty(3, nq, max_after, 5, dtype=torch.float64, device=dev)
+    n = torch.empty(3, nq, dtype=torch.int32, device=dev)
+    idx = torch.empty(3, nq, max_after, dtype=torch.int32, device=dev)
     fn = lib.cone_fuse_nms_f64 if cand.dtype == torch.float64 else lib.cone_fuse_nms
     _lib.check(fn(_lib.ptr(cand), _lib.ptr(cand_off, torch.int64), _lib.ptr(n_valid, torch.int32), nq, int(n_max), float(nms_thd), int(max_before),
                   int(max_after), _lib.ptr(rows), _lib.ptr(n), _lib.ptr(idx), _lib.stream()))

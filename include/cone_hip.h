@@ -262,7 +262,8 @@ int cone_compose_rows(const float* logits, const float* spans, const float* matc
  *   for score_idx in (2 fused, 0 proposal, 1 matching): stable sort desc, [:max_before],
  *   greedy NMS (pseudo-IoU, strict >), stop at max_after; nms_thd == -1 -> top max_after.
  * out_rows (3,nq,max_after,5) fp64 rows [st,ed,prop,match,fused]; out_n (3,nq) int32;
- * out_idx (3,nq,max_after) int32 = index into the query's cand rows (first occurrence of the key). */
+ * out_idx (3,nq,max_after) int32 = index into the query's cand rows (first occurrence of the key).  Every element of the
+ * three outputs is written (rows past out_n: zeros, index -1): the buffers need no initialisation. */
 int cone_fuse_nms(const float* cand, const int64_t* cand_off, const int32_t* n_valid, int nq, int n_max,
                   double nms_thd, int max_before, int max_after, double* out_rows, int32_t* out_n, int32_t* out_idx,
                   void* stream);
