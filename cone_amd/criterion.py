@@ -67,11 +67,20 @@ def _layer_losses(matcher, crit, outputs, targets, neg_outputs, want_saliency):
     L = P = L2 = 0
     if want_saliency and targets is not None and "saliency_pos_labels" in targets:
         sal = _f32(outputs["saliency_scores"])
-        pos, neg = _i32(targets["saliency_pos_labels"].to(dev)), _i32(targets["saliency_neg_labels"].to(dev))
-        L, P = sal.shape[1], pos.shape[1]
-        lo, hi = int(torch.minimum(pos.min(), neg.min())), int(torch.maximum(pos.max(), neg.max()))
-        if lo < 0 or hi >= L:       # the reference's advanced indexing raises here (cone/model.py:335-338)
-            raise IndexError(f"saliency label index out of range for {L} clips: [{lo}, {hi}]")
+        L = sal.shape[1]
+        lab = []
+        for key in ("saliency_pos_labels", "saliency_neg_labels"):
+            t = targets[key]
+            # the reference indexes saliency_scores[batch, label] (cone/model.py:335-338): torch wraps [-L, -1] and raises
+            # outside [-L, L).  Labels come from the dataloader on the HOST: checked and wrapped there (no device sync);
+            # device-resident labels are checked with one asynchronous device assert
+            if t.is_cuda:
+                torch._assert_async(((t >= -L) & (t < L)).all(), f"saliency label index out of range for {L} clips")
+            elif t.numel() and (int(t.min()) < -L or int(t.max()) >= L):
+                raise IndexError(f"saliency label index out of range for {L} clips: [{int(t.min())}, {int(t.max())}]")
+            lab.append(_i32(torch.where(t < 0, t + L, t).to(dev)))
+        pos, neg = lab
+        P = pos.shape[1]
         if neg_outputs is not None:
             nsal = _f32(neg_outputs["saliency_scores"])
             L2 = nsal.shape[1]

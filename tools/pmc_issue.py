@@ -42,6 +42,8 @@ def main():
         c = co.get(k, {})
         act, dur = sum(c.get("GRBM_GUI_ACTIVE", [0.0])), sum(c.get("_dur_ns", [0.0]))
         ghz = (act / 8) / dur if dur else 0.0
+        if dur and dur / max(1, len(c.get("_dur_ns", [1]))) < 200e3:
+            ghz = 0.0       # launches shorter than 200 us: the clock ratio is not a clock (no issue-time figure either)
         busy, coex = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0])), sum(c.get("SQ_VALU_MFMA_COEXEC_CYCLES", [0.0]))
         cyc = (32.0 * mfma + 4.0 * valu + 8.0 * trans) / 1024.0        # per SIMD
         issue_ms = cyc / (ghz * 1e9) * 1e3 if ghz else 0.0

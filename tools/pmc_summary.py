@@ -15,11 +15,22 @@ mis-calibration: its raw 2.24 GB per encoder launch is below the 3.96 GB its two
 count cannot be; doubled it is 1.13 x algorithmic); WRITE_SIZE is exact for 16-B-per-lane stores.
 MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs)."""
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
 
 READ_FACTOR = 2.0
+MIN_CLOCK_US = 200.0        # the effective clock of a launch is GRBM_GUI_ACTIVE / its wall time: meaningless for short kernels
+#                             (the counter runs on while the launch drains; 3.5 - 12 "GHz" came out for anything < 50 us)
+
+
+def csrc_hashes():
+    """sha1 of every kernel source (cone_amd/csrc): the stamp bench.py compares before it quotes a table as `traffic`."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cone_amd", "csrc")
+    return {f: hashlib.sha1(open(os.path.join(d, f), "rb").read()).hexdigest()[:12]
+            for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".c"))}
 
 
 def load(path):
@@ -51,13 +62,14 @@ def main():
         util = 100.0 * (busy / 1024) / (act / 8) if act else 0.0
         durs = mm.get("_dur_ns_GRBM_GUI_ACTIVE", [])
         dur = sum(durs)
-        ghz = (act / 8) / dur if dur else 0.0                   # effective shader clock under the profiler (guide: DVFS)
         avg_us = dur / max(1, len(durs)) / 1e3
+        # effective shader clock under the profiler (guide: DVFS) -- only where a launch is long enough for the ratio to mean it
+        ghz = (act / 8) / dur if dur and avg_us >= MIN_CLOCK_US else None
         rows.append((k, len(fv), rd, wr, rd + wr, util, avg_us, ghz))
         traffic[k] = {"launches": len(fv), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                       "hbm_bytes_per_launch": rd + wr, "fetch_size_raw_bytes_per_launch": rd / READ_FACTOR,
                       "mfma_busy_pct": round(util, 1), "avg_us_profiled": round(avg_us, 1),
-                      "effective_clock_ghz": round(ghz, 3),
+                      "effective_clock_ghz": None if ghz is None else round(ghz, 3),
                       "hbm_gbs_profiled": round((rd + wr) / (avg_us * 1e-6) / 1e9, 1) if avg_us else None}
     if dst.endswith("_prefilter"):
         out_csv, out_json = dst + "_counters.csv", dst + ".json"
@@ -67,7 +79,11 @@ def main():
         o.write("kernel,launches,hbm_read_bytes_per_launch(2 x FETCH_SIZE),hbm_write_bytes_per_launch,hbm_bytes_per_launch,"
                 "mfma_busy_pct,avg_us_profiled,effective_clock_ghz\n")
         for r in rows:
-            o.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.1f},{r[6]:.1f},{r[7]:.3f}\n")
+            clk = "" if r[7] is None else f"{r[7]:.3f}"
+            o.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.1f},{r[6]:.1f},{clk}\n")
+        o.write("# effective_clock_ghz only for launches of >= %.0f us; collected on cone_amd/csrc %s\n"
+                % (MIN_CLOCK_US, " ".join(f"{k}@{v}" for k, v in csrc_hashes().items())))
+    traffic["_csrc"] = csrc_hashes()        # what the counters were collected on (bench.py: another revision => traffic null)
     with open(out_json, "w") as o:
         json.dump(traffic, o, indent=1, sort_keys=True)
     print(open(out_csv).read())
