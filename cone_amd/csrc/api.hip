@@ -518,6 +518,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     // the cross-attention kernel (dec_cross.hip); otherwise memory K/V for all layers in two GEMMs.
     const bool fold = plan.fold;
     const bool want_aux = taps && (taps->hs || taps->aux_logits || taps->aux_spans);
+    bool sal_done = false;
     if (!fold) {
         GemmArgs g = G(m, f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
@@ -550,10 +551,20 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             g.R = m->dec_ca_tab[l]; g.ldr = 256; g.r_mod = m->nq;
             RUN(launch_gemm(g, s));
         }
-        if (fold && m->opt_dec_fold >= 2)
+        if (fold && m->opt_dec_fold >= 2) {
+            // the first layer's launch holds every memory row of the batch in registers anyway: the saliency head rides along
+            // (table form of the default kernel; other forms: the separate pass at the end)
+            const bool ride = l == 0 && saliency && plan.tables && m->opt_dec_fold == 2;
+            if (ride) {
+                CONE_CHECK_HIP(hipMemsetAsync(saliency, 0, (size_t)B * Lv_max * sizeof(float), s));     // padded clips: 0
+                sal_done = true;
+            }
             RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                       f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax,
-                                      Tq != T ? f.QKS : nullptr, s, m->opt_dec_fold == 4));    // layer 0: the same queries for every window; dec_fold 4: the LDS-resident form
+                                      Tq != T ? f.QKS : nullptr, s, m->opt_dec_fold == 4,      // layer 0: the same queries for every window; dec_fold 4: the LDS-resident form
+                                      ride ? m->saliency.w : nullptr, ride ? m->saliency.b : nullptr, ride ? saliency : nullptr,
+                                      ride ? Lv_max : 0));
+        }
         else if (fold)
             RUN(launch_dec_cross(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                  f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, s));
@@ -610,8 +621,8 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (taps->aux_spans && nd > 1)
             CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_spans, f.SP, last * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (saliency || (taps && taps->memory))     // saliency == NULL: not wanted (cone/inference.py never reads it)
-        RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
+    if ((saliency && !sal_done) || (taps && taps->memory))     // saliency == NULL: not wanted (cone/inference.py never reads it)
+        RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, sal_done ? nullptr : saliency, Lv_max,
                             taps ? taps->memory : nullptr, Lq_max, B, s));
     return 0;
 }

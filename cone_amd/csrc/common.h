@@ -231,7 +231,10 @@ size_t dec_cross_mfma_slab_floats();
 bool dec_cross_res_supported(int nq, int Lmax);
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s, bool resident = false);
+                          int Lmax, float* qk_slabs, hipStream_t s, bool resident = false, const float* sal_w = nullptr,
+                          const float* sal_b = nullptr, float* sal = nullptr, int sal_ld = 0);
+// sal != null (table form of the two-read kernel only): the launch also writes the saliency head of the window's clip rows,
+// sal[b][p] = <memory row p, sal_w> + sal_b[0] for p < vlen[b] (sal_ld floats per window; other entries untouched)
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 

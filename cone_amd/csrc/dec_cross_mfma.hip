@@ -52,7 +52,12 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
                                                                  const float* __restrict__ Wk,
                                                                  const float* __restrict__ WvT,
                                                                  const float* __restrict__ bv, float* __restrict__ OUT,
-                                                                 const float* __restrict__ QKS, float* __restrict__ QKS_OUT) {
+                                                                 const float* __restrict__ QKS, float* __restrict__ QKS_OUT,
+                                                                 const float* __restrict__ sal_w, const float* __restrict__ sal_b,
+                                                                 float* __restrict__ sal, int sal_ld) {
+    // sal != null (POSTAB only): the saliency head rides along -- sal[b][p] = <memory row of clip p, sal_w> + sal_b
+    // (cone/model.py:119-122) from the very registers stage A holds the window's memory rows in, instead of a separate pass
+    // over the 2 GB of memory rows (0.4 ms per 20 000-window step).  Entries of padded clips are the caller's zeros.
     // QKS != null: the qk operand slabs are window-independent (first decoder layer: tgt = 0, the queries are the
     // same for every window) and were written once by a one-workgroup launch of this kernel with QKS_OUT set.
     using C = DecCrossMfmaCfg<KTW>;
@@ -84,6 +89,16 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
             const float* kp = KEYS + (size_t)(t0 + key) * 256 + 4 * lg;
 #pragma unroll
             for (int q = 0; q < 16; ++q) xk[w][q] = *reinterpret_cast<const g4v*>(kp + 16 * q);
+            if (POSTAB && sal) {
+                g4v d4 = g4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d4 += xk[w][q] * *reinterpret_cast<const g4v*>(sal_w + 16 * q + 4 * lg);
+                float d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                const int p = kt * 16 + li;
+                if (lg == 0 && p < lv && p < sal_ld) sal[(size_t)b * sal_ld + p] = d + sal_b[0];
+            }
             if (POSTAB && key < lv) {
                 const float* pp = prow + (size_t)key * 256 + 4 * lg;
 #pragma unroll
@@ -729,7 +744,8 @@ static int launch_res_one(const float* DQ, const float* XP, const float* X, cons
 template <int KTW, bool POSTAB>
 static int launch_mfma_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                            const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
-                           float* qk_slabs, hipStream_t s) {
+                           float* qk_slabs, hipStream_t s, const float* sal_w = nullptr, const float* sal_b = nullptr,
+                           float* sal = nullptr, int sal_ld = 0) {
     using C = DecCrossMfmaCfg<KTW>;
     static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
     CONE_CHECK_HIP(device_once(once, [] {
@@ -738,11 +754,12 @@ static int launch_mfma_one(const float* DQ, const float* XP, const float* X, con
     }));
     if (qk_slabs) {     // window-independent queries: the operand slabs once, by one workgroup (window 0's rows)
         hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB>), dim3(1), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
-                           pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs);
+                           pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, 0);
         CONE_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB>), dim3(B), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
-                       pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr);
+                       pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, sal_w, sal_b, sal, sal_ld);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -755,11 +772,14 @@ bool dec_cross_res_supported(int nq, int Lmax) { return nq == 5 && Lmax <= DCR_R
 
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s, bool resident) {
+                          int Lmax, float* qk_slabs, hipStream_t s, bool resident, const float* sal_w, const float* sal_b,
+                          float* sal, int sal_ld) {
     CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
     CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
+    CONE_REQUIRE(!sal || (!XP && !resident && sal_w && sal_b && sal_ld > 0), "fused decoder cross-attention: the saliency "
+                 "head rides only on the table form of the two-read kernel");
     if (resident && dec_cross_res_supported(nq, Lmax)) {    // opt-in: rows LDS-resident, one HBM read per row (<= 110 tokens)
         if (XP) return launch_res_one<false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
         return launch_res_one<true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
@@ -768,8 +788,9 @@ int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, cons
         if (Lmax <= 128) return launch_mfma_one<1, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
         return launch_mfma_one<2, false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
     }
-    if (Lmax <= 128) return launch_mfma_one<1, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
-    return launch_mfma_one<2, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
+    if (Lmax <= 128)
+        return launch_mfma_one<1, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, sal_w, sal_b, sal, sal_ld);
+    return launch_mfma_one<2, true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, sal_w, sal_b, sal, sal_ld);
 }
 
 }  // namespace cone
