@@ -855,16 +855,18 @@ def predict_split(model, store: FeatureStore, opt):
         ev = torch.cuda.Event()
         ev.record()
         pend.append((sub, dp, host, ev))
+    # the split-level tensors of the info dict are enqueued right behind the last chunk, while the GPU is still busy with it
+    # (built after the last chunk's rows were waited for, their four small launches + allocations sat in the GPU-idle gap
+    # at the end of every step)
+    info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
+                n_windows=sum(p[1]["n_windows"] for p in pend), chunks=chunks, win_idx=win_idx,
+                windows={k: torch.cat([p[1]["windows"][k] for p in pend]) for k in ("vid_len", "txt_len")})
     outs = ([], [], [])
     for sub, dp, host, ev in pend:
         ev.synchronize()
         for dst, part in zip(outs, format_results(sub.ann, opt, host[0], host[1])):
             dst.extend(part)
-    model_seconds = time.time() - t0
-    info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
-                n_windows=sum(p[1]["n_windows"] for p in pend), model_seconds=model_seconds, chunks=chunks,
-                win_idx=win_idx,
-                windows={k: torch.cat([p[1]["windows"][k] for p in pend]) for k in ("vid_len", "txt_len")})
+    info["model_seconds"] = time.time() - t0
     return outs, info
 
 
