@@ -117,10 +117,14 @@ class FeatureStore:
         and so are the static index tables it caches on the device (annotation metadata only)."""
         views = self.__dict__.setdefault("_views", {})
         v = views.get((lo, hi))
-        if v is None:
+        # a view aliases the arenas it was cut from: refilling them IN PLACE (copy_) keeps it valid, assigning NEW tensors to
+        # vid_raw / tok_raw / cls_raw does not -- such a view is rebuilt
+        arenas = (self.vid_raw.data_ptr(), self.tok_raw.data_ptr(), self.cls_raw.data_ptr())
+        if v is None or v._arenas != arenas:
             if len(views) > 32:
                 views.clear()
             v = views[(lo, hi)] = FeatureStore.subset(self, lo, hi)
+            v._arenas = arenas
         return v
 
     def index_tensors(self):

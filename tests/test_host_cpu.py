@@ -312,3 +312,26 @@ def test_bench_plain_entry_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_store_views_are_cached_and_follow_replaced_arenas():
+    """FeatureStore.view: the same (lo, hi) view object step after step (its static index tables are uploaded once), rebuilt
+    when the parent's arenas are REPLACED by new tensors (an in-place refill keeps the view: it aliases the arena)."""
+    from cone_amd import inference as inf
+    opt = make_opt("ego4d", topk_window=3, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(opt, 9, 2, seed=3, ctx_range=(30, 120))
+    store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+    v1 = store.view(2, 7)
+    assert store.view(2, 7) is v1 and v1.q_base == 2 and len(v1.ann) == 5
+    assert v1.tok_raw.data_ptr() == store.tok_raw[int(store.tok_off[2]):].data_ptr()
+    store.tok_raw.mul_(2.0)                                   # in place: the view sees it
+    assert store.view(2, 7) is v1 and torch.equal(v1.tok_raw, store.tok_raw[int(store.tok_off[2]):int(store.tok_off[7])])
+    store.tok_raw = store.tok_raw.clone()                     # replaced: the cached view would be stale
+    v2 = store.view(2, 7)
+    assert v2 is not v1 and v2.tok_raw.data_ptr() == store.tok_raw[int(store.tok_off[2]):].data_ptr()
+    # the shape of the window list is host metadata: a query owns min(K, ceil(ctx_l / S) + 1) rows
+    sel = inf.selection(store, opt)
+    S = int(opt.max_v_l / 2)
+    assert sel.n_q.tolist() == [min(3, -(-store.ctx_l[v] // S) + 1) for v in store.q_vid.tolist()]
+    assert sel.row_off[-1] == sel.n_rows and [sel.query_of_row(r) for r in range(sel.n_rows)] == \
+        [q for q, n in enumerate(sel.n_q.tolist()) for _ in range(n)]
