@@ -24,8 +24,9 @@
 //             probability registers are directly the A operand of O = P . V (k slot g <-> key 4g + r of the tile;
 //             the MFMA k index may be permuted freely as long as A and B agree).  The head dim is walked as
 //             d = 8 g + step so that a lane's 8 query values are two contiguous float4.
-//   P.V     : V rows are read at stride 36 floats, K is staged d-major [32][KP + 2]: both conflict-free for
-//             ds_read_b32.
+//   P.V     : V rows are read at stride 36 floats, K is staged d-major [32][KP + 2]: both conflict-free for ds_read_b32.
+//             The keys of a tile sit PERMUTED in both images (key kk in row 4 (kk % 4) + kk / 4), so that P.V's MFMA r covers the
+//             consecutive keys 4 r .. 4 r + 3 and is skipped when they lie past the window's end.
 #include "common.h"
 
 namespace cone {
@@ -38,7 +39,9 @@ constexpr float kQScaleLog2 = 0.17677669529663687f * 1.4426950408889634f;
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 typedef float f32x2m __attribute__((ext_vector_type(2)));
 
-// Row softmax of one query column held as NKT x 4 score registers per lane (key 16 kt + 4 lg + r), shared by both kernel
+// Row softmax of one query column held as NKT x 4 score registers per lane (key 16 kt + 4 r + lg: the keys of a tile are
+// PERMUTED on the way into the S^T operand -- row 4 lg + r of the accumulator is key 4 r + lg -- so that the four keys of
+// P.V's MFMA r are CONSECUTIVE (4 r .. 4 r + 3) and the MFMAs of key quads past the window's end can be skipped), shared by both kernel
 // forms (same operations in the same order: identical bits).  Vector instructions do not hide under the exact-fp32 MFMA on
 // this part (tools/probe/mfma_valu_overlap.hip), so every one of them is on the critical path -- the count is what matters:
 //   * the scores arrive in the log2 domain (log2(e) is folded into the q scale): exp2(s - m) is ONE packed subtract per two
@@ -57,13 +60,13 @@ __device__ __forceinline__ float lane_xor(float v, int lane, int mask) {
 
 template <int NKT>
 __device__ __forceinline__ float attn_softmax(f32x4m (&sc)[NKT], int L, int lane, int lg) {
-    const int lim = L - 4 * lg;                     // key 16 kt + 4 lg + r is real iff 16 kt + r < lim
+    const int lim = L - lg;                         // key 16 kt + 4 r + lg is real iff 16 kt + 4 r < lim
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         if (16 * (kt + 1) > L) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + r < lim) ? sc[kt][r] : -INFINITY;
+            for (int r = 0; r < 4; ++r) sc[kt][r] = (16 * kt + 4 * r < lim) ? sc[kt][r] : -INFINITY;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
@@ -186,9 +189,11 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
         const int key = kr + it * (NT / 8);
         f32x4m k4 = kv[it];
         if (MODE != ATTN_PACKED) k4 += kt_[it];
-        float* kd = KsT + c4 * LDK + key;
+        // key kk of a tile sits in operand row 4 (kk % 4) + kk / 4, in both images
+        const int pos = (key & ~15) + 4 * (key & 3) + ((key >> 2) & 3);
+        float* kd = KsT + c4 * LDK + pos;
         kd[0] = k4[0]; kd[LDK] = k4[1]; kd[2 * LDK] = k4[2]; kd[3 * LDK] = k4[3];
-        *reinterpret_cast<f32x4m*>(Vs + key * LDV + c4) = vv[it];
+        *reinterpret_cast<f32x4m*>(Vs + pos * LDV + c4) = vv[it];
     }
     __syncthreads();
     if (q0 >= L) return;
@@ -210,11 +215,15 @@ __global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, floa
     f32x4m o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;
+        const float* vp = Vs + (kt * 16 + 4 * lg) * LDV + li;       // MFMA r: image rows 4 lg + r = keys 16 kt + 4 r + lg, lg = 0 .. 3
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV + 16], o1, 0, 0, 0);
+            // the last two tiles of a launch may reach past this window: a key quad entirely behind its end multiplies exact
+            // zeros (wave-uniform test; earlier tiles are always walked: no branch)
+            if (kt < NKT - 2 || 16 * kt + 4 * r < L) {
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r], vp[r * LDV + 16], o1, 0, 0, 0);
+            }
         }
     }
     attn_normalise(o0, o1, inv, lane, lg);
@@ -291,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float*
         }
     };
     load_q(0);
-    // keys: kreg[kt][st] = K[key 16 kt + li][8 lg + st] (rows past the window: a copy of its last row, masked below)
+    // keys: kreg[kt][st] = K[key of operand row li][8 lg + st] (rows past the window: a copy of its last row, masked below)
     float kreg[NKT][8];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const int key = min(16 * kt + li, L - 1);
+        const int key = min(16 * kt + 4 * (li & 3) + (li >> 2), L - 1);     // operand row li = key 4 (li % 4) + li / 4 of the tile
         const float* kp_ = kptr(key) + 8 * lg;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -305,13 +314,13 @@ __global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float*
             for (int j = 0; j < 4; ++j) kreg[kt][4 * u + j] = k4[j];
         }
     }
-    // values: vreg[kt][r][dt] = V[key 16 kt + 4 lg + r][16 dt + li]
+    // values: vreg[kt][r][dt] = V[key 16 kt + 4 r + lg][16 dt + li]
     float vreg[NKT][4][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float* vp_ = vptr(min(16 * kt + 4 * lg + r, L - 1));
+            const float* vp_ = vptr(min(16 * kt + 4 * r + lg, L - 1));
             vreg[kt][r][0] = vp_[li];
             vreg[kt][r][1] = vp_[16 + li];
         }
