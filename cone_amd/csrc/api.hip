@@ -53,8 +53,9 @@ struct cone_model {
     // qe W_q^T + b_q for the cross-attention query projection -- the same move as the encoder's position tables
     float* dec_sa_tab[CONE_MAX_LAYERS] = {}; float* dec_ca_tab[CONE_MAX_LAYERS] = {};
     // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
-    int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 = on the matrix
-                              // cores (dec_cross_mfma.hip), 1 = on the VALU (dec_cross.hip), 0 = K/V GEMMs + small_attn
+    int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 .. 5 = on the matrix
+                              // cores (dec_cross_mfma.hip; which form: see launch_dec_cross_mfma), 1 = on the VALU
+                              // (dec_cross.hip), 0 = K/V GEMMs + small_attn
     int opt_dec0_const = 1;   // first decoder layer's window-independent rows computed once and replicated
     int opt_l0_gather = 1;    // first encoder layer's attention gathers q|k|v from the layer-0 caches itself
     int opt_pos_tables = 1;   // later layers / decoder keys take the position term from the static tables
@@ -554,14 +555,18 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (fold && m->opt_dec_fold >= 2) {
             // the first layer's launch holds every memory row of the batch in registers anyway: the saliency head rides along
             // (table form of the default kernel; other forms: the separate pass at the end)
-            const bool ride = l == 0 && saliency && plan.tables && m->opt_dec_fold == 2;
+            const bool ride = l == 0 && saliency && plan.tables && (m->opt_dec_fold == 2 || m->opt_dec_fold == 3 || m->opt_dec_fold == 5);
             if (ride) {
                 CONE_CHECK_HIP(hipMemsetAsync(saliency, 0, (size_t)B * Lv_max * sizeof(float), s));     // padded clips: 0
                 sal_done = true;
             }
             RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
                                       f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax,
-                                      Tq != T ? f.QKS : nullptr, s, m->opt_dec_fold == 4,      // layer 0: the same queries for every window; dec_fold 4: the LDS-resident form
+                                      Tq != T ? f.QKS : nullptr, s,       // layer 0: the same queries for every window
+                                      // the kernel form.  Default: rows-once for the first layer, two-read behind it -- by
+                                      // LAYER, not by whether this batch shares its slabs (a one-window batch does not): a
+                                      // window's bits must not depend on the batch it rides in
+                                      m->opt_dec_fold == 2 ? (l == 0 ? 5 : 3) : m->opt_dec_fold,
                                       ride ? m->saliency.w : nullptr, ride ? m->saliency.b : nullptr, ride ? saliency : nullptr,
                                       ride ? Lv_max : 0));
         }
@@ -816,7 +821,7 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
 extern "C" int cone_model_set_option(cone_model* m, const char* name, int value) {
     CONE_REQUIRE(m && name, "set_option: null argument");
     if (!strcmp(name, "dec_fold")) {
-        CONE_REQUIRE(value >= 0 && value <= 4 && value != 3, "set_option: dec_fold %d not in {0, 1, 2, 4}", value);
+        CONE_REQUIRE(value >= 0 && value <= 5, "set_option: dec_fold %d not in [0, 5]", value);
         m->opt_dec_fold = value;
         return 0;
     }
@@ -918,7 +923,7 @@ extern "C" int cone_test_dec_cross(const float* DQ, const float* X, const float*
     if (variant == 1)
         return launch_dec_cross(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, (hipStream_t)stream);
     return launch_dec_cross_mfma(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, nq, Lmax, qk_slabs,
-                                 (hipStream_t)stream, variant == 4);
+                                 (hipStream_t)stream, variant);
 }
 extern "C" size_t cone_test_dec_cross_slab_floats(void) { return dec_cross_mfma_slab_floats(); }
 extern "C" int cone_test_layernorm(const float* x, const float* g, const float* b, float* out, int64_t n_rows,

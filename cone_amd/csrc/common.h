@@ -226,12 +226,14 @@ int launch_dec_cross(const float* DQ, const float* XP, const float* X, const flo
 // qk_slabs (dec_cross_mfma_slab_floats() floats of scratch, or null): the queries are the same rows for every window
 // (first decoder layer): the folded-key operand is built once instead of per window
 size_t dec_cross_mfma_slab_floats();
-// resident (opt-in): windows of at most 110 tokens run the LDS-resident persistent form (dec_cross_res_kernel: every memory
-// row read from HBM once; measured slower than the two-read form, see the kernel); same arithmetic, stage for stage
+// form 2 (default): windows of at most 128 tokens run dec_cross_x_kernel (rows read ONCE: the registers of stage A transposed
+// through LDS by channel quarters for stage C; two workgroups per CU), longer ones the two-read kernel; form 3: always the
+// two-read kernel; form 4 (opt-in): windows of at most 110 tokens on the LDS-resident persistent form (dec_cross_res_kernel:
+// one workgroup per CU, measured slower)
 bool dec_cross_res_supported(int nq, int Lmax);
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s, bool resident = false, const float* sal_w = nullptr,
+                          int Lmax, float* qk_slabs, hipStream_t s, int form = 2, const float* sal_w = nullptr,
                           const float* sal_b = nullptr, float* sal = nullptr, int sal_ld = 0);
 // sal != null (table form of the two-read kernel only): the launch also writes the saliency head of the window's clip rows,
 // sal[b][p] = <memory row p, sal_w> + sal_b[0] for p < vlen[b] (sal_ld floats per window; other entries untouched)

@@ -323,6 +323,317 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dec_cross_x_kernel: the same computation with the window's memory rows read ONCE, at two workgroups per CU.
+//
+// Stage A holds the window in registers (lane = key: 16 keys x 256 channels per wave); stage C needs it by channel (lane =
+// channel).  The two-read kernel above fetches the rows a second time from global memory for that -- from beyond the L2, in
+// 64-byte pieces, latency-bound -- and the LDS-resident form below pays for its 110-KiB image with one workgroup per CU.
+// Here the registers ARE the image and are transposed through LDS a channel QUARTER at a time: each wave parks the 64
+// channels of its 16 keys (four ds_write_b128 per lane) in a [128 keys][64 + 16] tile whose 16-B chunks are XOR-swizzled by
+// the key (2-way conflicts on the writes, none on stage C's ds_read_b32 of lanes (key 4 s + lg, channel 16 ct + li)), the
+// eight waves multiply it as (channel tile ct = w % 4) x (key half w / 4) against all pair tiles, and the next quarter
+// follows: 36 KiB of LDS beside Pt, 69 KiB per workgroup in all -- two per CU as before.  For the position term the rows must
+// stay RAW in the registers (stage C multiplies memory, not memory + pos), so stage A walks the channels in the OUTER loop and
+// forms memory + pos per 16-channel step in a temporary (the position row of that step is requested a step ahead); two
+// partial chains per pair tile keep an accumulator two MFMAs apart.  The key halves of a channel tile meet in LDS (the
+// second half adds to the first: two addends, order-independent).
+constexpr int DCR_QK = 32 * 256 + 16 * 128;         // compact slabs: pair tiles 0, 1 [16 q][16 rows][16], tile 2 [16 q][8 rows][16]
+constexpr int DCX_QS = 80;                          // row stride (floats) of the quarter tile: = 16 mod 32
+constexpr int DCX_REGA = 128 * 48 + 128 * DCX_QS;   // Pt [128][48] + the quarter tile [128][80] (>= slabs, ctx, partials)
+constexpr int DCX_LDS_FLOATS = DCX_REGA + 2 * 8 * 48;
+static_assert(DCX_REGA >= DCR_QK && DCX_REGA >= 40 * 260 && DCX_REGA >= 8 * 5 * 256, "region A holds each of its tenants");
+
+template <bool POSTAB>
+__global__ __launch_bounds__(512, 4) void dec_cross_x_kernel(const float* __restrict__ DQ, const float* __restrict__ XP,
+                                                             const float* __restrict__ X, const float* __restrict__ pos_rows,
+                                                             const int* __restrict__ vlen, const int* __restrict__ off,
+                                                             const float* __restrict__ Wk, const float* __restrict__ WvT,
+                                                             const float* __restrict__ bv, float* __restrict__ OUT,
+                                                             const float* __restrict__ QKS, float* __restrict__ QKS_OUT,
+                                                             const float* __restrict__ sal_w, const float* __restrict__ sal_b,
+                                                             float* __restrict__ sal, int sal_ld) {
+    constexpr int NQ = 5, NPT = 3, NPP = 48, NP = 40, CTX_LD = 260;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* regA = smem;                         // slabs (compact, 40 KiB) -> Pt + quarter tile -> ctx -> stage D partials
+    float* Pt = regA;                           // [128][48]
+    float* Qt = regA + 128 * NPP;               // [128][DCX_QS]
+    float* smax = regA + DCX_REGA;              // [8][48]
+    float* ssum = smax + 8 * NPP;               // [8][48]
+    const int b = blockIdx.x;
+    const int t0 = off[b];
+    const int L = min(off[b + 1] - t0, 128);
+    const int nkt = (L + 15) >> 4;
+    const int lv = POSTAB ? vlen[b] : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int rdA = li * 16 + ((lg ^ dcm_swz16(li)) << 2);
+    const int li8 = li & 7;
+    const int rdB = li8 * 16 + ((lg ^ dcm_swz16(li8)) << 2);
+    auto slab = [](int pt, int q) { return pt < 2 ? (pt * 16 + q) * 256 : 32 * 256 + q * 128; };
+
+    // ---- this wave's key rows, RAW (POSTAB: the memory rows; else memory + pos as given), requested first
+    // (the first 128 channels ahead of stage 0, the other 128 behind it: stage A walks the channels in order, so the second
+    // half has eight steps of MFMAs to land under, and stage 0 keeps the registers for a four-row look-ahead on W_k)
+    g4v xk[16];
+    const int my_key = min(wave * 16 + li, L - 1);
+    const bool have = wave < nkt && !QKS_OUT;
+    const float* kp = (POSTAB ? X : XP) + (size_t)(t0 + my_key) * 256 + 4 * lg;
+    if (have) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xk[q] = *reinterpret_cast<const g4v*>(kp + 16 * q);
+    }
+
+    // ---- stage 0: the folded-query slabs (compact layout)
+    if (QKS) {
+        for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(regA)[i] = reinterpret_cast<const g4v*>(QKS)[i];
+    } else {
+        const float* __restrict__ qb = DQ + (size_t)b * NQ * 256 + wave * 32;
+        const float* wb = Wk + (size_t)wave * 32 * 256;
+        const unsigned l4 = 4u * lane;
+        g4v a[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) a[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        g4v wn[4], wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + i * 256 + l4);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+            if (g < 7) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + ((g + 1) * 4 + i) * 256 + l4);
+            }
+            // (a fence per step: left alone, the scheduler either hoists W_k rows until the key rows spill, or -- with the loop
+            // rolled -- sinks each step's loads to their use and every step waits out an L2 round trip)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < NQ; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[s] += wc[i] * qb[s * 256 + g * 4 + i];
+        }
+        const int c = 4 * lane;
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+            const int p = s * 8 + wave, row = p & 15;
+            *reinterpret_cast<g4v*>(regA + slab(p >> 4, c >> 4) + row * 16 + ((((c >> 2) & 3) ^ dcm_swz16(row)) << 2)) =
+                a[s] * 0.17677669529663687f;
+        }
+    }
+    if (have) {                                             // the key rows' second half (see above)
+        const float* kp2 = kp;
+        asm volatile("" : "+v"(kp2));                       // not hoisted over stage 0 (the registers are W_k's there)
+        const float __attribute__((address_space(1)))* kg = (const float __attribute__((address_space(1)))*)kp2;
+#pragma unroll
+        for (int q = 8; q < 16; ++q) xk[q] = *reinterpret_cast<const g4v __attribute__((address_space(1)))*>(kg + 16 * q);
+    }
+    __syncthreads();                                        // slabs complete
+    if (QKS_OUT) {  // slab-building launch (one workgroup): publish and stop
+        for (int i = tid; i < DCR_QK / 4; i += 512) reinterpret_cast<g4v*>(QKS_OUT)[i] = reinterpret_cast<const g4v*>(regA)[i];
+        return;
+    }
+
+    // ---- stage A: scores of this wave's key tile against the 48 pairs, channels in the outer loop
+    g4v sc[NPT];
+    if (wave >= nkt) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) sc[pt] = g4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    } else {
+        g4v ch[NPT][2];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) { ch[pt][0] = g4v{0.f, 0.f, 0.f, 0.f}; ch[pt][1] = ch[pt][0]; }
+        const int pk = max(min(my_key, lv - 1), 0);         // a text key re-reads a clip's position row and is masked out
+        const float* pp = POSTAB ? pos_rows + ((size_t)(lv * (lv - 1) / 2) + pk) * 256 + 4 * lg : nullptr;
+        const float pmask = my_key < lv ? 1.f : 0.f;
+        g4v pn = g4v{0.f, 0.f, 0.f, 0.f};
+        if (POSTAB) pn = *reinterpret_cast<const g4v*>(pp);
+        g4v d4 = g4v{0.f, 0.f, 0.f, 0.f};                  // the saliency head rides along (see dec_cross_mfma_kernel)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            g4v t = xk[q];
+            if (POSTAB && sal) d4 += t * *reinterpret_cast<const g4v*>(sal_w + 16 * q + 4 * lg);
+            if (POSTAB) {
+                t += pn * pmask;
+                if (q < 15) pn = *reinterpret_cast<const g4v*>(pp + 16 * (q + 1));
+            }
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const g4v w4 = *reinterpret_cast<const g4v*>(regA + slab(pt, q) + (pt < 2 ? rdA : rdB));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ch[pt][r & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[r], w4[r], ch[pt][r & 1], 0, 0, 0);
+            }
+        }
+        if (POSTAB && sal) {
+            float d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            const int pc = wave * 16 + li;
+            if (lg == 0 && pc < lv && pc < sal_ld) sal[(size_t)b * sal_ld + pc] = d + sal_b[0];
+        }
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            g4v s4 = ch[pt][0] + ch[pt][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (wave * 16 + 4 * lg + r >= L) s4[r] = -INFINITY;       // key 4 lg + r of the tile is padding
+            sc[pt] = s4;
+        }
+    }
+
+    // ---- stage B: softmax over the keys of each pair
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        float m = fmaxf(fmaxf(sc[pt][0], sc[pt][1]), fmaxf(sc[pt][2], sc[pt][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (lg == 0) smax[wave * NPP + pt * 16 + li] = m;
+    }
+    __syncthreads();                                        // every wave is past stage A: the slabs are dead
+    float inv[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        float m = smax[pt * 16 + li];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, smax[w * NPP + pt * 16 + li]);
+        const float m2 = m * 1.4426950408889634f;
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[pt][r], 1.4426950408889634f, -m2));   // exp(-inf) = 0
+            sc[pt][r] = e;
+            l += e;
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (lg == 0) ssum[wave * NPP + pt * 16 + li] = l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        float l = ssum[pt * 16 + li];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) l += ssum[w * NPP + pt * 16 + li];
+        inv[pt] = 1.0f / l;
+    }
+    if (wave < nkt) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pt[(wave * 16 + 4 * lg + r) * NPP + pt * 16 + li] = sc[pt][r] * inv[pt];
+    }
+
+    // ---- stage C, a channel quarter at a time: ctx[p][c] = sum_j P[p][j] * mem[j][c]
+    // wave = (channel tile ct of the quarter, key half kh); quarter-tile chunk swizzle f(key) = (key / 2) % 4
+    const int ct = wave & 3, kh = wave >> 2;
+    const int krow = wave * 16 + li;                        // this lane's key row of the tile it parks
+    const int fw = (krow >> 1) & 3;
+    g4v acc[4][NPT];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        if (wave < nkt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<g4v*>(Qt + krow * DCX_QS + (((4 * j + lg) ^ fw) << 2)) = xk[4 * qq + j];
+        }
+        __syncthreads();                                    // the quarter (and, the first time, Pt) is complete
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[qq][pt] = g4v{0.f, 0.f, 0.f, 0.f};
+        const int s0 = kh * 2 * nkt, s1 = s0 + 2 * nkt;     // this half's k-steps (4 keys each) of the 4 nkt
+#pragma unroll 2
+        for (int s = s0; s < s1; ++s) {
+            const int key = 4 * s + lg;                     // rows [L, 16 nkt) are finite copies of the last row, their P is 0
+            const float a0 = Qt[key * DCX_QS + (((4 * ct + (li >> 2)) ^ ((key >> 1) & 3)) << 2) + (li & 3)];
+            const float* pr = Pt + key * NPP + li;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+                acc[qq][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, pr[pt * 16], acc[qq][pt], 0, 0, 0);
+        }
+        __syncthreads();                                    // the quarter tile is free again
+    }
+    // the two key halves of a channel tile meet in the ctx rows: the first half stores, the second adds
+    float* ctxs = regA;                                     // [40][260] (Pt and the tile are dead: barrier above)
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        if (kh == hlf) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {
+                    const int p = pt * 16 + li;
+                    if (p < NP) {
+                        float* cp = ctxs + p * CTX_LD + 64 * qq + 16 * ct + 4 * lg;
+                        g4v v = acc[qq][pt];
+                        if (hlf) v += *reinterpret_cast<const g4v*>(cp);
+                        *reinterpret_cast<g4v*>(cp) = v;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- stage D: out[s][o] = sum_c WvT[c][o] * ctx[(s, o / 32)][c] + bv[o] (as in dec_cross_mfma_kernel)
+    {
+        g4v o[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) o[s] = g4v{0.f, 0.f, 0.f, 0.f};
+        const float* wb = WvT + (size_t)wave * 32 * 256;
+        const unsigned l4 = 4u * lane;
+        const float* crow = ctxs + (lane >> 3) * CTX_LD + 32 * wave;
+        g4v wn[4], wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + i * 256 + l4);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+            if (g < 7) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + ((g + 1) * 4 + i) * 256 + l4);
+            }
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                const g4v cx = *reinterpret_cast<const g4v*>(crow + s * 8 * CTX_LD + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[s] += wc[i] * cx[i];
+            }
+        }
+        __syncthreads();                                    // every wave is done reading ctx
+        float* part = regA;                                 // [8 waves][5][256]
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) *reinterpret_cast<g4v*>(part + (wave * NQ + s) * 256 + 4 * lane) = o[s];
+        __syncthreads();
+        for (int i = tid; i < NQ * 256; i += 512) {
+            float v = part[i];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) v += part[w * NQ * 256 + i];
+            OUT[(size_t)b * NQ * 256 + i] = v + bv[i & 255];
+        }
+    }
+}
+
+template <bool POSTAB>
+static int launch_x_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen, const int* off,
+                        const float* Wk, const float* WvT, const float* bv, float* OUT, int B, float* qk_slabs, hipStream_t s,
+                        const float* sal_w, const float* sal_b, float* sal, int sal_ld) {
+    static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)dec_cross_x_kernel<POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   DCX_LDS_FLOATS * 4);
+    }));
+    if (qk_slabs) {     // window-independent queries: the (compact) operand slabs once, by one workgroup
+        hipLaunchKernelGGL((dec_cross_x_kernel<POSTAB>), dim3(1), dim3(512), DCX_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen, off,
+                           Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, (const float*)nullptr, (const float*)nullptr,
+                           (float*)nullptr, 0);
+        CONE_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((dec_cross_x_kernel<POSTAB>), dim3(B), dim3(512), DCX_LDS_FLOATS * 4, s, DQ, XP, X, pos_rows, vlen, off, Wk,
+                       WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, sal_w, sal_b, sal, sal_ld);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // dec_cross_res_kernel: the same computation with the window's memory rows read from HBM ONCE.
 //
 // The kernel above reads every memory row twice from beyond the L2 -- by key rows for the scores (stage A: lane = key), by
@@ -359,7 +670,6 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
 // outstanding per wave (vmcnt is 6 bits), the whole schedule stays below that.
 constexpr int DCR_RMAX = 110;                       // rows of the LDS image
 constexpr int DCR_ROWS = DCR_RMAX * 256;
-constexpr int DCR_QK = 32 * 256 + 16 * 128;         // compact slabs: pair tiles 0, 1 [16 q][16 rows][16], tile 2 [16 q][8 rows][16]
 constexpr int DCR_CTX_LD = 260;
 constexpr int DCR_REGB = 40 * DCR_CTX_LD + 5 * 256 + 96;   // >= the slabs, Pt [128][48], ctx [40][260], stage D partials [8][5][256]
 constexpr int DCR_LDS_FLOATS = DCR_ROWS + DCR_REGB + 2 * 8 * 48;
@@ -772,14 +1082,23 @@ bool dec_cross_res_supported(int nq, int Lmax) { return nq == 5 && Lmax <= DCR_R
 
 int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
-                          int Lmax, float* qk_slabs, hipStream_t s, bool resident, const float* sal_w, const float* sal_b,
+                          int Lmax, float* qk_slabs, hipStream_t s, int form, const float* sal_w, const float* sal_b,
                           float* sal, int sal_ld) {
     CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
     CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
-    CONE_REQUIRE(!sal || (!XP && !resident && sal_w && sal_b && sal_ld > 0), "fused decoder cross-attention: the saliency "
-                 "head rides only on the table form of the two-read kernel");
+    CONE_REQUIRE(!sal || (!XP && form != 4 && sal_w && sal_b && sal_ld > 0), "fused decoder cross-attention: the saliency "
+                 "head rides only on the table form of the register-row kernels");
+    // rows read once: registers transposed through LDS by channel quarters (two workgroups per CU).  Table form only: with a
+    // precomputed memory + pos matrix the registers of stage A do not hold the rows stage C multiplies
+    // -- and only where the queries are shared (first layer): with per-window queries the fold of stage 0 is VALU work this
+    // kernel has no idle issue slots left to hide (1.62 ms against the two-read kernel's 1.50 on 20 000 windows; shared: 1.36
+    // against 1.47)
+    // (form 5: everywhere it can run -- the parity tests and tools/dec_cross_bench.py)
+    if ((form == 5 || (form == 2 && qk_slabs)) && Lmax <= 128 && !XP)
+        return launch_x_one<true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, sal_w, sal_b, sal, sal_ld);
+    const bool resident = form == 4;
     if (resident && dec_cross_res_supported(nq, Lmax)) {    // opt-in: rows LDS-resident, one HBM read per row (<= 110 tokens)
         if (XP) return launch_res_one<false>(DQ, XP, X, nullptr, nullptr, off, Wk, WvT, bv, OUT, B, qk_slabs, s);
         return launch_res_one<true>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s);

@@ -339,11 +339,15 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
 /* -------------------------------------------------------------------- test hooks
  * Thin entry points onto single kernels so that parity tests can bisect; not needed by a binding. */
 /* A/B switches of ONE model handle for the parity tests (not thread-safe; set them before using the handle).
- * "dec_fold" (default 2): decoder cross-attention with the memory K/V projections folded into one kernel per layer,
- *   2 = its two 256-channel contractions on the matrix cores (dec_cross_mfma.hip); 4 (opt-in) = the same with windows of at
- *   most 110 tokens on the LDS-resident persistent form that reads every memory row from HBM once (half the row traffic,
- *   measured 1.3 - 1.4 x slower: one workgroup per CU); 1 = on the VALU (dec_cross.hip); 0 = two stacked K/V GEMMs +
- *   per-head attention.
+ * "dec_fold" (default 2): decoder cross-attention with the memory K/V projections folded into one kernel per layer, its
+ *   two 256-channel contractions on the matrix cores (dec_cross_mfma.hip).  2 = the first layer (the same queries for
+ *   every window, windows of at most 128 tokens, position tables) on the rows-once form -- every memory row is read from
+ *   HBM once, kept in registers and handed to the second contraction through LDS a 64-channel quarter at a time, two
+ *   workgroups per CU -- and every other launch on the two-read form; 3 = the two-read form everywhere; 5 = the rows-once
+ *   form wherever it can run (per-window queries too: measured slower there, its query fold has no idle issue slots to
+ *   hide in); 4 (opt-in) = windows of at most 110 tokens on the LDS-resident persistent form (one HBM read per row as
+ *   well, but one workgroup per CU: measured 1.3 - 1.4 x slower); 1 = on the VALU (dec_cross.hip); 0 = two stacked K/V
+ *   GEMMs + per-head attention.
  * "l0_gather" (default 1): with a cone_layer0 cache the first encoder layer's attention gathers q|k|v from the
  *   caches in its staging loads; 0 = a packing kernel writes them to the workspace first.  Bit-identical.
  * "pos_tables" (default 1): later encoder layers and the decoder keys take the position term from the static
@@ -412,9 +416,9 @@ int cone_test_enc_attn(int mode, const float* QKV, const float* qkv_vid, const f
  * DQ (B * nq, 256) projected queries (+ bias), X (M, 256) memory rows packed by off (B + 1), pos_rows / vlen = the sine
  * table and the clip count of each window (keys = memory + position row for clip tokens), Wk (256, 256) = rows
  * 256 .. 511 of in_proj_weight, WvT (256, 256) = W_v transposed, bv (256).  OUT (B * nq, 256) = attention output ahead
- * of out_proj.  variant 2: matrix cores (qk_slabs != NULL: every window has the SAME nq query rows, the folded operand
- * is built once into that scratch of cone_test_dec_cross_slab_floats() floats); 4: matrix cores, the LDS-resident persistent
- * form for windows of at most 110 tokens (the two-read form beyond); 1: VALU kernel. */
+ * of out_proj.  variant = the "dec_fold" value (cone_model_set_option): 2 default policy, 3 two-read, 5 rows-once, 4 LDS-
+ * resident, 1 VALU.  qk_slabs != NULL (matrix-core forms): every window has the SAME nq query rows, the folded operand is
+ * built once into that scratch of cone_test_dec_cross_slab_floats() floats. */
 int cone_test_dec_cross(const float* DQ, const float* X, const float* pos_rows, const int32_t* vlen, const int32_t* off,
                         const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq, int Lmax,
                         int variant, float* qk_slabs, void* stream);

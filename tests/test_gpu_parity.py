@@ -450,6 +450,18 @@ def test_position_tables_equal_materialised_pos_path(preset):
         assert maxdiff(outs[0][k], outs[2][k].cpu()) < 5e-5, ("ffn_fused 0", k)
         assert maxdiff(outs[0][k], outs[3][k].cpu()) < 5e-5, ("ffn_fused 1", k)
         assert maxdiff(outs[0][k], outs[4][k].cpu()) < 5e-5, ("dec_fold 1", k)
+    # the matrix-core forms of the folded cross-attention on the table path: default policy (rows-once kernel for the
+    # first decoder layer, saliency head riding on it) against two-read everywhere and rows-once everywhere
+    forms = {}
+    try:
+        for fold in (2, 3, 5):
+            model.set_option("dec_fold", fold)
+            forms[fold] = inf.run_windows(model, store, opt, wt)
+    finally:
+        model.set_option("dec_fold", 2)
+    for fold in (3, 5):
+        for k in ("pred_logits", "pred_spans", "saliency_scores"):
+            assert maxdiff(forms[2][k], forms[fold][k].cpu()) < 2e-5, ("dec_fold", fold, k)
         assert torch.equal(outs[0][k], outs[5][k]), ("res_gather 0", k)         # the same rows, read from another place
         assert maxdiff(outs[0][k], outs[6][k].cpu()) < 5e-5, ("split_bf16", k)
         assert torch.equal(outs[6][k], outs[7][k]), ("qkv_fused 0", k)          # the same products in the same order
@@ -1828,16 +1840,18 @@ def test_window_table_kernel_matches_index_arithmetic(q_base):
         assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
 
 
-@pytest.mark.parametrize("variant", [2, 4, 1])
+@pytest.mark.parametrize("variant", [2, 5, 3, 4, 1])
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("case", ["ragged128", "many110"])
 def test_fused_decoder_cross_attention_matches_float64(variant, shared, case):
     """dec_cross_mfma.hip / dec_cross.hip called directly: attention of the nq query slots over a window's memory rows with
     the K / V projections folded into the queries / the context (cone/transformer.py:308-311), keys = memory + sine row for
     clip tokens, against nn.MultiheadAttention's arithmetic in float64.  ``ragged128``: 1 clip, no text, 128 keys, a
-    window with text only (longer than 110 tokens: the two-read MFMA form whatever the variant); ``many110``: 700 windows of
-    1 .. 110 tokens -- variant 4 = the opt-in LDS-resident PERSISTENT form (one workgroup per CU walks several windows: the
-    cross-window prefetch, the row DMA, the shared LDS region), variant 2 = the default two-read form on the same input;
+    window with text only; ``many110``: 700 windows of 1 .. 110 tokens.  Variant 2 = the default policy (shared queries:
+    the rows-once form; else the two-read form), 5 = the rows-once form for any queries (every memory row read once, the
+    registers of stage A handed to stage C through LDS by channel quarters; windows of up to 128 tokens), 3 = the two-read
+    form, 4 = the opt-in LDS-resident PERSISTENT form (one workgroup per CU walks several windows; up to 110 tokens, the
+    two-read form beyond), 1 = the VALU kernel;
     ``shared``: every window has the same query rows (first decoder layer)."""
     from cone_amd import _lib
     if shared and variant == 1:

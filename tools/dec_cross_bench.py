@@ -38,9 +38,9 @@ def run(variant, shared):
 
 
 flops = float((2 * 2 * 40 * L.double() * 256).sum()) + B * 2 * 2 * 5 * 256 * 256      # two contractions + the two folds
-for name, v, sh in (("mfma two-read", 2, False), ("mfma two-read, shared q", 2, True), ("mfma resident", 4, False),
-                    ("mfma resident, shared q", 4, True), ("valu", 1, False), ("mfma two-read", 2, False),
-                    ("mfma two-read, shared q", 2, True)):
+for name, v, sh in (("mfma rows-once", 5, False), ("mfma rows-once, shared q", 5, True), ("mfma two-read", 3, False),
+                    ("mfma two-read, shared q", 3, True), ("mfma resident", 4, False), ("mfma resident, shared q", 4, True),
+                    ("valu", 1, False), ("mfma rows-once", 5, False), ("mfma rows-once, shared q", 5, True)):
     for _ in range(2):
         run(v, sh)
     torch.cuda.synchronize()
