@@ -584,6 +584,10 @@ def main():
     ap.add_argument("--pipeline_tail", type=float, default=None,
                     help="fraction of the queries in the tail chunk of the host/GPU pipeline (default: automatic = 1/16 from 32 "
                          "reference batches on, i.e. at this size; 0 = one chunk)")
+    ap.add_argument("--steps_in_flight", type=int, default=2,
+                    help="2 (default): the GPU half of step i + 1 is enqueued before the host half of step i (waiting for its kept "
+                         "rows, building its submission lists) runs -- cone_amd.inference.predict_split_async; every step is "
+                         "complete inside the timed bracket.  1: one step at a time (predict_split)")
     ap.add_argument("--elide_dead_work", action="store_true",
                     help="A/B: the headline step WITHOUT the saliency head and the intermediate decoder layer's heads "
                          "(CONE.forward computes them, cone/inference.py never reads them); the default headline computes "
@@ -659,9 +663,19 @@ def main():
         name, _, val = kv.partition("=")
         model.set_option(name, int(val or 1))
 
+    inflight, last = [], [None]
+
+    def finish_oldest():
+        h = inflight.pop(0)
+        out, dp = h.result()                # waits for the kept rows in pinned memory, builds the submission lists
+        last[0] = ([out], dp)
+
     def step():
-        # the product's own driver (cone_amd.inference.predict_split): stages A->C + the submission rows
-        out, dp = inf.predict_split(model, store, opt)
+        # the product's own driver (cone_amd.inference.predict_split_async / PendingSplit.result): stages A->C + the submission
+        # rows.  --steps_in_flight 2 (default): the GPU half of step i + 1 is enqueued before the host half of step i runs (the
+        # product's eval loop does the same across splits); 1: predict_split, one step at a time
+        h = inf.predict_split_async(model, store, opt)
+        dp = h.info
         if use_dist:    # the one exchange step: kept rows of every shard on every rank (all_gather over RCCL,
             # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors; every rank has
             # built the submission rows of ITS OWN shard (the host work shards with the queries)
@@ -673,9 +687,14 @@ def main():
             dist.all_gather_into_tensor(n_all, n.contiguous())
             dp["rows_all"] = rows_all.view((world,) + tuple(rows.shape))
             dp["n_all"] = n_all.view((world,) + tuple(n.shape))
-        return [out], dp
+        inflight.append(h)
+        while len(inflight) >= max(1, args.steps_in_flight):
+            finish_oldest()
+        return last[0]
 
     def fence():
+        while inflight:                     # every enqueued step is finished (lists built) inside the timed bracket
+            finish_oldest()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -692,6 +711,8 @@ def main():
             res = fn()
         fence()
         dt = time.perf_counter() - t0
+        if fn is step:
+            res = last[0]                   # (a step's own result is complete once it is no longer in flight: here, all of them)
         rec = collect_profile()
         lib.cone_prof_enable(0)
         timed_region.per_rank = [dt]
@@ -727,6 +748,7 @@ def main():
                                    f"{args.queries} queries x {args.videos} videos per GPU, window_len=90, d=256, "
                                    f"topk_window=20, NMS 0.5, {n_windows} windows per GPU per step",
                        "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture",
+                       "steps_in_flight": max(1, args.steps_in_flight),
                        "query_chunks": [list(c) for c in dp.get("chunks", [(0, args.queries)])],
                        "outputs": "per window pred_logits, pred_spans, matching scores -> rows [st, ed, proposal, "
                                   "matching]; per query fused / proposal / matching top-5 after NMS as JSON rows"
@@ -796,7 +818,10 @@ def main():
                 def one_chunk_outputs():            # per-window outputs of the whole split: one untimed unchunked step
                     tail0, opt.pipeline_tail = opt.pipeline_tail, 0.0
                     try:
-                        return step()[1].get("outputs") or {}
+                        step()
+                        while inflight:
+                            finish_oldest()
+                        return last[0][1].get("outputs") or {}
                     finally:
                         opt.pipeline_tail = tail0
                 ref_out = {k: v.clone() for k, v in one_chunk_outputs().items() if k in ("pred_logits", "pred_spans")}

@@ -817,61 +817,97 @@ def _graph_replay(model, store: FeatureStore, opt):
     return dict(hit[1])
 
 
-def predict_split(model, store: FeatureStore, opt):
-    """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info.
+class PendingSplit:
+    """A split whose device work is enqueued (``predict_split_async``).  ``info`` -- the run-info dict with the device-side
+    result tensors -- is valid at once (stream-ordered); ``result()`` waits for the kept rows in pinned host memory, builds
+    the submission lists and returns what ``predict_split`` returns.  A caller that evaluates split after split keeps one
+    in flight: the lists of split i are built while the GPU runs split i + 1."""
 
-    The queries run as a short software pipeline: all chunks are enqueued on the stream back to back (nothing in
-    device_pipeline synchronises when the window table is dense), their kept rows are copied to pinned host
-    memory behind an event each, and the host builds the submission rows of chunk i while the GPU is still
-    working on chunk i+1.  Results are identical to one big batch (rows of a GEMM are independent).
+    def __init__(self, info, finish):
+        self.info, self._finish, self._res = info, finish, None
 
-    ``--debug`` keeps the reference's meaning (cone/inference.py:93-94): the pre-filter runs over the whole split,
-    the window model stops after the first batch of ``eval_bsz`` queries, and only those queries are written."""
+    def result(self):
+        if self._finish is not None:
+            self._res, self._finish = self._finish(), None
+        return self._res
+
+
+def _to_pinned(t):
+    return torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
+
+
+def predict_split_async(model, store: FeatureStore, opt) -> PendingSplit:
+    """``predict_split`` in two halves: everything the GPU does is enqueued here (nothing waits for it), the host half --
+    waiting for the kept rows and building the submission lists -- runs in ``PendingSplit.result()``."""
     t0 = time.time()
     if getattr(opt, "debug", False) and len(store.ann) > opt.eval_bsz:
         win_idx = prefilter(model, store, opt)
         store = FeatureStore.subset(store, 0, opt.eval_bsz)
         dp = device_pipeline(model, store, opt, win_idx=win_idx[:opt.eval_bsz].contiguous())
-        torch.cuda.synchronize()
-        dp["model_seconds"] = time.time() - t0
         dp["ann"] = store.ann
-        return format_results(store.ann, opt, dp["rows"], dp["n"]), dp
-    chunks = query_chunks(len(store.ann), opt)
-    if len(chunks) == 1:
-        if getattr(opt, "hip_graph", False):
-            dp = _graph_replay(model, store, opt)       # the whole launch sequence as ONE hipGraph launch
+        pend = [(store, dp, None)]
+        chunks = [(0, len(store.ann))]
+        info = dp
+    else:
+        chunks = query_chunks(len(store.ann), opt)
+        if len(chunks) == 1:
+            if getattr(opt, "hip_graph", False):
+                dp = _graph_replay(model, store, opt)       # the whole launch sequence as ONE hipGraph launch
+            else:
+                dp = device_pipeline(model, store, opt)     # enqueued; nothing in it waits for the GPU
+            pend = [(store, dp, None)]
+            info = dp
         else:
-            dp = device_pipeline(model, store, opt)     # enqueued; nothing in it waits for the GPU
-        skel = result_skeletons(store.ann, opt)         # host work that needs no result: under the GPU's time
-        torch.cuda.synchronize()
-        dp["model_seconds"] = time.time() - t0
-        return format_results(store.ann, opt, dp["rows"], dp["n"], skel), dp
-    # clip-side work once for the split, shared by the chunks (they are views of one arena)
-    store.index_tensors()
-    win_idx = prefilter(model, store, opt)
-    video = project_video(model, store)
-    pend = []
-    for lo, hi in chunks:
-        sub = store.view(lo, hi)        # cached: the view's static index tables are uploaded once, not once per step
-        dp = device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi], video=video)
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
-                for t in (dp["rows"], dp["n"])]
-        ev = torch.cuda.Event()
+            # clip-side work once for the split, shared by the chunks (they are views of one arena)
+            store.index_tensors()
+            win_idx = prefilter(model, store, opt)
+            video = project_video(model, store)
+            pend = []
+            for lo, hi in chunks:
+                sub = store.view(lo, hi)    # cached: the view's static index tables are uploaded once, not once per step
+                pend.append((sub, device_pipeline(model, sub, opt, win_idx=win_idx[lo:hi], video=video), None))
+            info = None
+    # kept rows to pinned host memory behind an event per chunk (a graph replay's outputs are only valid until the next
+    # replay: the copy is stream-ordered ahead of it)
+    pend = [(sub, dp, ([_to_pinned(dp["rows"]), _to_pinned(dp["n"])], torch.cuda.Event())) for sub, dp, _ in pend]
+    for _, _, (_, ev) in pend:
         ev.record()
-        pend.append((sub, dp, host, ev))
-    # the split-level tensors of the info dict are enqueued right behind the last chunk, while the GPU is still busy with it
-    # (built after the last chunk's rows were waited for, their four small launches + allocations sat in the GPU-idle gap
-    # at the end of every step)
-    info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
-                n_windows=sum(p[1]["n_windows"] for p in pend), chunks=chunks, win_idx=win_idx,
-                windows={k: torch.cat([p[1]["windows"][k] for p in pend]) for k in ("vid_len", "txt_len")})
-    outs = ([], [], [])
-    for sub, dp, host, ev in pend:
-        ev.synchronize()
-        for dst, part in zip(outs, format_results(sub.ann, opt, host[0], host[1])):
-            dst.extend(part)
-    info["model_seconds"] = time.time() - t0
-    return outs, info
+    if info is None:
+        # the split-level tensors of the info dict are enqueued right behind the last chunk, while the GPU is still busy with
+        # it (built after the last chunk's rows were waited for, their four small launches + allocations sat in the GPU-idle
+        # gap at the end of every step)
+        info = dict(rows=torch.cat([p[1]["rows"] for p in pend], dim=1), n=torch.cat([p[1]["n"] for p in pend], dim=1),
+                    n_windows=sum(p[1]["n_windows"] for p in pend), chunks=chunks, win_idx=win_idx,
+                    windows={k: torch.cat([p[1]["windows"][k] for p in pend]) for k in ("vid_len", "txt_len")})
+
+    def finish():
+        outs = None
+        for sub, dp, (host, ev) in pend:
+            skel = result_skeletons(sub.ann, opt)           # host work that needs no result: under the GPU's time
+            ev.synchronize()
+            part = format_results(sub.ann, opt, host[0], host[1], skel)
+            if outs is None:
+                outs = part if len(pend) == 1 else tuple(list(x) for x in part)
+            else:
+                for dst, src in zip(outs, part):
+                    dst.extend(src)
+        info["model_seconds"] = time.time() - t0
+        return outs, info
+
+    return PendingSplit(info, finish)
+
+
+def predict_split(model, store: FeatureStore, opt):
+    """Stages A->C; returns the three submission lists (fused, proposal, matching) and run info.
+
+    The queries run as a short software pipeline: all chunks are enqueued on the stream back to back (nothing in
+    device_pipeline synchronises), their kept rows are copied to pinned host memory behind an event each, and the host
+    builds the submission rows of chunk i while the GPU is still working on chunk i+1.  Results are identical to one big
+    batch (rows of a GEMM are independent).  (``predict_split_async`` hands the host half back to the caller.)
+
+    ``--debug`` keeps the reference's meaning (cone/inference.py:93-94): the pre-filter runs over the whole split,
+    the window model stops after the first batch of ``eval_bsz`` queries, and only those queries are written."""
+    return predict_split_async(model, store, opt).result()
 
 
 EGO4D_VAL_GT = "data/ego4d_ori_data/nlq_val.json"      # hard-coded by the reference, cone/inference.py:420
