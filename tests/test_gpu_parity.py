@@ -1272,6 +1272,28 @@ def test_predict_split_pipeline_is_chunk_invariant():
     assert inf.query_chunks(100, tail) == [(0, 100)]
 
 
+def test_predict_split_async_keeps_splits_in_flight():
+    """predict_split_async enqueues a split's device work and hands the host half back: two splits (different stores, one of
+    them under hipGraph replay, whose outputs are overwritten by the next replay) in flight at once, finished out of order,
+    give the lists predict_split gives one at a time; ``info`` is valid before ``result()``."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 0)
+    opts = [make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=4, pipeline_chunks=3),
+            make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=4, hip_graph=True)]
+    stores = []
+    for i, o in enumerate(opts):
+        ann, vf, qf = synth.make_dataset(o, 19 + 6 * i, 3, seed=40 + i, ctx_range=(120, 420))
+        stores.append(inf.FeatureStore(o, ann, vf, qf))
+    ref = [inf.predict_split(model, st, o)[0] for st, o in zip(stores, opts)]
+    for _ in range(2):                                      # the second round replays the captured graph
+        pend = [inf.predict_split_async(model, st, o) for st, o in zip(stores, opts)]
+        again = inf.predict_split_async(model, stores[1], opts[1])      # a second replay before the first one's lists are built
+        assert all(int(h.info["n_windows"]) > 0 and h.info["rows"].is_cuda for h in pend)
+        got1, got_again, got0 = pend[1].result()[0], again.result()[0], pend[0].result()[0]
+        assert got0 == ref[0] and got1 == ref[1] and got_again == ref[1]
+        assert pend[0].result()[0] is got0                  # result() is idempotent
+
+
 def test_cli_start_inference_on_packed_store(tmp_path):
     """The reference's command line end to end: checkpoint + opt.json beside it (saved options win except the CLI
     whitelist, cone/config.py:184-196), annotations + features from the packed arena file, prediction files and
