@@ -798,6 +798,18 @@ def main():
         if v is not None:
             note(name, v)
 
+    # ---- the same K steps one at a time (predict_split: the host half of a step runs before the next step is enqueued)
+    if not args.no_extras and max(1, args.steps_in_flight) > 1:
+        def serial():
+            keep, args.steps_in_flight = args.steps_in_flight, 1
+            try:
+                sdt1, _, (_, sdp1) = timed_region(step)
+            finally:
+                args.steps_in_flight = keep
+            note("ms_per_step_one_at_a_time", round(sdt1 / args.steps * 1e3, 2))
+            note("value_one_at_a_time", round(world * sdp1["n_windows"] * args.steps / sdt1, 1))
+        guarded("one_at_a_time_error", serial)
+
     # ---- the eval pipeline's own default (cone_amd.inference): the outputs cone/inference.py never reads are not computed
     if full and not args.no_extras:
         def elided():
