@@ -572,8 +572,8 @@ def rccl_preflight(dist, world, rank, nq, max_after, backend, device="cuda"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--pipeline_chunks", type=int, default=None,
