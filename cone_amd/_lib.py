@@ -50,6 +50,7 @@ class Weights(C.Structure):
         ("dec_norm", LNorm), ("query_embed", C.c_void_p), ("class_embed", Linear),
         ("span_embed", Linear * 3), ("saliency_proj", Linear), ("adapter", Linear * 2),
         ("pos_dim_t", C.c_void_p),
+        ("txt_pos_embed", C.c_void_p), ("txt_pos_rows", C.c_int32), ("txt_pos_ln", LNorm),      # ABI 5: --use_txt_pos (NULL: off)
     ]
 
 
@@ -175,7 +176,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 4:
+    if lib.cone_abi_version() != 5:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -39,6 +39,7 @@ struct cone_model {
     const float* query_embed = nullptr;
     cone::Linear class_embed, span[3], saliency, adapter[2];
     const float* dim_t = nullptr;
+    const float* txt_pos_emb = nullptr; int txt_pos_rows = 0; cone::LNorm txt_pos_ln;     // --use_txt_pos (NULL: off)
     // derived: the cross-attention K / V projections of all decoder layers stacked along N
     cone::Linear dec_k, dec_v;
     // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
@@ -153,6 +154,16 @@ static int build_model(const cone_weights* w, cone_model** out) {
         lin(w->adapter[1], m->dv, d, m->adapter[1]);
     }
     ab.add(w->pos_dim_t, d, &m->dim_t);
+    if (w->txt_pos_embed) {     // --use_txt_pos
+        if (w->txt_pos_rows < 1 || w->txt_pos_rows > 4096 || !w->txt_pos_ln.g || !w->txt_pos_ln.b) {
+            delete m;
+            set_error("model_create: txt_pos_embed needs txt_pos_rows in [1, 4096] (got %d) and its LayerNorm", w->txt_pos_rows);
+            return CONE_E_INVALID;
+        }
+        m->txt_pos_rows = w->txt_pos_rows;
+        ab.add(w->txt_pos_embed, (size_t)w->txt_pos_rows * d, &m->txt_pos_emb);
+        ln(w->txt_pos_ln, d, m->txt_pos_ln);
+    }
     for (auto& it : ab.items)
         if (!it.src) {
             delete m;
@@ -369,6 +380,7 @@ struct FwdBuffers {
 struct FwdPlan { bool tables, fold; };
 static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
     FwdPlan p;
+    if (m->txt_pos_emb) l0 = nullptr;   // --use_txt_pos: the caches / tables assume a zero text position term (general path)
     p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && m->opt_l0_gather;
     p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax);
     if (!p.fold) p.tables = false;      // the unfolded decoder projects keys from memory + pos rows
@@ -409,6 +421,11 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int Lmax = Lv_max + Lq_max;
     CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
     CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
+    if (m->txt_pos_emb) {
+        l0 = nullptr;                   // see plan_of
+        CONE_REQUIRE(Lq_max <= m->txt_pos_rows, "forward: %d text tokens but txt_position_embed has %d rows (max_q_l)", Lq_max,
+                     m->txt_pos_rows);
+    }
     if (l0)
         CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
                      "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
@@ -437,7 +454,8 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                            l0->pos_qk, f.X, f.POS, gather0 ? nullptr : f.QKV, gather0 ? nullptr : f.QKV + (size_t)Mmax * 512,
                            B, Lmax, s));
     } else {
-        RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s));
+        RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s,
+                            m->txt_pos_emb, m->txt_pos_ln.g, m->txt_pos_ln.b));
     }
 
     bool qkv_fused = false;               // this layer's q | k | v rows were written by the previous layer's tail

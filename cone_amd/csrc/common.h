@@ -244,7 +244,8 @@ int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const fl
 int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s);
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                     const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
-                    int Lmax, hipStream_t s);
+                    int Lmax, hipStream_t s, const float* tpe = nullptr, const float* tpg = nullptr,
+                    const float* tpb = nullptr);        // tpe != null: --use_txt_pos (embedding rows + its LayerNorm)
 int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
 // X always; POS (sine rows) and QK / V (layer-0 q|k|v gathered from the caches) only when non-null
 int launch_row_index(const int* vrow0, const int* vlen, const int* trow0, const int* qlen, const int* off, int* ridx,

@@ -47,8 +47,15 @@ int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipSt
 // token matrix X at off[b], and write the matching position rows:
 //   video token p : PositionEmbeddingSine(normalize=True), cone/position_encoding.py:51-72:
 //                   x = (p+1) / (vlen + 1e-6) * 2pi ;  pos[c] = c even ? sin(x / dim_t[c]) : cos(x / dim_t[c])
-//   text token    : zeros (cone/model.py:106, use_txt_pos off).
+//   text token    : zeros (cone/model.py:106, use_txt_pos off); with --use_txt_pos (tpe != null) token t of the query gets
+//                   LayerNorm(x + position_embeddings[t]) -- TrainablePositionalEncoding applied to the projected text rows
+//                   (cone/position_encoding.py:18-32; eval: no dropout).
 // One wavefront per token, float4 per lane (d = 256).
+__device__ __forceinline__ float pack_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__ vproj,
                                                        const int* __restrict__ vrow0,
                                                        const int* __restrict__ vlen,
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__
                                                        const int* __restrict__ qlen,
                                                        const int* __restrict__ off,
                                                        const float* __restrict__ dim_t, float* X, float* POS,
-                                                       float* XP) {
+                                                       float* XP, const float* __restrict__ tpe,
+                                                       const float* __restrict__ tpg, const float* __restrict__ tpb) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -76,6 +84,16 @@ __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__
     } else {
         x = reinterpret_cast<const float4*>(tproj + (size_t)(trow0[b] + p - lv) * 256)[lane];
         ps = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tpe) {      // wave-uniform
+            const float4 e = reinterpret_cast<const float4*>(tpe + (size_t)(p - lv) * 256)[lane];
+            float4 v = make_float4(x.x + e.x, x.y + e.y, x.z + e.z, x.w + e.w);
+            const float mean = pack_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+            v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+            const float var = pack_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            const float4 g = reinterpret_cast<const float4*>(tpg)[lane], bb = reinterpret_cast<const float4*>(tpb)[lane];
+            ps = make_float4(v.x * rstd * g.x + bb.x, v.y * rstd * g.y + bb.y, v.z * rstd * g.z + bb.z, v.w * rstd * g.w + bb.w);
+        }
     }
     reinterpret_cast<float4*>(X + dst)[lane] = x;
     reinterpret_cast<float4*>(POS + dst)[lane] = ps;
@@ -85,10 +103,10 @@ __global__ __launch_bounds__(256) void pack_pos_kernel(const float* __restrict__
 
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                     const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
-                    int Lmax, hipStream_t s) {
+                    int Lmax, hipStream_t s, const float* tpe, const float* tpg, const float* tpb) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(pack_pos_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, vproj, vrow0, vlen, tproj,
-                       trow0, qlen, off, dim_t, X, POS, XP);
+                       trow0, qlen, off, dim_t, X, POS, XP, tpe, tpg, tpb);
     CONE_LAUNCH_CHECK();
     return 0;
 }

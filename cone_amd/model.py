@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from .synth import state_dict_spec
 
-_TXT_POS_PREFIX = "txt_position_embed."  # present in checkpoints, unused when use_txt_pos is off
+_TXT_POS_PREFIX = "txt_position_embed."  # present in checkpoints, read only with --use_txt_pos
 
 
 def _dim_t_table(d: int) -> torch.Tensor:
@@ -45,9 +45,10 @@ class CONE:
     """Drop-in for the inference surface of the reference ``CONE`` nn.Module."""
 
     def __init__(self, args):
-        if getattr(args, "use_txt_pos", False):
-            raise NotImplementedError("use_txt_pos is off in every shipped config (cone/config.py:115); "
-                                      "the HIP path implements the zero text position of cone/model.py:106")
+        # --use_txt_pos (cone/config.py:115; off in every shipped configuration): text tokens carry
+        # TrainablePositionalEncoding(src_txt) instead of a zero position term (cone/model.py:106); the library then runs the
+        # general path (x + pos materialised per token; no layer-0 caches / position tables)
+        self.use_txt_pos = bool(getattr(args, "use_txt_pos", False))
         if getattr(args, "span_loss_type", "l1") != "l1":
             raise NotImplementedError("only span_loss_type='l1' (cone/config.py:134)")
         if getattr(args, "pre_norm", False):
@@ -90,7 +91,7 @@ class CONE:
         sd = OrderedDict()
         for k, shape in spec.items():
             if k not in state_dict:
-                if k.startswith(_TXT_POS_PREFIX):
+                if k.startswith(_TXT_POS_PREFIX) and not self.use_txt_pos:
                     continue
                 raise KeyError(f"missing key in state_dict: {k}")
             v = state_dict[k]
@@ -145,6 +146,10 @@ class CONE:
         if w.has_adapter:
             lin(w.adapter[0], "adapter_layer.layers.0"); lin(w.adapter[1], "adapter_layer.layers.1")
         w.pos_dim_t = self._dim_t.data_ptr()
+        if self.use_txt_pos:
+            w.txt_pos_embed = p(_TXT_POS_PREFIX + "position_embeddings.weight")
+            w.txt_pos_rows = int(sd[_TXT_POS_PREFIX + "position_embeddings.weight"].shape[0])
+            ln(w.txt_pos_ln, _TXT_POS_PREFIX + "LayerNorm")
         if self._handle is not None:
             lib.cone_model_destroy(self._handle)
             self._handle = None

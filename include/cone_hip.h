@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 4
+#define CONE_HIP_ABI_VERSION 5
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -71,6 +71,13 @@ typedef struct {
     cone_linear_w saliency_proj;             /* [1][d]                          */
     cone_linear_w adapter[2];                /* adapter_layer.layers.{0,1}      */
     const float* pos_dim_t;                  /* [d] temperature**(2*(i//2)/d), cone/position_encoding.py:66-67 */
+    /* (ABI 5) --use_txt_pos (cone/config.py:115, cone/model.py:106): the position term of text token t of a query is
+     * TrainablePositionalEncoding(src_txt) = LayerNorm(src_txt[t] + position_embeddings[t]) (cone/position_encoding.py:10-32).
+     * txt_pos_embed = txt_position_embed.position_embeddings.weight [txt_pos_rows = max_q_l][d], txt_pos_ln its LayerNorm;
+     * NULL = the option is off (every shipped configuration): text tokens carry a zero position term.  With it set the forward
+     * runs on the general path (x + pos materialised per token; the layer-0 caches / position tables, which assume the
+     * zero term, are not used). */
+    const float* txt_pos_embed; int32_t txt_pos_rows; cone_ln_w txt_pos_ln;
 } cone_weights;
 
 const char* cone_last_error(void);

@@ -223,7 +223,14 @@ def cone_forward(sd, opt, src_txt, src_txt_mask, src_vid_motion, src_vid_motion_
     src = torch.cat([src_vid, src_txt_p], dim=1)
     mask = torch.cat([src_vid_motion_mask, src_txt_mask], dim=1).bool()
     pos_vid = sine_position(src_vid_motion_mask, opt.hidden_dim)
-    pos = torch.cat([pos_vid, torch.zeros_like(src_txt_p)], dim=1)
+    if getattr(opt, "use_txt_pos", False):
+        # cone/model.py:106 with --use_txt_pos: TrainablePositionalEncoding(src_txt) = LayerNorm(src_txt + position_embeddings[t])
+        # (cone/position_encoding.py:18-32; eval: the dropout is the identity)
+        emb = sd["txt_position_embed.position_embeddings.weight"][: src_txt_p.shape[1]]
+        pos_txt = layer_norm(src_txt_p + emb.unsqueeze(0), sd, "txt_position_embed.LayerNorm")
+    else:
+        pos_txt = torch.zeros_like(src_txt_p)
+    pos = torch.cat([pos_vid, pos_txt], dim=1)
     key_pad = ~mask
     x = src
     for i in range(opt.enc_layers):

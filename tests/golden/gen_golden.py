@@ -140,9 +140,9 @@ class StableSort:
 
 
 # ---- fixtures ------------------------------------------------------------------------------
-def gen_stage_b(name, preset, seed, lens_v, lens_q):
-    """CONE.forward + forward_clip_matching on one ragged padded batch."""
-    opt = ref_opt(preset)
+def gen_stage_b(name, preset, seed, lens_v, lens_q, **opt_kw):
+    """CONE.forward + forward_clip_matching on one ragged padded batch (opt_kw: reference options, e.g. use_txt_pos)."""
+    opt = ref_opt(preset, **opt_kw)
     model, cks = ref_model(opt, seed)
     inp = gi.stage_b_inputs(opt, 1000 + seed, lens_v, lens_q)
     vid, txt, vmask, tmask, cls = (inp[k] for k in ("src_vid", "src_txt", "vid_mask", "txt_mask", "src_cls_txt"))
@@ -158,6 +158,7 @@ def gen_stage_b(name, preset, seed, lens_v, lens_q):
     np.savez_compressed(
         os.path.join(HERE, name + ".npz"),
         preset=preset, weight_seed=seed, weight_checksum=cks, input_seed=1000 + seed,
+        **({"use_txt_pos": 1} if opt_kw.get("use_txt_pos") else {}),     # (key present only in the fixtures that set it)
         lens_v=np.array(lens_v), lens_q=np.array(lens_q),
         input_checksum=gi.checksum(vid, txt, cls),
         pred_logits=out["pred_logits"].numpy(), pred_spans=out["pred_spans"].numpy(),
@@ -498,8 +499,13 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "criterion":
         gen_criterion("criterion", 0)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "txtpos":
+        gen_stage_b("stageB_ego4d_txtpos", "ego4d", 3, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], use_txt_pos=True)
+        return
     gen_stage_b("stageB_ego4d", "ego4d", 0, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17])
     gen_stage_b("stageB_mad", "mad", 1, [125, 62, 3, 125], [25, 6, 11, 18])
+    # --use_txt_pos (cone/config.py:115): text tokens carry TrainablePositionalEncoding(src_txt) (cone/model.py:106)
+    gen_stage_b("stageB_ego4d_txtpos", "ego4d", 3, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], use_txt_pos=True)
     gen_stage_a("stageA_ego4d", "ego4d", 0, [901, 900, 44, 91])
     gen_stage_a("stageA_mad", "mad", 1, [1250, 187])
     gen_e2e("e2e_ego4d", "ego4d", 0, 12, 3, (300, 420))

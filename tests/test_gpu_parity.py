@@ -37,11 +37,11 @@ def _gpu():
 _MODELS = {}
 
 
-def get_model(preset, seed):
+def get_model(preset, seed, **opt_kw):
     from cone_amd.model import build_model
-    key = (preset, seed)
+    key = (preset, seed) + tuple(sorted(opt_kw.items()))
     if key not in _MODELS:
-        opt = make_opt(preset)
+        opt = make_opt(preset, **opt_kw)
         sd = synth.make_state_dict(opt, seed)
         m, _ = build_model(opt)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -306,13 +306,15 @@ def split_bf16(request):
 
 
 @pytest.mark.parametrize("split_bf16", [0, 1], indirect=True)
-@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad"])
+@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos"])
 def test_stage_b_matches_reference_golden(golden_dir, name, split_bf16):
     """split_bf16 = 1: the same reference fixtures at the same tolerance with every layer tail computed as six bf16
-    partial products per fp32 product (ffn_split.hip)."""
+    partial products per fp32 product (ffn_split.hip).  ``stageB_ego4d_txtpos``: the reference run with --use_txt_pos
+    (text tokens carry TrainablePositionalEncoding(src_txt), cone/model.py:106)."""
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     preset = str(fx["preset"])
-    model, opt, _ = get_model(preset, int(fx["weight_seed"]))
+    kw = {"use_txt_pos": True} if "use_txt_pos" in fx.files else {}
+    model, opt, _ = get_model(preset, int(fx["weight_seed"]), **kw)
     model.set_option("split_bf16", split_bf16)
     lens_v, lens_q = fx["lens_v"].tolist(), fx["lens_q"].tolist()
     inp = gi.stage_b_inputs(opt, int(fx["input_seed"]), lens_v, lens_q)
@@ -914,6 +916,37 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
         for i in range(len(pt)):
             for j in range(i + 1, len(pt)):
                 assert O.compute_temporal_iou(pt[i], pt[j]) <= opt.nms_thd
+
+
+def test_use_txt_pos_pipeline_matches_oracle():
+    """--use_txt_pos (cone/config.py:115): text tokens carry TrainablePositionalEncoding(src_txt) (cone/model.py:106).  The
+    library runs such a model on the general path (x + pos materialised per token, no layer-0 caches / position tables): the
+    reference fixture of that option (stageB_ego4d_txtpos, in test_stage_b_matches_reference_golden), and here the device
+    pipeline end to end against the oracle with the option on -- window rows within the logit tolerance, kept moments as in
+    the default configuration, results independent of chunking; and the option changes the outputs (it is not ignored)."""
+    from cone_amd import inference as inf
+    model, _, sd = get_model("ego4d", 3, use_txt_pos=True)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8, use_txt_pos=True)
+    ann, vf, qf = synth.make_dataset(opt, 24, 3, seed=13, ctx_range=(150, 420))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    (f1, p1, m1), info = inf.predict_split(model, store, opt)
+    opt2 = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8, use_txt_pos=True, window_batch=29,
+                    pipeline_chunks=2)
+    (f2, p2, m2), _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
+    assert f1 == f2 and p1 == p2 and m1 == m2
+    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    agree = 0
+    for a, b in zip(f1, fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
+            agree += 1
+    record_measured("txt_pos_pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, share=agree / len(f1))
+    assert agree >= PIPELINE_FLOOR * len(f1), agree
+    # the same weights with the option off give other moments: the position term is really applied
+    plain, _, _ = get_model("ego4d", 3)
+    opt0 = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=8)
+    (g1, _, _), _ = inf.predict_split(plain, inf.FeatureStore(opt0, ann, vf, qf), opt0)
+    assert g1 != f1
 
 
 def test_distributed_drivers_single_rank_equal_plain_pipeline():

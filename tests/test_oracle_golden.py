@@ -23,10 +23,10 @@ def _load_sd(opt, fx):
     return O.as_torch_sd(sd)
 
 
-@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad"])
+@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos"])
 def test_stage_b_matches_reference(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
-    opt = make_opt(str(fx["preset"]))
+    opt = make_opt(str(fx["preset"]), use_txt_pos="use_txt_pos" in fx.files)       # (--use_txt_pos: cone/model.py:106)
     sd = _load_sd(opt, fx)
     inp = gi.stage_b_inputs(opt, int(fx["input_seed"]), fx["lens_v"].tolist(), fx["lens_q"].tolist())
     assert gi.checksum(inp["src_vid"], inp["src_txt"], inp["src_cls_txt"]) == str(fx["input_checksum"])
@@ -46,7 +46,8 @@ def test_stage_b_matches_reference(golden_dir, name):
         assert err < TOL, (key, err)
     # the proposals really exercise hazard H3 (end beyond the window's valid length)
     start, end, _ = O.proposal_slices(out["pred_spans"], t(inp["vid_mask"]))
-    assert (end.numpy() > fx["lens_v"][:, None]).any()
+    if "use_txt_pos" not in fx.files:       # (a property of the two base fixtures' weights)
+        assert (end.numpy() > fx["lens_v"][:, None]).any()
 
 
 @pytest.mark.parametrize("name", ["stageA_ego4d", "stageA_mad"])
