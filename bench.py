@@ -270,6 +270,25 @@ def _timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps, out
 
 
+def _timed_in_flight(start, steps, warmup):
+    """The headline's stepping for an extra: `start()` enqueues a step and returns its PendingSplit; one step stays in flight
+    (its host half runs after the next step is enqueued); every step is finished inside the bracket."""
+    def run(n):
+        prev, out = None, None
+        for _ in range(n):
+            h = start()
+            if prev is not None:
+                out = prev.result()
+            prev = h
+        return prev.result() if prev is not None else out
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
 def bench_prefilter_mad(ctx_l=6_200_000, dv=512, W=125, topk=30, steps=5):
     """BASELINE configs[2]: MAD-scale long video (ctx_l x 512 fp32 = 12.7 GB resident in HBM, ~100 k windows of 125
     clips), window scores (frame scores with the window max fused into the stream: no (nq, ctx_l) matrix is written)
@@ -416,20 +435,20 @@ def bench_config2_ragged(model, opt, queries, videos, us_per_window_dense, steps
     ann, vf, qf = synth.make_dataset(opt, queries, videos, seed=11, ctx_range=(200, 1500))
     store = inf.FeatureStore(opt, ann, vf, qf)
     sel = inf.selection(store, opt)
-    dt, (lists, dp) = _timed(lambda: inf.predict_split(model, store, opt), steps, warmup)
+    dt, (lists, dp) = _timed_in_flight(lambda: inf.predict_split_async(model, store, opt), steps, warmup)     # the headline's stepping
     nw = dp["n_windows"]
     out = {"workload": f"BASELINE.json configs[1], ragged: {queries} queries x {videos} videos, ctx_l ~ U[200, 1500), "
                        f"window_len=90, d=256, topk_window=20, NMS 0.5: {nw} windows "
                        f"({int((sel.n_q < sel.K).sum())} queries own fewer than {sel.K})",
            "ms_per_step": round(dt * 1e3, 3), "n_windows": nw, "windows_per_s": round(nw / dt, 1),
            "queries_per_s": round(queries / dt, 1), "us_per_window": round(dt * 1e6 / nw, 4),
-           "us_per_window_dense_split": round(us_per_window_dense, 4),     # the dense split stepped the same way (one at a time)
+           "us_per_window_dense_split": round(us_per_window_dense, 4),     # the headline (both with one step in flight)
            "per_window_cost_vs_dense": round(dt * 1e6 / nw / us_per_window_dense, 4),
            "query_chunks": [list(c) for c in dp.get("chunks", [(0, queries)])]}
     saved = (opt.hip_graph if hasattr(opt, "hip_graph") else False, opt.pipeline_tail)
     try:
         opt.hip_graph, opt.pipeline_tail = True, 0.0
-        gdt, (glists, _) = _timed(lambda: inf.predict_split(model, store, opt), steps, 2)
+        gdt, (glists, _) = _timed_in_flight(lambda: inf.predict_split_async(model, store, opt), steps, 2)
         out["sync_free"] = {"hip_graph_ms_per_step": round(gdt * 1e3, 3), "same_rows_as_eager": glists == lists}
     except Exception as e:      # noqa: BLE001
         out["sync_free"] = {"error": repr(e)[:300]}
@@ -886,7 +905,7 @@ def main():
     if world == 1 and not args.no_extras:
         guarded("shard_proxy_8", lambda: bench_shard_proxy(model, store, opt, serial_ms[0]))
         guarded("config2_ragged", lambda: bench_config2_ragged(model, opt, args.queries, args.videos,
-                                                               serial_ms[0] * 1e3 / n_windows))
+                                                               dt / args.steps * 1e6 / n_windows, steps=args.steps))
         del store, dp, out
         model._ws.buf = None
         torch.cuda.empty_cache()
