@@ -607,6 +607,8 @@ def main():
                     help="2 (default): the GPU half of step i + 1 is enqueued before the host half of step i (waiting for its kept "
                          "rows, building its submission lists) runs -- cone_amd.inference.predict_split_async; every step is "
                          "complete inside the timed bracket.  1: one step at a time (predict_split)")
+    ap.add_argument("--extras_timeout", type=float, default=420.0,
+                    help="N > 1: seconds the extras behind the headline may take before rank 0 prints the line as it stands")
     ap.add_argument("--elide_dead_work", action="store_true",
                     help="A/B: the headline step WITHOUT the saliency head and the intermediate decoder layer's heads "
                          "(CONE.forward computes them, cone/inference.py never reads them); the default headline computes "
@@ -804,6 +806,30 @@ def main():
         if res is not None:
             res[name] = value
 
+    # N > 1: the extras below contain collectives.  Should one of them ever stall (a rank that failed inside an extra while
+    # the others wait for it), the headline -- measured and complete above -- must still come out: a watchdog on every rank
+    # prints rank 0's line as it stands after --extras_timeout seconds and ends the process.
+    import threading
+    extras_done, emit_lock, emitted = threading.Event(), threading.Lock(), [False]
+
+    def emit(extra=None):
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                line = dict(res)
+                if extra:
+                    line.update(extra)
+                print(json.dumps(line), flush=True)
+
+    def watchdog():
+        if not extras_done.wait(args.extras_timeout):
+            emit({"extras_timed_out_after_s": args.extras_timeout})
+            os._exit(0)
+    if use_dist and world > 1 and not args.no_extras:
+        threading.Thread(target=watchdog, daemon=True).start()
+
     def guarded(name, fn):
         """Run one extra; a failure becomes {"error": ...} under its name instead of taking the line down."""
         try:
@@ -928,8 +954,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
         guarded("cpu_baseline", lambda: cpu_baseline(opt, sd, args.cpu_queries,
                                                      max(1, args.cpu_queries * args.videos // args.queries)))
-    if rank == 0:
-        print(json.dumps(res))
+    extras_done.set()
+    emit()
     if use_dist:
         dist.destroy_process_group()
 
