@@ -37,8 +37,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# dmabuf IPC: RCCL / device-memory sharing across the ranks' processes needs it on this driver (also when the ranks are
+# started by torch.distributed.run directly rather than by self_launch below); harmless for one process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
