@@ -51,6 +51,7 @@ class Weights(C.Structure):
         ("span_embed", Linear * 3), ("saliency_proj", Linear), ("adapter", Linear * 2),
         ("pos_dim_t", C.c_void_p),
         ("txt_pos_embed", C.c_void_p), ("txt_pos_rows", C.c_int32), ("txt_pos_ln", LNorm),      # ABI 5: --use_txt_pos (NULL: off)
+        ("pre_norm", C.c_int32), ("enc_norm", LNorm),                                            # ABI 5: --pre_norm (0: post-norm)
     ]
 
 

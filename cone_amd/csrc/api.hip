@@ -40,6 +40,7 @@ struct cone_model {
     cone::Linear class_embed, span[3], saliency, adapter[2];
     const float* dim_t = nullptr;
     const float* txt_pos_emb = nullptr; int txt_pos_rows = 0; cone::LNorm txt_pos_ln;     // --use_txt_pos (NULL: off)
+    int pre_norm = 0; cone::LNorm enc_norm;   // --pre_norm: normalize_before + the encoder's final LayerNorm
     // derived: the cross-attention K / V projections of all decoder layers stacked along N
     cone::Linear dec_k, dec_v;
     // derived: W_v^T of each decoder layer's cross-attention (256x256, [c][o]) for the fused cross-attention
@@ -163,6 +164,10 @@ static int build_model(const cone_weights* w, cone_model** out) {
         m->txt_pos_rows = w->txt_pos_rows;
         ab.add(w->txt_pos_embed, (size_t)w->txt_pos_rows * d, &m->txt_pos_emb);
         ln(w->txt_pos_ln, d, m->txt_pos_ln);
+    }
+    if (w->pre_norm) {          // --pre_norm
+        m->pre_norm = 1;
+        ln(w->enc_norm, d, m->enc_norm);
     }
     for (auto& it : ab.items)
         if (!it.src) {
@@ -380,9 +385,10 @@ struct FwdBuffers {
 struct FwdPlan { bool tables, fold; };
 static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
     FwdPlan p;
-    if (m->txt_pos_emb) l0 = nullptr;   // --use_txt_pos: the caches / tables assume a zero text position term (general path)
+    if (m->txt_pos_emb || m->pre_norm) l0 = nullptr;    // --use_txt_pos / --pre_norm: the general path (the caches / tables assume
+                                                        // a zero text position term and the post-norm layer order)
     p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && m->opt_l0_gather;
-    p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax);
+    p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax) && !m->pre_norm;
     if (!p.fold) p.tables = false;      // the unfolded decoder projects keys from memory + pos rows
     return p;
 }
@@ -413,6 +419,97 @@ static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax, const FwdPlan& 
     return c.cur;
 }
 
+// --pre_norm (cone/config.py:120 -> normalize_before, cone/transformer.py:19-36): every layer normalises its INPUT
+// (forward_pre, :248-260 / :319-342), the residual stream stays un-normalised, and the encoder ends with its own LayerNorm.
+// Off in every shipped configuration: built from the plain blocks (LayerNorm kernel, row GEMMs with residual epilogue, the
+// packed encoder attention, the small decoder attentions) -- no fused tails, no caches.
+static int forward_packed_prenorm(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
+                                  const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
+                                  float* logits, float* spans, float* saliency, const cone_taps* taps, FwdBuffers& f,
+                                  hipStream_t s) {
+    const int Lmax = Lv_max + Lq_max, Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
+    const int* Mdev = f.off + B;
+    RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
+    RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s,
+                        m->txt_pos_emb, m->txt_pos_ln.g, m->txt_pos_ln.b));
+    GemmArgs g;
+    for (int l = 0; l < m->n_enc; ++l) {
+        const EncLayer& e = m->enc[l];
+        RUN(launch_layernorm(f.X, 256, e.n1.g, e.n1.b, f.X1, 256, Mmax, Mdev, 256, s));                 // src2 = norm1(src)
+        float* QK = f.QKV; float* V = f.QKV + (size_t)Mmax * 512;
+        g = G(m, f.X1, 256, e.sa.in_w, 256, e.sa.in_b, QK, 512, Mmax, Mdev, 512, 256);                  // q | k = (src2 + pos) W^T
+        g.A2 = f.POS; g.lda2 = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_gemm(G(m, f.X1, 256, e.sa.in_w + 512 * 256, 256, e.sa.in_b + 512, V, 256, Mmax, Mdev, 256, 256), s));
+        AttnSrc src{};
+        src.Q = QK; src.K = QK + 256; src.V = V; src.ldq = src.ldk = 512; src.ldv = 256;
+        RUN(launch_enc_attn(ATTN_PACKED, src, f.ATT, f.off, B, Lmax, s));
+        g = G(m, f.ATT, 256, e.sa.out.w, 256, e.sa.out.b, f.X, 256, Mmax, Mdev, 256, 256, EPI_RESIDUAL);
+        g.R = f.X; g.ldr = 256;                                                                        // src += attn Wo^T + bo
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.X, 256, e.n2.g, e.n2.b, f.X1, 256, Mmax, Mdev, 256, s));                 // src2 = norm2(src)
+        RUN(launch_gemm(G(m, f.X1, 256, e.l1.w, 256, e.l1.b, f.H, ff, Mmax, Mdev, ff, 256, EPI_RELU), s));
+        g = G(m, f.H, ff, e.l2.w, ff, e.l2.b, f.X, 256, Mmax, Mdev, 256, ff, EPI_RESIDUAL);
+        g.R = f.X; g.ldr = 256;                                                                        // src += ffn(src2)
+        RUN(launch_gemm(g, s));
+    }
+    RUN(launch_layernorm(f.X, 256, m->enc_norm.g, m->enc_norm.b, f.X1, 256, Mmax, Mdev, 256, s));       // memory = encoder.norm(src)
+    const float* MEM = f.X1;
+    // decoder keys / values of all layers: k = (memory + pos) W_k^T, v = memory W_v^T (cone/transformer.py:333-336)
+    g = G(m, MEM, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
+    g.A2 = f.POS; g.lda2 = 256;
+    RUN(launch_gemm(g, s));
+    RUN(launch_gemm(G(m, MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
+    CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));                       // tgt = 0 (:66)
+    for (int l = 0; l < nd; ++l) {
+        const DecLayer& dl = m->dec[l];
+        RUN(launch_layernorm(f.TGT, 256, dl.n1.g, dl.n1.b, f.TGT1, 256, T, nullptr, 256, s));           // tgt2 = norm1(tgt)
+        g = G(m, f.TGT1, 256, dl.sa.in_w, 256, nullptr, f.DQK, 768, T, nullptr, 768, 256, EPI_RESIDUAL); // q | k | v, slot term from the table
+        g.R = m->dec_sa_tab[l]; g.ldr = 768; g.r_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_small_attn(f.DQK, 768, f.DQK + 256, 768, f.DQK + 512, 768, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
+        g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+        g.R = f.TGT; g.ldr = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.TGT, 256, dl.n2.g, dl.n2.b, f.TGT1, 256, T, nullptr, 256, s));           // tgt2 = norm2(tgt)
+        g = G(m, f.TGT1, 256, dl.ca.in_w, 256, nullptr, f.DQ, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+        g.R = m->dec_ca_tab[l]; g.ldr = 256; g.r_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B, m->nq,
+                              Lmax, s));
+        g = G(m, f.DATT, 256, dl.ca.out.w, 256, dl.ca.out.b, f.TGT, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+        g.R = f.TGT; g.ldr = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.TGT, 256, dl.n3.g, dl.n3.b, f.TGT1, 256, T, nullptr, 256, s));           // tgt2 = norm3(tgt)
+        RUN(launch_gemm(G(m, f.TGT1, 256, dl.l1.w, 256, dl.l1.b, f.DH, ff, T, nullptr, ff, 256, EPI_RELU), s));
+        g = G(m, f.DH, ff, dl.l2.w, ff, dl.l2.b, f.TGT, 256, T, nullptr, 256, ff, EPI_RESIDUAL);
+        g.R = f.TGT; g.ldr = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr, 256, s));
+    }
+    // heads (cone/model.py:112-117), all layers into the workspace, the last layer's rows out
+    const int HT = nd * T;
+    RUN(launch_rowdot(f.HS, 256, m->class_embed.w, m->class_embed.b, f.LG, 2, HT, 2, 0, s));
+    RUN(launch_gemm(G(m, f.HS, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP, 2, HT, 2, 1, s));
+    const size_t last = (size_t)(nd - 1) * T * 2;
+    CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (taps) {
+        if (taps->hs)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)nd * T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_logits && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_logits, f.LG, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_spans && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_spans, f.SP, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (saliency || (taps && taps->memory))
+        RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
+                            taps ? taps->memory : nullptr, Lq_max, B, s));
+    return 0;
+}
+
 static int forward_packed(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
                           const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
                           float* logits, float* spans, float* saliency, const cone_taps* taps, void* ws,
@@ -421,6 +518,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int Lmax = Lv_max + Lq_max;
     CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
     CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
+    if (m->pre_norm) l0 = nullptr;      // see plan_of
     if (m->txt_pos_emb) {
         l0 = nullptr;                   // see plan_of
         CONE_REQUIRE(Lq_max <= m->txt_pos_rows, "forward: %d text tokens but txt_position_embed has %d rows (max_q_l)", Lq_max,
@@ -434,6 +532,9 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     FwdBuffers f;
     carve_fwd(m, c, B, Lmax, plan, f);
     if (!c.ok) { set_error("forward: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    if (m->pre_norm)
+        return forward_packed_prenorm(m, vproj, vrow0, vlen, tproj, trow0, qlen, B, Lv_max, Lq_max, logits, spans, saliency, taps,
+                                      f, s);
     const int Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
     const int* Mdev = f.off + B;
     const size_t pos_rows_n = l0 ? (size_t)cone_pos_table_rows(l0->max_v_l) : 0;

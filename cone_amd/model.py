@@ -51,8 +51,8 @@ class CONE:
         self.use_txt_pos = bool(getattr(args, "use_txt_pos", False))
         if getattr(args, "span_loss_type", "l1") != "l1":
             raise NotImplementedError("only span_loss_type='l1' (cone/config.py:134)")
-        if getattr(args, "pre_norm", False):
-            raise NotImplementedError("only the post-norm transformer (pre_norm=False) is implemented")
+        # --pre_norm (cone/config.py:120): normalize_before in every layer + the encoder's final norm; general path as well
+        self.pre_norm = bool(getattr(args, "pre_norm", False))
         if getattr(args, "v_motion_feat_dim", None) != getattr(args, "v_appear_feat_dim", None):
             raise NotImplementedError("motion and appearance features share one source in every shipped script")
         self.args = args
@@ -146,6 +146,9 @@ class CONE:
         if w.has_adapter:
             lin(w.adapter[0], "adapter_layer.layers.0"); lin(w.adapter[1], "adapter_layer.layers.1")
         w.pos_dim_t = self._dim_t.data_ptr()
+        if self.pre_norm:
+            w.pre_norm = 1
+            ln(w.enc_norm, "transformer.encoder.norm")
         if self.use_txt_pos:
             w.txt_pos_embed = p(_TXT_POS_PREFIX + "position_embeddings.weight")
             w.txt_pos_rows = int(sd[_TXT_POS_PREFIX + "position_embeddings.weight"].shape[0])

@@ -64,6 +64,8 @@ def state_dict_spec(opt) -> "OrderedDict[str, tuple]":
         dv = opt.v_appear_feat_dim
         spec["adapter_layer.layers.0.weight"] = (d, dv); spec["adapter_layer.layers.0.bias"] = (d,)
         spec["adapter_layer.layers.1.weight"] = (dv, d); spec["adapter_layer.layers.1.bias"] = (dv,)
+    if getattr(opt, "pre_norm", False):     # the encoder's final LayerNorm exists only then (cone/transformer.py:32)
+        ln("transformer.encoder.norm")
     return spec
 
 

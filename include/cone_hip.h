@@ -78,6 +78,11 @@ typedef struct {
      * runs on the general path (x + pos materialised per token; the layer-0 caches / position tables, which assume the
      * zero term, are not used). */
     const float* txt_pos_embed; int32_t txt_pos_rows; cone_ln_w txt_pos_ln;
+    /* (ABI 5) --pre_norm (cone/config.py:120 -> normalize_before, cone/transformer.py:19-36): pre_norm != 0 = every layer
+     * normalises its input (forward_pre) and the encoder ends with enc_norm = transformer.encoder.norm, which exists only
+     * then.  0 (every shipped configuration) = post-norm.  Such a model runs on the general path (plain LayerNorm / GEMM /
+     * attention launches: no fused layer tails, no layer-0 caches). */
+    int32_t pre_norm; cone_ln_w enc_norm;
 } cone_weights;
 
 const char* cone_last_error(void);

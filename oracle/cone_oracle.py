@@ -193,8 +193,15 @@ def mha(sd, prefix, q_in, k_in, v_in, nheads, key_pad=None):
     return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def encoder_layer(sd, p, x, pos, key_pad, nheads):
-    """A9: cone/transformer.py:233-246 (post-norm)."""
+def encoder_layer(sd, p, x, pos, key_pad, nheads, pre_norm=False):
+    """A9: cone/transformer.py:233-246 (post-norm); :248-260 (forward_pre, --pre_norm)."""
+    if pre_norm:
+        x2 = layer_norm(x, sd, p + ".norm1")
+        qk = x2 + pos
+        x = x + mha(sd, p + ".self_attn", qk, qk, x2, nheads, key_pad)
+        x2 = layer_norm(x, sd, p + ".norm2")
+        return x + F.linear(F.relu(F.linear(x2, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                            sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     qk = x + pos
     x = layer_norm(x + mha(sd, p + ".self_attn", qk, qk, x, nheads, key_pad), sd, p + ".norm1")
     h = F.linear(F.relu(F.linear(x, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
@@ -202,8 +209,17 @@ def encoder_layer(sd, p, x, pos, key_pad, nheads):
     return layer_norm(x + h, sd, p + ".norm2")
 
 
-def decoder_layer(sd, p, tgt, memory, pos, query_pos, key_pad, nheads):
-    """A10: cone/transformer.py:296-317 (post-norm)."""
+def decoder_layer(sd, p, tgt, memory, pos, query_pos, key_pad, nheads, pre_norm=False):
+    """A10: cone/transformer.py:296-317 (post-norm); :319-342 (forward_pre, --pre_norm)."""
+    if pre_norm:
+        t2 = layer_norm(tgt, sd, p + ".norm1")
+        qk = t2 + query_pos
+        tgt = tgt + mha(sd, p + ".self_attn", qk, qk, t2, nheads)
+        t2 = layer_norm(tgt, sd, p + ".norm2")
+        tgt = tgt + mha(sd, p + ".multihead_attn", t2 + query_pos, memory + pos, memory, nheads, key_pad)
+        t2 = layer_norm(tgt, sd, p + ".norm3")
+        return tgt + F.linear(F.relu(F.linear(t2, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                              sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     qk = tgt + query_pos
     tgt = layer_norm(tgt + mha(sd, p + ".self_attn", qk, qk, tgt, nheads), sd, p + ".norm1")
     tgt = layer_norm(tgt + mha(sd, p + ".multihead_attn", tgt + query_pos, memory + pos, memory,
@@ -233,16 +249,17 @@ def cone_forward(sd, opt, src_txt, src_txt_mask, src_vid_motion, src_vid_motion_
     pos = torch.cat([pos_vid, pos_txt], dim=1)
     key_pad = ~mask
     x = src
+    pre = bool(getattr(opt, "pre_norm", False))        # --pre_norm: normalize_before (cone/transformer.py:19-36)
     for i in range(opt.enc_layers):
-        x = encoder_layer(sd, f"transformer.encoder.layers.{i}", x, pos, key_pad, H)
-    memory = x
+        x = encoder_layer(sd, f"transformer.encoder.layers.{i}", x, pos, key_pad, H, pre)
+    memory = layer_norm(x, sd, "transformer.encoder.norm") if pre else x      # encoder_norm only when normalize_before (:32)
     B = src.shape[0]
     query_pos = sd["query_embed.weight"][None].expand(B, -1, -1)
     tgt = torch.zeros_like(query_pos)
     hs = []
     for i in range(opt.dec_layers):
         tgt = decoder_layer(sd, f"transformer.decoder.layers.{i}", tgt, memory, pos, query_pos,
-                            key_pad, H)
+                            key_pad, H, pre)
         hs.append(layer_norm(tgt, sd, "transformer.decoder.norm"))
     hs = torch.stack(hs)  # (layers, B, Nq, d)
     logits = F.linear(hs, sd["class_embed.weight"], sd["class_embed.bias"])

@@ -159,6 +159,7 @@ def gen_stage_b(name, preset, seed, lens_v, lens_q, **opt_kw):
         os.path.join(HERE, name + ".npz"),
         preset=preset, weight_seed=seed, weight_checksum=cks, input_seed=1000 + seed,
         **({"use_txt_pos": 1} if opt_kw.get("use_txt_pos") else {}),     # (key present only in the fixtures that set it)
+        **({"pre_norm": 1} if opt_kw.get("pre_norm") else {}),
         lens_v=np.array(lens_v), lens_q=np.array(lens_q),
         input_checksum=gi.checksum(vid, txt, cls),
         pred_logits=out["pred_logits"].numpy(), pred_spans=out["pred_spans"].numpy(),
@@ -499,6 +500,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "criterion":
         gen_criterion("criterion", 0)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "prenorm":
+        gen_stage_b("stageB_ego4d_prenorm", "ego4d", 4, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], pre_norm=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "txtpos":
         gen_stage_b("stageB_ego4d_txtpos", "ego4d", 3, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], use_txt_pos=True)
         return
@@ -506,6 +510,8 @@ def main():
     gen_stage_b("stageB_mad", "mad", 1, [125, 62, 3, 125], [25, 6, 11, 18])
     # --use_txt_pos (cone/config.py:115): text tokens carry TrainablePositionalEncoding(src_txt) (cone/model.py:106)
     gen_stage_b("stageB_ego4d_txtpos", "ego4d", 3, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], use_txt_pos=True)
+    # --pre_norm (cone/config.py): normalize_before in every transformer layer + the encoder's final norm (cone/transformer.py:19-36)
+    gen_stage_b("stageB_ego4d_prenorm", "ego4d", 4, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], pre_norm=True)
     gen_stage_a("stageA_ego4d", "ego4d", 0, [901, 900, 44, 91])
     gen_stage_a("stageA_mad", "mad", 1, [1250, 187])
     gen_e2e("e2e_ego4d", "ego4d", 0, 12, 3, (300, 420))

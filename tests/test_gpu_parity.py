@@ -306,14 +306,14 @@ def split_bf16(request):
 
 
 @pytest.mark.parametrize("split_bf16", [0, 1], indirect=True)
-@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos"])
+@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos", "stageB_ego4d_prenorm"])
 def test_stage_b_matches_reference_golden(golden_dir, name, split_bf16):
     """split_bf16 = 1: the same reference fixtures at the same tolerance with every layer tail computed as six bf16
     partial products per fp32 product (ffn_split.hip).  ``stageB_ego4d_txtpos``: the reference run with --use_txt_pos
     (text tokens carry TrainablePositionalEncoding(src_txt), cone/model.py:106)."""
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     preset = str(fx["preset"])
-    kw = {"use_txt_pos": True} if "use_txt_pos" in fx.files else {}
+    kw = {k: True for k in ("use_txt_pos", "pre_norm") if k in fx.files}       # ``stageB_ego4d_prenorm``: --pre_norm (normalize_before)
     model, opt, _ = get_model(preset, int(fx["weight_seed"]), **kw)
     model.set_option("split_bf16", split_bf16)
     lens_v, lens_q = fx["lens_v"].tolist(), fx["lens_q"].tolist()
@@ -916,6 +916,29 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
         for i in range(len(pt)):
             for j in range(i + 1, len(pt)):
                 assert O.compute_temporal_iou(pt[i], pt[j]) <= opt.nms_thd
+
+
+def test_pre_norm_pipeline_matches_oracle():
+    """--pre_norm (cone/config.py:120): every transformer layer normalises its input and the encoder ends with its own
+    LayerNorm (cone/transformer.py:19-36, 248-260, 319-342).  The reference fixture of that option is in
+    test_stage_b_matches_reference_golden; here the device pipeline end to end against the oracle, chunk-invariant."""
+    from cone_amd import inference as inf
+    model, _, sd = get_model("ego4d", 4, pre_norm=True)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=8, pre_norm=True)
+    ann, vf, qf = synth.make_dataset(opt, 21, 3, seed=17, ctx_range=(130, 400))
+    (f1, p1, m1), info = inf.predict_split(model, inf.FeatureStore(opt, ann, vf, qf), opt)
+    opt2 = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=8, pre_norm=True, window_batch=23,
+                    pipeline_chunks=2)
+    (f2, p2, m2), _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
+    assert f1 == f2 and p1 == p2 and m1 == m2
+    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    agree = 0
+    for a, b in zip(f1, fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
+            agree += 1
+    record_measured("pre_norm_pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, share=agree / len(f1))
+    assert agree >= PIPELINE_FLOOR * len(f1), agree
 
 
 def test_use_txt_pos_pipeline_matches_oracle():

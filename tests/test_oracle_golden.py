@@ -23,10 +23,11 @@ def _load_sd(opt, fx):
     return O.as_torch_sd(sd)
 
 
-@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos"])
+@pytest.mark.parametrize("name", ["stageB_ego4d", "stageB_mad", "stageB_ego4d_txtpos", "stageB_ego4d_prenorm"])
 def test_stage_b_matches_reference(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
-    opt = make_opt(str(fx["preset"]), use_txt_pos="use_txt_pos" in fx.files)       # (--use_txt_pos: cone/model.py:106)
+    # (--use_txt_pos: cone/model.py:106; --pre_norm: cone/transformer.py:19-36 -- the fixture says which option it was made with)
+    opt = make_opt(str(fx["preset"]), use_txt_pos="use_txt_pos" in fx.files, pre_norm="pre_norm" in fx.files)
     sd = _load_sd(opt, fx)
     inp = gi.stage_b_inputs(opt, int(fx["input_seed"]), fx["lens_v"].tolist(), fx["lens_q"].tolist())
     assert gi.checksum(inp["src_vid"], inp["src_txt"], inp["src_cls_txt"]) == str(fx["input_checksum"])
@@ -46,7 +47,7 @@ def test_stage_b_matches_reference(golden_dir, name):
         assert err < TOL, (key, err)
     # the proposals really exercise hazard H3 (end beyond the window's valid length)
     start, end, _ = O.proposal_slices(out["pred_spans"], t(inp["vid_mask"]))
-    if "use_txt_pos" not in fx.files:       # (a property of the two base fixtures' weights)
+    if "use_txt_pos" not in fx.files and "pre_norm" not in fx.files:       # (a property of the two base fixtures' weights)
         assert (end.numpy() > fx["lens_v"][:, None]).any()
 
 
