@@ -96,12 +96,12 @@ static int build_model(const cone_weights* w, cone_model** out) {
     CONE_REQUIRE(w->hidden_dim == 256 && w->nheads == 8,
                  "model_create: unsupported model shape hidden_dim=%d nheads=%d -- the attention / layer-tail kernels of this "
                  "build are instantiated for hidden_dim 256 with 8 heads (head_dim 32: every shipped CONE configuration, "
-                 "cone/config.py:101-104); also required: dim_feedforward a multiple of 128, num_queries <= 8, feature dims "
+                 "cone/config.py:101-104); also required: dim_feedforward a multiple of 128, num_queries <= 16, feature dims "
                  "multiples of 32 up to 1024, at most 192 tokens (clips + words) per window", w->hidden_dim, w->nheads);
     CONE_REQUIRE(w->dim_ff % 128 == 0 && w->dim_ff >= 128, "model_create: dim_feedforward=%d must be a multiple of 128", w->dim_ff);
     CONE_REQUIRE(w->enc_layers >= 1 && w->enc_layers <= CONE_MAX_LAYERS && w->dec_layers >= 1 &&
                      w->dec_layers <= CONE_MAX_LAYERS, "model_create: layer counts out of range");
-    CONE_REQUIRE(w->num_queries >= 1 && w->num_queries <= 8, "model_create: num_queries=%d not in [1,8]", w->num_queries);
+    CONE_REQUIRE(w->num_queries >= 1 && w->num_queries <= 16, "model_create: num_queries=%d not in [1,16]", w->num_queries);
     CONE_REQUIRE(w->n_input_proj >= 1 && w->n_input_proj <= CONE_MAX_PROJ, "model_create: n_input_proj out of range");
     CONE_REQUIRE(w->t_dim % 32 == 0 && w->v_dim % 32 == 0 && w->t_dim <= 1024 && w->v_dim <= 1024,
                  "model_create: feature dims must be multiples of 32 and <= 1024 (t=%d v=%d)", w->t_dim, w->v_dim);

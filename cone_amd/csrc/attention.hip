@@ -407,33 +407,34 @@ int launch_enc_attn(int mode, const AttnSrc& a, float* OUT, const int* off, int 
     return CONE_E_INVALID;
 }
 
-// Decoder attentions: NQ (<= 8) query slots per window, one wavefront per (window, head).
+// Decoder attentions: NQ (<= MQ = 8 or 16) query slots per window, one wavefront per (window, head).
 // off == nullptr : keys are the window's own NQ slot rows (self-attention, no mask);
 // off != nullptr : keys are memory tokens off[b] .. off[b+1] (cross-attention, <= 192 keys).
 constexpr int kSmallMaxKeys = 192;
+template <int MQ>
 __global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict__ Q, int ldq,
                                                         const float* __restrict__ K, int ldk,
                                                         const float* __restrict__ V, int ldv,
                                                         float* __restrict__ OUT, int ldo,
                                                         const int* __restrict__ off, int nq) {
-    __shared__ float qs[8][32];
-    __shared__ float ps[8][kSmallMaxKeys];
+    __shared__ float qs[MQ][32];
+    __shared__ float ps[MQ][kSmallMaxKeys];
     const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     const int k0 = off ? off[b] : b * nq;
     const int L = off ? off[b + 1] - k0 : nq;
-    if (lane < nq * 8) {
-        const int qi = lane >> 3, c = lane & 7;
+    for (int i = lane; i < nq * 8; i += 64) {
+        const int qi = i >> 3, c = i & 7;
         const float4 x = *reinterpret_cast<const float4*>(Q + (size_t)(b * nq + qi) * ldq + head * 32 + c * 4);
         qs[qi][c * 4] = x.x * kQScale; qs[qi][c * 4 + 1] = x.y * kQScale;
         qs[qi][c * 4 + 2] = x.z * kQScale; qs[qi][c * 4 + 3] = x.w * kQScale;
     }
     __syncthreads();
-    float sc[3][8];
+    float sc[3][MQ];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
         const int j = lane + 64 * jj;
 #pragma unroll
-        for (int qi = 0; qi < 8; ++qi) sc[jj][qi] = -INFINITY;
+        for (int qi = 0; qi < MQ; ++qi) sc[jj][qi] = -INFINITY;
         if (j < L) {
             float kv[32];
             const float* kp = K + (size_t)(k0 + j) * ldk + head * 32;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict_
                 kv[4 * u] = x.x; kv[4 * u + 1] = x.y; kv[4 * u + 2] = x.z; kv[4 * u + 3] = x.w;
             }
 #pragma unroll
-            for (int qi = 0; qi < 8; ++qi)
+            for (int qi = 0; qi < MQ; ++qi)
                 if (qi < nq) {
                     float a = 0.f;
 #pragma unroll
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict_
         }
     }
 #pragma unroll
-    for (int qi = 0; qi < 8; ++qi)
+    for (int qi = 0; qi < MQ; ++qi)
         if (qi < nq) {
             const float m = wave_max(fmaxf(fmaxf(sc[0][qi], sc[1][qi]), sc[2][qi]));
             float e[3], l = 0.f;
@@ -469,17 +470,17 @@ __global__ __launch_bounds__(64) void small_attn_kernel(const float* __restrict_
         }
     __syncthreads();
     const int d = lane & 31, h = lane >> 5;
-    float o[8];
+    float o[MQ];
 #pragma unroll
-    for (int qi = 0; qi < 8; ++qi) o[qi] = 0.f;
+    for (int qi = 0; qi < MQ; ++qi) o[qi] = 0.f;
     for (int j = h; j < L; j += 2) {
         const float v = V[(size_t)(k0 + j) * ldv + head * 32 + d];
 #pragma unroll
-        for (int qi = 0; qi < 8; ++qi)
+        for (int qi = 0; qi < MQ; ++qi)
             if (qi < nq) o[qi] = fmaf(ps[qi][j], v, o[qi]);
     }
 #pragma unroll
-    for (int qi = 0; qi < 8; ++qi)
+    for (int qi = 0; qi < MQ; ++qi)
         if (qi < nq) {
             const float t = o[qi] + __shfl_xor(o[qi], 32, 64);
             if (h == 0) OUT[(size_t)(b * nq + qi) * ldo + head * 32 + d] = t;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 
 int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* OUT,
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s) {
-    CONE_REQUIRE(nq >= 1 && nq <= 8, "decoder attention: num_queries=%d not in [1,8]", nq);
+    CONE_REQUIRE(nq >= 1 && nq <= 16, "decoder attention: num_queries=%d not in [1,16]", nq);
     CONE_REQUIRE(Lmax <= kSmallMaxKeys, "decoder attention: %d keys > %d", Lmax, kSmallMaxKeys);
     if (B <= 0) return 0;
     if (!off && nq == 5 && (ldq | ldk | ldv | ldo) % 4 == 0) {     // self-attention over the slots, the shipped slot count
@@ -543,7 +544,10 @@ int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const fl
         CONE_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(small_attn_kernel, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);
+    if (nq <= 8)
+        hipLaunchKernelGGL(small_attn_kernel<8>, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);
+    else        // (more slots than every shipped configuration trains with: cone/scripts/train_*.sh take NUM_QUERIES as an argument)
+        hipLaunchKernelGGL(small_attn_kernel<16>, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void compose_rows_kernel(const float* __restri
                                                            int sort, int B, int Nq, float* rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float st[8], ed[8], pr[8], mt[8];
-    int order[8];
+    float st[16], ed[16], pr[16], mt[16];
+    int order[16];
     const float dur = (float)duration[b], vs = (float)vstart[b];
     for (int n = 0; n < Nq; ++n) {
         const float l0 = logits[(b * Nq + n) * 2], l1 = logits[(b * Nq + n) * 2 + 1];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void compose_rows_kernel(const float* __restri
 extern "C" int cone_compose_rows(const float* logits, const float* spans, const float* match,
                                  const int32_t* duration, const int32_t* video_start, float clip_length, int sort,
                                  int B, int Nq, float* rows, void* stream) {
-    CONE_REQUIRE(Nq >= 1 && Nq <= 8, "compose_rows: Nq=%d not in [1,8]", Nq);
+    CONE_REQUIRE(Nq >= 1 && Nq <= 16, "compose_rows: Nq=%d not in [1,16]", Nq);
     if (B <= 0) return 0;
     hipLaunchKernelGGL(cone::compose_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        logits, spans, match, duration, video_start, clip_length, sort, B, Nq, rows);

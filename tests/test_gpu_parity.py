@@ -918,6 +918,42 @@ def test_pipeline_matches_oracle_and_is_chunk_invariant():
                 assert O.compute_temporal_iou(pt[i], pt[j]) <= opt.nms_thd
 
 
+@pytest.mark.parametrize("nq", [3, 10, 16])
+def test_other_slot_counts_match_oracle(nq):
+    """NUM_QUERIES is the first argument of the reference's training scripts (cone/scripts/train_*.sh; README: 5).  Any
+    count up to 16 runs -- the folded cross-attention kernels are instantiated for 5 slots, other counts take the general
+    decoder path: CONE.forward against the oracle on a ragged batch, and the device pipeline end to end."""
+    from cone_amd import inference as inf
+    model, opt, sd = get_model("ego4d", 5, num_queries=nq)
+    rng = np.random.default_rng(nq)
+    B = 9
+    lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
+    lens_v[0] = opt.max_v_l
+    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
+    inp = gi.stage_b_inputs(opt, 90 + nq, lens_v, lens_q)
+    t = torch.from_numpy
+    with torch.no_grad():
+        ref = O.cone_forward(sd, opt, t(inp["src_txt"]), t(inp["txt_mask"]), t(inp["src_vid"]), t(inp["vid_mask"]))
+    dev = _gpu()
+    g = lambda a: torch.from_numpy(a).to(dev)
+    out = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]))
+    assert tuple(out["pred_logits"].shape) == (B, nq, 2)
+    assert maxdiff(out["pred_logits"], ref["pred_logits"]) < TOL
+    assert maxdiff(out["pred_spans"], ref["pred_spans"]) < TOL
+    assert maxdiff(out["aux_outputs"][0]["pred_logits"], ref["aux_outputs"][0]["pred_logits"]) < TOL
+    popt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=8, num_queries=nq)
+    ann, vf, qf = synth.make_dataset(popt, 17, 3, seed=23, ctx_range=(130, 400))
+    (f1, _, _), info = inf.predict_split(model, inf.FeatureStore(popt, ann, vf, qf), popt)
+    (fo, _, _), ranks, mr = O.eval_epoch(sd, popt, ann, vf, qf)
+    agree = 0
+    for a, b in zip(f1, fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * popt.max_v_l * popt.clip_length + 2e-4:
+            agree += 1
+    record_measured("slot_counts_pipeline_vs_oracle", slots=nq, queries=len(f1), kept_moments_agree=agree)
+    assert agree >= PIPELINE_FLOOR * len(f1), (nq, agree)
+
+
 def test_pre_norm_pipeline_matches_oracle():
     """--pre_norm (cone/config.py:120): every transformer layer normalises its input and the encoder ends with its own
     LayerNorm (cone/transformer.py:19-36, 248-260, 319-342).  The reference fixture of that option is in
