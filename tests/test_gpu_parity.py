@@ -954,6 +954,26 @@ def test_other_slot_counts_match_oracle(nq):
     assert agree >= PIPELINE_FLOOR * len(f1), (nq, agree)
 
 
+def test_no_adapter_pipeline_matches_oracle():
+    """ADAPTER = none is the reference's other documented setting (README: ``train_mad.sh 0 5 125 none --no_adapter_loss``): the
+    pre-filter scores the normalised clip features as they are (cone/inference.py:254-260).  Pipeline against the oracle,
+    rank lists exact."""
+    from cone_amd import inference as inf
+    model, _, sd = get_model("mad", 6, adapter_module="none")
+    opt = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=4, eval_bsz=4, adapter_module="none")
+    ann, vf, qf = synth.make_dataset(opt, 10, 2, seed=29, ctx_range=(300, 700))
+    (f1, _, _), info = inf.predict_split(model, inf.FeatureStore(opt, ann, vf, qf), opt)
+    (fo, _, _), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    for qi, row in enumerate(ann):
+        assert [w for w in info["win_idx"][qi].cpu().tolist() if w >= 0] == ranks[row["query_id"]][:4]
+    agree = 0
+    for a, b in zip(f1, fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
+            agree += 1
+    assert agree >= PIPELINE_FLOOR * len(f1), agree
+
+
 def test_pre_norm_pipeline_matches_oracle():
     """--pre_norm (cone/config.py:120): every transformer layer normalises its input and the encoder ends with its own
     LayerNorm (cone/transformer.py:19-36, 248-260, 319-342).  The reference fixture of that option is in
