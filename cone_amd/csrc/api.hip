@@ -389,7 +389,10 @@ static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
                                                         // a zero text position term and the post-norm layer order)
     p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && m->opt_l0_gather;
     p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax) && !m->pre_norm;
-    if (!p.fold) p.tables = false;      // the unfolded decoder projects keys from memory + pos rows
+    // the unfolded decoder projects its keys from memory + pos rows: on the table path that matrix is written once behind the
+    // encoder (launch_add_pos_rows) -- slot counts other than 5 keep the encoder's fast path.  The fold switched off BY OPTION
+    // (parity tests) keeps meaning the whole general path
+    if (!p.fold && !(m->opt_dec_fold && m->nq != 5)) p.tables = false;
     return p;
 }
 static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const FwdPlan& p, FwdBuffers& f) {
@@ -405,6 +408,7 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
         f.QKV = c.take<float>(M * 768); f.ATT = c.take<float>(M * 256);
     }
     if (!p.fold) { f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd); }
+    if (!p.fold && p.tables) f.XP = c.take<float>(M * 256);      // memory + pos for the unfolded decoder (launch_add_pos_rows)
     f.TGT = c.take<float>(T * 256); f.TGT1 = c.take<float>(T * 256); f.TGT2 = c.take<float>(T * 256);
     f.DQK = c.take<float>(T * 768); f.DV = nullptr; f.DATT = c.take<float>(T * 256);      // DQK: the slots' q | k | v
     f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
@@ -640,6 +644,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const bool want_aux = taps && (taps->hs || taps->aux_logits || taps->aux_spans);
     bool sal_done = false;
     if (!fold) {
+        if (plan.tables) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s));
         GemmArgs g = G(m, f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
         RUN(launch_gemm(G(m, MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));

@@ -247,6 +247,8 @@ int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const
                     int Lmax, hipStream_t s, const float* tpe = nullptr, const float* tpg = nullptr,
                     const float* tpb = nullptr);        // tpe != null: --use_txt_pos (embedding rows + its LayerNorm)
 int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
+int launch_add_pos_rows(const float* MEM, const int* off, const int* vlen, const float* pos_rows, float* XP, int B, int Lmax,
+                        hipStream_t s);     // XP = MEM + table row of (vlen[b], p) for clip tokens (the unfolded decoder's keys)
 // X always; POS (sine rows) and QK / V (layer-0 q|k|v gathered from the caches) only when non-null
 int launch_row_index(const int* vrow0, const int* vlen, const int* trow0, const int* qlen, const int* off, int* ridx,
                      int B, int Lmax, hipStream_t s);

@@ -131,6 +131,32 @@ int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s) 
     return 0;
 }
 
+// XP = MEM + pos for the UNFOLDED decoder on the table path (slot counts other than 5: the folded cross-attention kernels are
+// specialised): clip token p of window b gets the table row (vlen[b], p), a text token nothing.  One wavefront per token.
+__global__ __launch_bounds__(256) void add_pos_rows_kernel(const float* __restrict__ MEM, const int* __restrict__ off,
+                                                           const int* __restrict__ vlen, const float* __restrict__ pos_rows,
+                                                           float* __restrict__ XP) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int t0 = off[b], L = off[b + 1] - t0, lv = vlen[b];
+    if (p >= L) return;
+    float4 x = reinterpret_cast<const float4*>(MEM + (size_t)(t0 + p) * 256)[lane];
+    if (p < lv) {
+        const float4 q = reinterpret_cast<const float4*>(pos_rows + ((size_t)(lv * (lv - 1) / 2 + p)) * 256)[lane];
+        x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+    }
+    reinterpret_cast<float4*>(XP + (size_t)(t0 + p) * 256)[lane] = x;
+}
+
+int launch_add_pos_rows(const float* MEM, const int* off, const int* vlen, const float* pos_rows, float* XP, int B, int Lmax,
+                        hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(add_pos_rows_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, MEM, off, vlen, pos_rows, XP);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
 // pack_pos_kernel + the first encoder layer's in_proj by gather: the q|k|v rows of a token are
 //   video clip  : qkv_vid[clip] (= vproj W^T + b, computed once per CLIP) + pos_qk[Lv, p] (= pos W_qk^T, a
 //                 static table) on the q|k part -- (x + pos) W^T = x W^T + pos W^T, rows independent;
