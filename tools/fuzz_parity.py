@@ -2,7 +2,7 @@
 """Randomised parity soak: random small splits (ragged videos from 1 clip up, 1..N queries, text lengths 1..max, top-k
 above and below the number of windows, every eval_bsz / NMS threshold / window batch), device pipeline against the CPU
 oracle: rank lists exact, window rows within the logit tolerance, fusion + NMS exact on identical candidates, results
-independent of window_batch.  Test infrastructure (imports oracle/).  usage: fuzz_parity.py [iterations] [seed0] [preset] [split_bf16 0|1]"""
+independent of window_batch.  Test infrastructure (imports oracle/).  usage: fuzz_parity.py [iterations] [seed0] [preset] [split_bf16 0|1] [model options k=v,...]"""
 import os
 import sys
 import time
@@ -21,8 +21,13 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 preset = sys.argv[3] if len(sys.argv) > 3 else "ego4d"
 split_bf16 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+# model options of the whole soak, e.g. "num_queries=10,use_txt_pos=1,pre_norm=1,adapter_module=none"
+model_kw = {}
+for kv in (sys.argv[5].split(",") if len(sys.argv) > 5 and sys.argv[5] else []):
+    k, _, v = kv.partition("=")
+    model_kw[k] = v if not v.lstrip("-").isdigit() else (bool(int(v)) if k in ("use_txt_pos", "pre_norm") else int(v))
 torch.cuda.set_device(0)
-base = make_opt(preset)
+base = make_opt(preset, **model_kw)
 sd = synth.make_state_dict(base, 0)
 model, _ = build_model(base)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -38,7 +43,7 @@ for it in range(iters):
     W = base.max_v_l
     lo = int(rng.choice([1, 5, W // 2, W, W + 1, 2 * W]))
     hi = lo + int(rng.choice([1, 7, W, 3 * W]))
-    opt = make_opt(preset, nms_thd=float(rng.choice([0.3, 0.5, 0.7, -1.0])), eval_split_name="test",
+    opt = make_opt(preset, **model_kw, nms_thd=float(rng.choice([0.3, 0.5, 0.7, -1.0])), eval_split_name="test",
                    topk_window=int(rng.choice([1, 2, 5, 9])), eval_bsz=int(rng.choice([1, 3, 4, 32])),
                    window_batch=int(rng.choice([1, 7, 64, 32768])))
     nq, nv = int(rng.choice([1, 2, 7, 13])), int(rng.choice([1, 2, 3]))
@@ -95,11 +100,11 @@ for it in range(iters):
     fmt = inf.postprocessing_format_ego4d if opt.dset_name == "ego4d" else inf.postprocessing_format_mad
     assert fmt(mr, opt) == (fo, po, mo), f"{tag}: fusion / NMS differ on identical candidates"
     assert len(fusion) == len(fo) == nq, tag
-    opt2 = make_opt(preset, **{k: getattr(opt, k) for k in ("nms_thd", "eval_split_name", "topk_window", "eval_bsz")},
+    opt2 = make_opt(preset, **model_kw, **{k: getattr(opt, k) for k in ("nms_thd", "eval_split_name", "topk_window", "eval_bsz")},
                     window_batch=32768 if opt.window_batch != 32768 else 5)
     again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
     assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
-print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
+print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}{', ' + str(model_kw) if model_kw else ''}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
       f"worst span diff {worst['sec']:.2e} s; matching: every proposal within {worst['match_alt']:.1e} of the oracle's pooling of its "
       f"own span, {tot['bad']} of {tot['rows']} rows ({tot['bad'] / max(tot['rows'], 1):.2%}) beyond 2e-4 of the oracle's rows "
       f"({tot['bnd']} proposals next to a clip boundary; worst split {worst['match_bad']:.0%}); "
