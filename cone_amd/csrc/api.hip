@@ -54,6 +54,10 @@ struct cone_model {
     // self-attention in_proj (ONE N = 768 GEMM on tgt, the table as a row-periodic residual) and a (nq, 256) table
     // qe W_q^T + b_q for the cross-attention query projection -- the same move as the encoder's position tables
     float* dec_sa_tab[CONE_MAX_LAYERS] = {}; float* dec_ca_tab[CONE_MAX_LAYERS] = {};
+    // derived (ABI 6): the static position tables of this checkpoint for windows of up to CONE_TABLE_MAX_V_L clips (row
+    // lv (lv - 1) / 2 + p: the same rows whatever the bound) -- every entry point runs the table path without the caller
+    // building anything (cone_forward_windows, cone_forward_packed without a cone_layer0 or with caches only)
+    float* tab_arena = nullptr; const float* tab_pos_rows = nullptr; const float* tab_pos_qk = nullptr; int tab_max_v_l = 0;
     // A/B switches of THIS handle (cone_model_set_option; parity tests only).  Defaults = the fast paths.
     int opt_dec_fold = 2;     // decoder memory K/V projections folded into the cross-attention kernel: 2 .. 5 = on the matrix
                               // cores (dec_cross_mfma.hip; which form: see launch_dec_cross_mfma), 1 = on the VALU
@@ -90,6 +94,8 @@ struct ArenaBuilder {
 };
 
 static int dec0_constants(cone_model* m, hipStream_t s);
+static int build_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, hipStream_t s);
+static int64_t pos_table_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2 + 1; }
 
 static int build_model(const cone_weights* w, cone_model** out) {
     CONE_REQUIRE(w && out, "model_create: null argument");
@@ -279,6 +285,21 @@ static int build_model(const cone_weights* w, cone_model** out) {
         delete m;
         return CONE_E_HIP;
     }
+    {   // the handle's own position tables (19 MB + 38 MB per encoder layer at 192 clips)
+        const size_t rows = (size_t)pos_table_rows(CONE_TABLE_MAX_V_L);
+        e = hipMalloc((void**)&m->tab_arena, rows * (256 + 512 * (size_t)m->n_enc) * sizeof(float));
+        int rc = e == hipSuccess ? 0 : CONE_E_HIP;
+        if (rc == 0) rc = build_pos_tables(m, CONE_TABLE_MAX_V_L, m->tab_arena, m->tab_arena + rows * 256, nullptr);
+        if (rc != 0 || hipDeviceSynchronize() != hipSuccess) {
+            if (e != hipSuccess) set_error("model_create: hipMalloc of the position tables failed: %s", hipGetErrorString(e));
+            if (m->tab_arena) (void)hipFree(m->tab_arena);
+            if (m->split_img) (void)hipFree(m->split_img);
+            (void)hipFree(m->arena);
+            delete m;
+            return CONE_E_HIP;
+        }
+        m->tab_pos_rows = m->tab_arena; m->tab_pos_qk = m->tab_arena + rows * 256; m->tab_max_v_l = CONE_TABLE_MAX_V_L;
+    }
     *out = m;
     return 0;
 }
@@ -338,13 +359,28 @@ static int dec0_constants(cone_model* m, hipStream_t s) {
     return 0;
 }
 
+// rows (lv, p), p < lv <= max_v_l, then ONE all-zero row: the position term of a text token (cone/model.py:106), which the
+// encoder attention adds unconditionally instead of branching on the token kind
+static int build_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, hipStream_t s) {
+    const int64_t rows = pos_table_rows(max_v_l);
+    RUN(launch_pos_rows(m->dim_t, max_v_l, pos_rows, s));
+    CONE_CHECK_HIP(hipMemsetAsync(pos_rows + (size_t)(rows - 1) * 256, 0, 256 * sizeof(float), s));    // the zero row
+    // pos W_q^T | pos W_k^T of every encoder layer, no bias (the bias travels with the clip / token rows): zero row -> zeros
+    for (int l = 0; l < m->n_enc; ++l)
+        RUN(launch_gemm(G(m, pos_rows, 256, m->enc[l].sa.in_w, 256, nullptr, pos_qk + (size_t)l * rows * 512, 512,
+                          (int)rows, nullptr, 512, 256), s));
+    return 0;
+}
+
 // input_{vid,txt}_proj: LN -> Linear -> ReLU (all but last) with the next LN fused into the GEMM epilogue.
 static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
     const size_t din = which == 0 ? m->dv : m->dt;
     return align_up(n * din * 4, 256) + 2 * align_up(n * 256 * 4, 256);
 }
+// src_row != null: row i of the projection reads row src_row[i] of x (the valid rows of a zero-padded batch, compacted by the
+// first LayerNorm's loads); n_dev != null: only the first *n_dev rows exist (device-side count, n bounds it)
 static int project_tokens(const cone_model* m, int which, const float* x, int64_t n, float* out, void* ws,
-                          size_t ws_bytes, hipStream_t s) {
+                          size_t ws_bytes, hipStream_t s, const int* src_row = nullptr, const int* n_dev = nullptr) {
     CONE_REQUIRE(n < (1ll << 31), "project: too many rows");
     const int din = which == 0 ? m->dv : m->dt;
     const LNorm* lns = which == 0 ? m->vproj_ln : m->tproj_ln;
@@ -354,13 +390,13 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
     float* ta = c.take<float>((size_t)n * 256);
     float* tb = c.take<float>((size_t)n * 256);
     if (!c.ok) { set_error("project: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
-    RUN(launch_layernorm(x, din, lns[0].g, lns[0].b, t0, din, n, nullptr, din, s));
+    RUN(launch_layernorm(x, din, lns[0].g, lns[0].b, t0, din, n, n_dev, din, s, src_row));
     const float* cur = t0;
     int K = din;
     for (int i = 0; i < m->n_proj; ++i) {
         const bool last = i == m->n_proj - 1;
         float* dst = last ? out : (cur == ta ? tb : ta);
-        GemmArgs g = G(m, cur, K, lin[i].w, K, lin[i].b, dst, 256, (int)n, nullptr, 256, K, last ? 0 : EPI_RELU);
+        GemmArgs g = G(m, cur, K, lin[i].w, K, lin[i].b, dst, 256, (int)n, n_dev, 256, K, last ? 0 : EPI_RELU);
         if (!last) { g.flags |= EPI_LN; g.ln_g = lns[i + 1].g; g.ln_b = lns[i + 1].b; }
         RUN(launch_gemm(g, s));
         cur = dst;
@@ -383,11 +419,23 @@ struct FwdBuffers {
     float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS;
 };
 struct FwdPlan { bool tables, fold; };
-static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0, int Lmax) {
+// What a call runs on: the caller's cone_layer0 with the handle's position tables filled in where it brings none (ABI 6: a
+// NULL cone_layer0, or one with the row caches only, still takes the table path), or nothing for --use_txt_pos / --pre_norm
+// (the general path: the caches / tables assume a zero text position term and the post-norm layer order).
+static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff) {
+    if (m->txt_pos_emb || m->pre_norm) return nullptr;
+    *eff = l0 ? *l0 : cone_layer0{};
+    if (!eff->qkv_vid || !eff->qkv_txt) eff->qkv_vid = eff->qkv_txt = nullptr;
+    if (!eff->pos_rows || !eff->pos_qk) {
+        if (!m->tab_pos_rows || Lv_max > m->tab_max_v_l) return (eff->qkv_vid && eff->pos_qk) ? eff : nullptr;
+        eff->pos_rows = m->tab_pos_rows; eff->pos_qk = m->tab_pos_qk; eff->max_v_l = m->tab_max_v_l;
+    }
+    return eff;
+}
+static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l0 */, int Lmax) {
     FwdPlan p;
-    if (m->txt_pos_emb || m->pre_norm) l0 = nullptr;    // --use_txt_pos / --pre_norm: the general path (the caches / tables assume
-                                                        // a zero text position term and the post-norm layer order)
-    p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && m->opt_l0_gather;
+    const bool caches = l0 && l0->qkv_vid;
+    p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && (!caches || m->opt_l0_gather);
     p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax) && !m->pre_norm;
     // the unfolded decoder projects its keys from memory + pos rows: on the table path that matrix is written once behind the
     // encoder (launch_add_pos_rows) -- slot counts other than 5 keep the encoder's fast path.  The fold switched off BY OPTION
@@ -522,14 +570,14 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const int Lmax = Lv_max + Lq_max;
     CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
     CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
-    if (m->pre_norm) l0 = nullptr;      // see plan_of
-    if (m->txt_pos_emb) {
-        l0 = nullptr;                   // see plan_of
+    if (m->txt_pos_emb)
         CONE_REQUIRE(Lq_max <= m->txt_pos_rows, "forward: %d text tokens but txt_position_embed has %d rows (max_q_l)", Lq_max,
                      m->txt_pos_rows);
-    }
-    if (l0)
-        CONE_REQUIRE(l0->qkv_vid && l0->qkv_txt && l0->pos_qk && l0->max_v_l >= Lv_max,
+    cone_layer0 eff;
+    l0 = effective_l0(m, l0, Lv_max, &eff);
+    const bool caches = l0 && l0->qkv_vid;
+    if (caches)
+        CONE_REQUIRE(l0->pos_qk && l0->max_v_l >= Lv_max,
                      "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
     const FwdPlan plan = plan_of(m, l0, Lmax);
     Carver c(ws, ws_bytes);
@@ -544,7 +592,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const size_t pos_rows_n = l0 ? (size_t)cone_pos_table_rows(l0->max_v_l) : 0;
 
     RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
-    const bool gather0 = l0 && m->opt_l0_gather;
+    const bool gather0 = caches && m->opt_l0_gather;
     // first layer entirely from the per-clip / per-token rows: attention gathers q|k|v, the fused layer tail gathers its
     // residual rows through a row index (kept in the X1 region, unused by that path) -- no packed copy of the input
     const bool gather_res = gather0 && plan.tables && m->opt_ffn_fused >= 2 && m->opt_res_gather && ffn_fused_supported(ff) &&
@@ -552,12 +600,17 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     int* RIDX = reinterpret_cast<int*>(f.X1);
     if (gather_res) {
         RUN(launch_row_index(vrow0, vlen, trow0, qlen, f.off, RIDX, B, Lmax, s));
-    } else if (l0) {
+    } else if (caches) {
         // X (and, off the table path, POS): the first layer's attention gathers q|k|v from the caches itself; with
         // the gather switched off a packing pass writes them out first
         RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, l0->qkv_vid, l0->qkv_txt,
                            l0->pos_qk, f.X, f.POS, gather0 ? nullptr : f.QKV, gather0 ? nullptr : f.QKV + (size_t)Mmax * 512,
                            B, Lmax, s));
+    } else if (plan.tables) {
+        // no row caches (a caller that hands over projected rows only): the packed layer input, nothing else -- the first
+        // layer then runs like the later ones (one N = 768 GEMM on x, position rows from the table)
+        RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, nullptr, nullptr, nullptr, f.X, nullptr,
+                           nullptr, nullptr, B, Lmax, s));
     } else {
         RUN(launch_pack_pos(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, f.X, f.POS, f.XP, B, Lmax, s,
                             m->txt_pos_emb, m->txt_pos_ln.g, m->txt_pos_ln.b));
@@ -573,7 +626,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             mode = ATTN_GATHER;
             src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.pos_qk = l0->pos_qk;
             src.vrow0 = vrow0; src.vlen = vlen; src.trow0 = trow0; src.pos_zero_row = (int)pos_rows_n - 1;
-        } else if (l == 0 && l0) {                         // packed by pack_l0: (M, 512) q|k then (M, 256) v
+        } else if (l == 0 && caches) {                     // packed by pack_l0: (M, 512) q|k then (M, 256) v
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + (size_t)Mmax * 512;
             src.ldq = src.ldk = 512; src.ldv = 256;
         } else if (plan.tables) {
@@ -581,7 +634,8 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             // static table ((x + pos) W^T = x W^T + pos W^T): no x + pos matrix, no second A operand
             if (qkv_fused) {
                 // written by the previous layer's fused tail from the registers that held its output rows
-            } else if (m->opt_split_bf16 && m->split_img)
+            } else if (m->opt_split_bf16 && m->split_img && l > 0)      // (l == 0: the kernel of cone_layer0_project, so that
+                                                                        // a window's bits do not depend on who projected it)
                 RUN(launch_rows256_split(f.X, 256, m->enc_qkv_img[l], e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, s));
             else
                 RUN(launch_gemm(G(m, f.X, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));
@@ -777,6 +831,7 @@ extern "C" void cone_model_destroy(cone_model* m) {
     if (!m) return;
     if (m->arena) (void)hipFree(m->arena);
     if (m->split_img) (void)hipFree(m->split_img);
+    if (m->tab_arena) (void)hipFree(m->tab_arena);
     delete m;
 }
 
@@ -823,7 +878,8 @@ extern "C" int cone_project_tokens(const cone_model* m, int which, const float* 
 
 extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
                                                 const cone_layer0* l0) {
-    return fwd_ws_bytes(m, B, Lv_max + Lq_max, plan_of(m, l0, Lv_max + Lq_max));
+    cone_layer0 eff;
+    return fwd_ws_bytes(m, B, Lv_max + Lq_max, plan_of(m, effective_l0(m, l0, Lv_max, &eff), Lv_max + Lq_max));
 }
 extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                                    const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
@@ -836,21 +892,11 @@ extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, cons
                           saliency, taps, ws, ws_bytes, (hipStream_t)stream, l0);
 }
 
-// rows (lv, p), p < lv <= max_v_l, then ONE all-zero row: the position term of a text token (cone/model.py:106), which the
-// encoder attention adds unconditionally instead of branching on the token kind
-extern "C" int64_t cone_pos_table_rows(int max_v_l) { return (int64_t)max_v_l * (max_v_l + 1) / 2 + 1; }
+extern "C" int64_t cone_pos_table_rows(int max_v_l) { return pos_table_rows(max_v_l); }
 
 extern "C" int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream) {
-    CONE_REQUIRE(m && pos_rows && pos_qk && max_v_l >= 1 && max_v_l <= 192, "pos_tables: bad argument");
-    const int64_t rows = cone_pos_table_rows(max_v_l);
-    hipStream_t s = (hipStream_t)stream;
-    RUN(launch_pos_rows(m->dim_t, max_v_l, pos_rows, s));
-    CONE_CHECK_HIP(hipMemsetAsync(pos_rows + (size_t)(rows - 1) * 256, 0, 256 * sizeof(float), s));    // the zero row
-    // pos W_q^T | pos W_k^T of every encoder layer, no bias (the bias travels with the clip / token rows): zero row -> zeros
-    for (int l = 0; l < m->n_enc; ++l)
-        RUN(launch_gemm(G(m, pos_rows, 256, m->enc[l].sa.in_w, 256, nullptr, pos_qk + (size_t)l * rows * 512, 512,
-                          (int)rows, nullptr, 512, 256), s));
-    return 0;
+    CONE_REQUIRE(m && pos_rows && pos_qk && max_v_l >= 1 && max_v_l <= CONE_TABLE_MAX_V_L, "pos_tables: bad argument");
+    return build_pos_tables(m, max_v_l, pos_rows, pos_qk, (hipStream_t)stream);
 }
 
 extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv,
@@ -861,13 +907,43 @@ extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, 
                          768, 256), (hipStream_t)stream);
 }
 
-extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad) {
+// The padded entry.  A zero-padded batch is first COMPACTED: the valid clip rows and the valid token rows are gathered by the
+// first LayerNorm of their input projection (padding is never projected), every later row-wise step -- the projections, the
+// first encoder layer's q | k | v rows -- runs on the compact rows with a device-side row count, and the windows enter
+// forward_packed as (row0, len) pairs into them: from there on this IS the arena path of the eval driver (gathering first
+// layer, position tables, fused layer tails, folded decoder), bit for bit.
+struct PaddedCarve {
+    int *voff, *toff, *vidx, *tidx;
+    float *vp, *tp, *qv, *qt;
+    char* pws; size_t pw;
+};
+static void carve_padded(const cone_model* m, Carver& c, int B, int Lv_pad, int Lq_pad, bool caches, PaddedCarve& p) {
     const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
-    size_t pw = project_ws_bytes(m, 0, nv);
+    p.voff = c.take<int>(B + 1); p.toff = c.take<int>(B + 1);
+    p.vidx = c.take<int>(nv); p.tidx = c.take<int>(nt);
+    p.vp = c.take<float>(nv * 256); p.tp = c.take<float>(nt * 256);
+    p.qv = p.qt = nullptr;
+    if (caches) { p.qv = c.take<float>(nv * 768); p.qt = c.take<float>(nt * 768); }
+    p.pw = project_ws_bytes(m, 0, nv);
     const size_t pt = project_ws_bytes(m, 1, nt);
-    if (pt > pw) pw = pt;
-    return fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_of(m, nullptr, Lv_pad + Lq_pad)) + pw + align_up(nv * 256 * 4, 256) +
-           align_up(nt * 256 * 4, 256) + 2 * align_up((size_t)B * 4, 256);
+    if (pt > p.pw) p.pw = pt;
+    p.pws = c.take<char>(p.pw);
+}
+static bool padded_uses_caches(const cone_model* m, int Lv_pad) {
+    cone_layer0 eff;
+    const cone_layer0* l0 = effective_l0(m, nullptr, Lv_pad, &eff);
+    return l0 && m->opt_pos_tables && m->opt_l0_gather;
+}
+extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad) {
+    const bool caches = padded_uses_caches(m, Lv_pad);
+    Carver c(nullptr, ~(size_t)0);
+    PaddedCarve p;
+    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, p);
+    cone_layer0 l0{};
+    if (caches) { l0.qkv_vid = l0.qkv_txt = reinterpret_cast<const float*>(16); }    // presence only: sizes the same plan
+    cone_layer0 eff;
+    return c.cur + fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_of(m, effective_l0(m, caches ? &l0 : nullptr, Lv_pad, &eff),
+                                                               Lv_pad + Lq_pad));
 }
 extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len, const float* txt,
                                     const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,
@@ -875,26 +951,28 @@ extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const
                                     size_t ws_bytes, void* stream) {
     CONE_REQUIRE(m && vid && txt && vid_len && txt_len && logits && spans, "forward_windows: null argument");
     CONE_REQUIRE(B > 0 && Lv_pad > 0 && Lq_pad > 0, "forward_windows: bad sizes");
+    CONE_REQUIRE((int64_t)B * Lv_pad < (1ll << 31) && (int64_t)B * Lq_pad < (1ll << 31), "forward_windows: batch too large");
     hipStream_t s = (hipStream_t)stream;
     const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
+    const bool caches = padded_uses_caches(m, Lv_pad);
     Carver c(ws, ws_bytes);
-    float* vp = c.take<float>(nv * 256);
-    float* tp = c.take<float>(nt * 256);
-    int* vrow0 = c.take<int>(B);
-    int* trow0 = c.take<int>(B);
-    size_t pw = project_ws_bytes(m, 0, nv);
-    const size_t pt = project_ws_bytes(m, 1, nt);
-    if (pt > pw) pw = pt;
-    char* pws = c.take<char>(pw);
+    PaddedCarve p;
+    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, p);
     if (!c.ok) { set_error("forward_windows: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
-    // Rows of the zero padding are projected too (wasted work, only on this compatibility path).
-    RUN(project_tokens(m, 0, vid, nv, vp, pws, pw, s));
-    RUN(project_tokens(m, 1, txt, nt, tp, pws, pw, s));
-    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, vrow0, B, Lv_pad);
-    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trow0, B, Lq_pad);
-    CONE_LAUNCH_CHECK();
-    return forward_packed(m, vp, vrow0, vid_len, tp, trow0, txt_len, B, Lv_pad, Lq_pad, logits, spans, saliency,
-                          taps, (char*)ws + c.cur, ws_bytes - c.cur, s);
+    // compact row lists of the valid clips / tokens: offsets (= the windows' first rows), source-row indices, device counts
+    RUN(launch_scan_lengths(vid_len, nullptr, B, p.voff, s));
+    RUN(launch_scan_lengths(txt_len, nullptr, B, p.toff, s));
+    RUN(launch_compact_index(vid_len, p.voff, Lv_pad, p.vidx, txt_len, p.toff, Lq_pad, p.tidx, B, s));
+    RUN(project_tokens(m, 0, vid, nv, p.vp, p.pws, p.pw, s, p.vidx, p.voff + B));
+    RUN(project_tokens(m, 1, txt, nt, p.tp, p.pws, p.pw, s, p.tidx, p.toff + B));
+    cone_layer0 l0{};
+    if (caches) {   // the first encoder layer's in_proj once per compact row (cone_layer0_project's kernel)
+        RUN(launch_gemm(G(m, p.vp, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, p.qv, 768, (int)nv, p.voff + B, 768, 256), s));
+        RUN(launch_gemm(G(m, p.tp, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, p.qt, 768, (int)nt, p.toff + B, 768, 256), s));
+        l0.qkv_vid = p.qv; l0.qkv_txt = p.qt;
+    }
+    return forward_packed(m, p.vp, p.voff, vid_len, p.tp, p.toff, txt_len, B, Lv_pad, Lq_pad, logits, spans, saliency,
+                          taps, (char*)ws + c.cur, ws_bytes - c.cur, s, caches ? &l0 : nullptr);
 }
 
 extern "C" size_t cone_clip_matching_workspace(const cone_model* m, int B) {

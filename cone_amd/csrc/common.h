@@ -190,7 +190,8 @@ int launch_proj_ffn_split(const float* A, int lda, const void* Woimg, const floa
 
 // ---------------------------------------------------------------- row kernels (rowops.hip)
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
-                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s);
+                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s, const int* src_row = nullptr);
+// src_row != null: output row i normalises input row src_row[i]
 int launch_l2norm(const float* x, int64_t n_rows, int dim, float eps, float* out, hipStream_t s, int clamp = 0);
 // out[m][n] = act(<X[m], W[n]> + b[n]), n < nout <= 2, K = 256; act 0 none, 1 sigmoid
 int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float* out, int ldo,
@@ -241,7 +242,9 @@ int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const fl
                       int ldo, const int* off, int B, int nq, int Lmax, hipStream_t s);
 
 // ---------------------------------------------------------------- window_ops.hip
-int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s);
+int launch_scan_lengths(const int* vlen, const int* qlen /* may be null */, int B, int* off, hipStream_t s);
+int launch_compact_index(const int* vlen, const int* voff, int Lv_pad, int* vidx, const int* qlen, const int* toff, int Lq_pad,
+                         int* tidx, int B, hipStream_t s);
 int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const float* tproj, const int* trow0,
                     const int* qlen, const int* off, const float* dim_t, float* X, float* POS, float* XP, int B,
                     int Lmax, hipStream_t s, const float* tpe = nullptr, const float* tpg = nullptr,

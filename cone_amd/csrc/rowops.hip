@@ -9,12 +9,13 @@ namespace cone {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, float* out, int ldo,
-                                                        int64_t n_rows, const int* n_rows_dev, int dim) {
+                                                        int64_t n_rows, const int* n_rows_dev, int dim,
+                                                        const int* __restrict__ src_row) {
     if (n_rows_dev) { int64_t nd = *n_rows_dev; n_rows = nd < n_rows ? nd : n_rows; }
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
-    const float* xr = x + row * ldx;
+    const float* xr = x + (src_row ? (int64_t)src_row[row] : row) * ldx;      // src_row: a gathering read (compaction)
     const int nv = dim >> 2;  // float4 per row
     float4 v[4];
     float s = 0.f;
@@ -55,12 +56,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, int ldx, const float* g, const float* b, float* out, int ldo,
-                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s) {
+                     int64_t n_rows, const int* n_rows_dev, int dim, hipStream_t s, const int* src_row) {
     CONE_REQUIRE(dim % 4 == 0 && dim <= 1024 && ldx % 4 == 0 && ldo % 4 == 0,
                  "layernorm: dim=%d must be a multiple of 4 and <= 1024", dim);
     if (n_rows <= 0) return 0;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, ldx, g, b,
-                       out, ldo, n_rows, n_rows_dev, dim);
+                       out, ldo, n_rows, n_rows_dev, dim, src_row);
     CONE_LAUNCH_CHECK();
     return 0;
 }

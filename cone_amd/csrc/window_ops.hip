@@ -15,7 +15,7 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int* __restric
     const int per = (((B + 15) / 16 + 63) / 64) * 64;             // windows per wave, a multiple of 64
     const int b0 = min(wave * per, B), b1 = min(b0 + per, B);
     int s = 0;
-    for (int b = b0 + lane; b < b1; b += 64) s += vlen[b] + qlen[b];
+    for (int b = b0 + lane; b < b1; b += 64) s += vlen[b] + (qlen ? qlen[b] : 0);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) wsum[wave] = s;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int* __restric
     if (tid == 1023) off[B] = run + wsum[15];
     for (int base = b0; base < b1; base += 64) {
         const int b = base + lane;
-        const int v = b < b1 ? vlen[b] + qlen[b] : 0;
+        const int v = b < b1 ? vlen[b] + (qlen ? qlen[b] : 0) : 0;
         int x = v;                                                // inclusive scan over the 64 lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -39,6 +39,29 @@ __global__ __launch_bounds__(1024) void scan_lengths_kernel(const int* __restric
 
 int launch_scan_lengths(const int* vlen, const int* qlen, int B, int* off, hipStream_t s) {
     hipLaunchKernelGGL(scan_lengths_kernel, dim3(1), dim3(1024), 0, s, vlen, qlen, B, off);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Source rows of the COMPACT row lists of a zero-padded batch (cone_forward_windows): valid row p of window b of a (B, Lpad, *)
+// tensor is row b * Lpad + p; it becomes row off[b] + p of the compact list.  blockIdx.z: 0 = clips, 1 = text tokens.
+__global__ __launch_bounds__(256) void compact_index_kernel(const int* __restrict__ vlen, const int* __restrict__ voff, int Lv_pad,
+                                                            int* __restrict__ vidx, const int* __restrict__ qlen,
+                                                            const int* __restrict__ toff, int Lq_pad, int* __restrict__ tidx) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const bool txt = blockIdx.z != 0;
+    const int len = min(txt ? qlen[b] : vlen[b], txt ? Lq_pad : Lv_pad);
+    if (p >= len) return;
+    if (txt) tidx[toff[b] + p] = b * Lq_pad + p;
+    else vidx[voff[b] + p] = b * Lv_pad + p;
+}
+
+int launch_compact_index(const int* vlen, const int* voff, int Lv_pad, int* vidx, const int* qlen, const int* toff, int Lq_pad,
+                         int* tidx, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int L = Lv_pad > Lq_pad ? Lv_pad : Lq_pad;
+    hipLaunchKernelGGL(compact_index_kernel, dim3((L + 255) / 256, B, 2), dim3(256), 0, s, vlen, voff, Lv_pad, vidx, qlen, toff,
+                       Lq_pad, tidx);
     CONE_LAUNCH_CHECK();
     return 0;
 }

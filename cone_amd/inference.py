@@ -82,6 +82,8 @@ class FeatureStore:
         self.q_vid = np.array([self.clip2idx[r["clip_id"]] for r in self.ann], dtype=np.int64)
         self.q_base = 0         # annotation index of this store's first query in the split it was cut from
         self.nq_split = len(self.ann)
+        self.max_tok_len = max(self.tok_len) if self.tok_len else 0     # of the SPLIT (views inherit it): kernel forms are
+                                                                        # chosen from it, never from a chunk's own queries
         self._plan = None
         self._index = None
 
@@ -95,6 +97,7 @@ class FeatureStore:
         sub.opt, sub.device = store.opt, store.device
         sub.tok_normalized, sub.cls_normalized = store.tok_normalized, store.cls_normalized
         sub.q_base, sub.nq_split = store.q_base + lo, store.nq_split
+        sub.max_tok_len = store.max_tok_len
         sub.ann = store.ann[lo:hi]
         sub.clip_ids, sub.clip2idx, sub.ctx_l, sub.vid_off = store.clip_ids, store.clip2idx, store.ctx_l, store.vid_off
         sub.vid_raw = store.vid_raw
@@ -297,6 +300,7 @@ class FeatureStore:
         st.cls_raw = up(mm["cls_raw"][:nq])
         st.q_vid = np.array([st.clip2idx[r["clip_id"]] for r in st.ann], dtype=np.int64)
         st.q_base, st.nq_split = 0, len(st.ann)
+        st.max_tok_len = max(st.tok_len) if st.tok_len else 0
         st._plan = None
         st._index = None
         return st
@@ -466,8 +470,7 @@ def project_video(model, store: FeatureStore, row_range=None):
     vproj = model.project(0, store.vid_raw[r0:r1])
     out = dict(vproj=vproj, vid_base=r0)
     if getattr(store.opt, "layer0_cache", True):
-        out["l0_vid"] = model.layer0_rows(vproj)
-        out["tables"] = model.pos_tables(store.opt.max_v_l)
+        out["l0_vid"] = model.layer0_rows(vproj)      # (the position tables are the model handle's own)
     return out
 
 
@@ -484,8 +487,7 @@ def project_features(model, store: FeatureStore, video=None):
     cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :280
     feats = dict(vproj=video["vproj"], vid_base=video["vid_base"], tproj=tproj, cls_norm=cls_norm)
     if "l0_vid" in video:
-        feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=model.layer0_rows(tproj), max_v_l=store.opt.max_v_l,
-                           **video["tables"])
+        feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=model.layer0_rows(tproj), max_v_l=store.opt.max_v_l)
     return feats
 
 
@@ -497,7 +499,9 @@ def run_windows(model, store: FeatureStore, opt, wt, feats=None, chunk=None):
     feats = feats or project_features(model, store)
     nw = wt["vid_row0"].shape[0]
     chunk = chunk or int(getattr(opt, "window_batch", 32768))
-    Lq_max = max(store.tok_len)
+    # the longest query of the SPLIT, not of this chunk / shard view: the library picks kernel forms from Lv_max + Lq_max
+    # (e.g. the rows-once cross-attention up to 128 tokens), and a window's bits must not depend on the chunk it rides in
+    Lq_max = int(getattr(store, "max_tok_len", 0)) or max(store.tok_len)
     base = int(feats.get("vid_base", 0))
     outs = {k: [] for k in ("pred_logits", "pred_spans", "matching", "rows")}
     for c0 in range(0, nw, chunk):
@@ -812,7 +816,7 @@ def _graph_replay(model, store: FeatureStore, opt):
             dp = device_pipeline(model, store, opt)
         # everything the captured launches point at must outlive the graph: the model (weights, position tables) and the
         # workspace buffer of THIS capture (the model's grow-only workspace may be replaced by a larger one later)
-        hit = cache[key] = (g, dp, model, model._ws.buf, getattr(model, "_pos_tabs", None))
+        hit = cache[key] = (g, dp, model, model._ws.buf)
     hit[0].replay()
     return dict(hit[1])
 

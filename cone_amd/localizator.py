@@ -65,7 +65,10 @@ class CONELocalizator:
         zeros = torch.zeros(K, dtype=torch.int32, device=dev)
         full = lambda v: torch.full((K,), v, dtype=torch.int32, device=dev)
         vproj, tproj = m.project(0, vid), m.project(1, tok)
-        out = m.forward_packed(vproj, i32(start), i32(vlen), tproj, zeros, full(tok.shape[0]), W, a.max_q_l)
+        # the eval driver's path: first-layer q|k|v once per clip / token, position tables, fused layer tails (the reference
+        # replicates and re-projects per window, run_on_video/cone_localizator.py:150-182)
+        out = m.forward_packed(vproj, i32(start), i32(vlen), tproj, zeros, full(tok.shape[0]), W, a.max_q_l,
+                               l0=m.layer0_cache(vproj, tproj, W), saliency=False)
         match = m.clip_matching_gathered(cls, zeros, vid, i32(start), i32(vlen), full(W), out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, full(W), i32(start), a.clip_length,
                                 sort=False)                                                   # :191, no sort

@@ -287,9 +287,9 @@ class CONE:
         return self._pos_tabs[1]
 
     def layer0_cache(self, vproj, tproj, max_v_l: int):
-        """cone_layer0 for forward_packed: per-row q|k|v caches + the static position tables."""
-        return dict(qkv_vid=self.layer0_rows(vproj), qkv_txt=self.layer0_rows(tproj), max_v_l=max_v_l,
-                    **self.pos_tables(max_v_l))
+        """cone_layer0 for forward_packed: the per-row q|k|v caches.  The static position tables are the handle's own
+        (built at cone_model_create, ABI 6); ``pos_tables()`` builds caller-owned ones (parity tests)."""
+        return dict(qkv_vid=self.layer0_rows(vproj), qkv_txt=self.layer0_rows(tproj), max_v_l=max_v_l)
 
     def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None,
                        saliency: bool = True, aux: bool = False):
@@ -300,8 +300,8 @@ class CONE:
         lib, h = _lib.load(), self._h()
         l0s = l0p = None
         if l0 is not None:
-            l0s = _lib.Layer0(l0["qkv_vid"].data_ptr(), l0["qkv_txt"].data_ptr(), l0["pos_qk"].data_ptr(),
-                              l0["pos_rows"].data_ptr() if l0.get("pos_rows") is not None else None, l0["max_v_l"])
+            dp = lambda k: l0[k].data_ptr() if l0.get(k) is not None else None
+            l0s = _lib.Layer0(dp("qkv_vid"), dp("qkv_txt"), dp("pos_qk"), dp("pos_rows"), l0["max_v_l"])
             l0p = C.byref(l0s)
         B = vid_row0.shape[0]
         dev = vproj.device

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 5
+#define CONE_HIP_ABI_VERSION 6
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -40,6 +40,7 @@ extern "C" {
 
 #define CONE_MAX_LAYERS 8
 #define CONE_MAX_PROJ 3
+#define CONE_TABLE_MAX_V_L 192 /* longest window (clips) the handle's own position tables cover */
 
 typedef struct cone_model cone_model;
 

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cone_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-    assert lib.cone_abi_version() == 5
+    assert lib.cone_abi_version() == 6
     assert lib.cone_num_windows(901, 90) == 22 and lib.cone_num_windows(1250, 125) == 22
 
 
