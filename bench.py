@@ -409,6 +409,96 @@ def bench_latency_config1(sd_seed=0, steps=20):
     return out
 
 
+def reference_batch_tensors(model, store, opt, n_batch_queries=None):
+    """The FIRST reference batch of the split as cone/inference.py:45-50 sees it: ``eval_bsz`` consecutive queries x their
+    top-k windows (cone/config.py:59, cone/ego4d_mad_dataloader.py:146), collated like StartEndDataset's collate
+    (:305-344): clips zero-padded to the batch's longest window, the query's tokens REPLICATED into each of its windows and
+    zero-padded to the batch's longest query, prefix masks.  Returns the ``model_inputs`` dict + the window table rows."""
+    nqb = min(n_batch_queries or opt.eval_bsz, len(store.ann))
+    sub = store.view(0, nqb) if nqb < len(store.ann) else store
+    win_idx = inf.prefilter(model, sub, opt)
+    wt = inf.window_table(sub, opt, win_idx)
+    vrow0, vlen = wt["vid_row0"].long(), wt["vid_len"].long()
+    trow0, tlen = wt["txt_row0"].long(), wt["txt_len"].long()
+    B, Lv, Lq = int(vrow0.shape[0]), int(vlen.max()), int(tlen.max())
+    dev = store.device
+    ar_v, ar_q = torch.arange(Lv, device=dev)[None], torch.arange(Lq, device=dev)[None]
+    vmask, tmask = (ar_v < vlen[:, None]), (ar_q < tlen[:, None])
+    tok = store.tok_raw if store.tok_normalized else ops.l2_normalize(store.tok_raw, 1e-5)
+    cls = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)
+    src_vid = store.vid_raw[(vrow0[:, None] + ar_v).clamp_(max=store.vid_raw.shape[0] - 1)] * vmask[..., None]
+    src_txt = tok[(trow0[:, None] + ar_q).clamp_(max=tok.shape[0] - 1)] * tmask[..., None]
+    return dict(src_txt=src_txt.contiguous(), src_txt_mask=tmask.float(), src_vid_motion=src_vid.contiguous(),
+                src_vid_motion_mask=vmask.float(), src_cls_txt=cls[wt["cls_row"].long()].contiguous()), wt, sub
+
+
+def bench_dropin_forward(model, store, opt, arena_exec_tflops, steps=20, warmup=3):
+    """INTEGRATION.md Option A, measured: the reference's own call sites (cone/inference.py:45-50) on the reference's own
+    batch -- ``outputs = model(**model_inputs)`` then ``model.forward_clip_matching(...)`` on eval_bsz x top-k zero-padded
+    windows -- through cone_amd.model.CONE.forward = cone_forward_windows (compaction, projection of the valid rows,
+    first-layer row caches, then the arena path's launches).  The dominant kernel's roofline from the launch records of the
+    timed region; executed FLOPs / time against the arena path's figure for the same quantity."""
+    lib = _lib.load()
+    inputs, wt, sub = reference_batch_tensors(model, store, opt)
+    B, Lv = inputs["src_vid_motion"].shape[:2]
+    Lq = inputs["src_txt"].shape[1]
+    mi = {k: inputs[k] for k in ("src_txt", "src_txt_mask", "src_vid_motion", "src_vid_motion_mask")}
+
+    def call():
+        o = model(**mi)
+        m = model.forward_clip_matching(inputs["src_cls_txt"], inputs["src_vid_motion"], inputs["src_vid_motion_mask"],
+                                        proposal=o["pred_spans"])
+        return o, m
+    dt, (o, mt) = _timed(call, steps, warmup)       # the figure: no launch timer (its two event records per launch cost a
+    lib.cone_prof_enable(1)                         # 2.5 ms batch ~10 %; a 53 ms step nothing)
+    dt_prof, _ = _timed(call, steps, 0)             # the kernel records: a second pass with the timer on
+    rec = collect_profile()
+    lib.cone_prof_enable(0)
+    roof, kern = roofline_from_profile(rec)
+    vl, tl = wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy()
+    ex = executed_mfma_flops(rec, vl, tl, opt, steps)
+    etf = ex["total"] / (dt * steps) / 1e12         # FLOPs of the recorded pass = FLOPs of the timed pass (same batch)
+    big_gemm = [f"N{int(b)}_K{int(c)}" for k, a, b, c, ms in rec if int(k) in (5, 6, 14) and (int(b) == 1024 or int(c) == 1024)]
+    # the same windows through the arena entry: the two entries are one path, bit for bit
+    feats = inf.project_features(model, sub)
+    ar = model.forward_packed(feats["vproj"], wt["vid_row0"], wt["vid_len"], feats["tproj"], wt["txt_row0"], wt["txt_len"],
+                              opt.max_v_l, int(tl.max()), l0=feats.get("l0"), saliency=True, aux=True)
+    same = bool(torch.equal(ar["pred_logits"], o["pred_logits"]) and torch.equal(ar["pred_spans"], o["pred_spans"]))
+    return {"workload": f"the reference's batch (cone/inference.py:45-50): eval_bsz {opt.eval_bsz} x top-{opt.topk_window} = {B} "
+                        f"zero-padded windows (Lv_pad {Lv}, Lq_pad {Lq}, {int(vl.sum() + tl.sum())} valid of {B * (Lv + Lq)} "
+                        "token rows), model(**model_inputs) + model.forward_clip_matching(...) through CONE.forward -> "
+                        "cone_forward_windows",
+            "ms_per_batch": round(dt * 1e3, 3), "windows_per_s": round(B / dt, 1),
+            "ms_per_batch_with_launch_timer": round(dt_prof * 1e3, 3),
+            "launches_per_batch": int(len(rec) / steps), "roofline": roof,
+            "layer_tail_launches": {k: v["launches"] // steps for k, v in kern.items() if k.startswith("ffn_")},
+            "row_gemm_launches_with_1024": len(big_gemm),       # 0: no unfused linear1 / linear2 GEMM anywhere
+            "executed_tflops": round(etf, 1), "executed_frac": round(etf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_gflop_per_batch": {k: round(v / steps / 1e9, 2) for k, v in ex.items()},
+            "arena_path_executed_tflops": round(arena_exec_tflops, 1) if arena_exec_tflops else None,
+            "executed_rate_vs_arena_path": round(etf / arena_exec_tflops, 3) if arena_exec_tflops else None,
+            "same_bits_as_arena_entry": same,
+            "note": "a 640-window batch is 2.1 rounds of the persistent layer-tail grid (256 CUs x 128 rows) and its small "
+                    "kernels are launch-bound: the arena path runs 20 000 windows per launch sequence"}
+
+
+def bench_localizer(sd_seed=0, steps=30, ctx_l=900, n_tok=12):
+    """run_on_video/cone_localizator.py:121-221 -- CONELocalizator.predict_moment(video_feats, text_feats): one query over
+    one resident 900-clip video (BASELINE configs[0]'s shape), host tensors in, python list out."""
+    from cone_amd.localizator import CONELocalizator
+    opt = make_opt("ego4d")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, sd_seed).items()}
+    loc = CONELocalizator(state_dict=sd)
+    g = torch.Generator().manual_seed(3)
+    vid = torch.randn(ctx_l, 256, generator=g).cuda()
+    tok, cls = torch.randn(n_tok, 768, generator=g).cuda(), torch.randn(256, generator=g).cuda()
+    dt, res = _timed(lambda: loc.predict_moment(vid, (tok, cls)), steps, 5)
+    return {"workload": f"CONELocalizator.predict_moment: 1 query ({n_tok} tokens) x 1 video (ctx_l {ctx_l}) resident on the "
+                        "device, 20 windows, fused-score NMS, python list of [st, ed, score]",
+            "ms_per_query": round(dt * 1e3, 3), "queries_per_s": round(1.0 / dt, 1), "moments": len(res)}
+
+
+
 def bench_config5(ctx_l=33_000, queries=64, steps=10):
     """BASELINE configs[4] on one GPU: 64 concurrent queries over one MAD-length video (ctx_l ~ 33 k clips = 110 min
     at 5 fps, d 512, window_len 125, top-30 => 1 920 windows), stages A->C + JSON rows."""
@@ -833,7 +923,7 @@ def main():
     def watchdog():
         if not extras_done.wait(args.extras_timeout):
             emit({"extras_timed_out_after_s": args.extras_timeout})
-            os._exit(0)
+            os._exit(4)         # the headline is out, but a stalled extra / dead rank is a FAILED run for the launcher
     if use_dist and world > 1:
         threading.Thread(target=watchdog, daemon=True).start()
 
@@ -952,6 +1042,8 @@ def main():
                     "same_rows_as_eager": glists == out[0],
                     "note": "opt-in opt.hip_graph (NOT the headline): one graph launch per step instead of ~110 kernel launches"}
         guarded("hip_graph", dense_graph)
+        guarded("dropin_forward", lambda: bench_dropin_forward(
+            model, store, opt, (res or {}).get("window_model", {}).get("executed_tflops")))
         guarded("shard_proxy_8", lambda: bench_shard_proxy(model, store, opt, serial_ms[0]))
         guarded("config2_ragged", lambda: bench_config2_ragged(model, opt, args.queries, args.videos,
                                                                dt / args.steps * 1e6 / n_windows, steps=args.steps))
@@ -959,11 +1051,33 @@ def main():
         model._ws.buf = None
         torch.cuda.empty_cache()
         guarded("latency_config1", bench_latency_config1)
+
+        def localizer():
+            v = bench_localizer()
+            base = (res or {}).get("latency_config1", {}).get("ms_per_query")
+            if base:
+                v["latency_config1_ms_per_query"] = base
+                v["vs_latency_config1"] = round(v["ms_per_query"] / base, 3)
+            return v
+        guarded("localizer", localizer)
         guarded("config5", bench_config5)
         guarded("prefilter_mad", bench_prefilter_mad)
     if world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
         guarded("cpu_baseline", lambda: cpu_baseline(opt, sd, args.cpu_queries,
                                                      max(1, args.cpu_queries * args.videos // args.queries)))
+    if res is not None and isinstance(res.get("roofline"), dict):
+        # SURVEY 8(d)'s second roofline rides inside the headline's `roofline` object (the driver keeps that object): the
+        # pre-filter's HBM roofline on BASELINE configs[2] at 1 and 64 queries, and the whole step's executed fraction
+        pm = res.get("prefilter_mad") or {}
+        for key, name in (("q1", "prefilter"), ("q64", "prefilter_q64")):
+            r = (pm.get(key) or {}).get("roofline")
+            if r:
+                res["roofline"][name] = dict(r, kernel=pm[key].get("kernel"), workload="BASELINE.json configs[2], "
+                                             f"{pm[key].get('queries')} query(ies): 4 ctx_l dv + Q 4 (dv + num_window) bytes "
+                                             "over the hipEvent time of the frame-score launch")
+        wm = res.get("window_model") or {}
+        if "executed_frac" in wm:
+            res["roofline"]["step_executed_frac"] = wm["executed_frac"]      # all MFMA FLOPs of the step / step time / 157.3
     extras_done.set()
     emit()
     if use_dist:

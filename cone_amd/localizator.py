@@ -46,8 +46,28 @@ class CONELocalizator:
         idx, _ = ops.topk_windows(ws, ws.shape[1])
         return idx[0].tolist()
 
+    def _const(self, ctx_l: int, n_tok: int):
+        """Index metadata of one (video length, query length) shape on the device, built once: the latency path uploads
+        nothing per call (a pageable H2D copy waits for the stream to drain)."""
+        cache = self.__dict__.setdefault("_consts", {})
+        c = cache.get((ctx_l, n_tok))
+        if c is None:
+            if len(cache) > 64:
+                cache.clear()
+            dev, a = self.device, self.args
+            K = min(a.topk_window, ops.num_windows(ctx_l, a.max_v_l))
+            t = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            c = cache[(ctx_l, n_tok)] = dict(
+                K=K, q_ctx_l=t([ctx_l]), q_vid_off=t([0]), tok_off=t([0, n_tok]), tok_len=t([n_tok]),
+                batch_pad=t([a.max_v_l]), full_w=torch.full((K,), a.max_v_l, dtype=torch.int32, device=dev),
+                n_valid=t([K * self.localizator.num_queries]))
+        return c
+
     @torch.no_grad()
     def predict_moment(self, video_feats, text_feats):
+        """run_on_video/cone_localizator.py:121-221 on the eval driver's kernels, enqueued without a host round trip until
+        the kept moments are read back: window ranks stay on the device (the window table kernel turns them into row
+        ranges), first-layer q|k|v once per clip / token, position tables, fused layer tails."""
         a, m, dev = self.args, self.localizator, self.device
         text_token_feats, text_cls_feat = text_feats
         if text_token_feats.shape[0] > a.max_q_l:
@@ -55,24 +75,21 @@ class CONELocalizator:
         vid = ops.l2_normalize(video_feats.to(dev, torch.float32), 1e-5, clamp=True)          # :129
         tok = ops.l2_normalize(text_token_feats.to(dev, torch.float32), 1e-5, clamp=True)     # :133
         cls = text_cls_feat.to(dev, torch.float32).reshape(1, -1).contiguous()
+        c = self._const(int(vid.shape[0]), int(tok.shape[0]))
+        K, W = c["K"], a.max_v_l
         adapted = m.adapter_norm(vid, renorm=False)                                           # :135-138
-        ranks = self.compute_window_ranklist(adapted, cls)
-        widx = torch.tensor(ranks[:a.topk_window], dtype=torch.int64, device=dev)
-        K, S, W, ctx_l = widx.shape[0], self.slide_window_size, a.max_v_l, vid.shape[0]
-        start = torch.clamp((widx - 1) * S, min=0)
-        vlen = torch.minimum((widx - 1) * S + W, torch.tensor(ctx_l, device=dev)) - start
-        i32 = lambda t: t.to(torch.int32).contiguous()
-        zeros = torch.zeros(K, dtype=torch.int32, device=dev)
-        full = lambda v: torch.full((K,), v, dtype=torch.int32, device=dev)
+        _, ws = ops.prefilter_scores(adapted, cls, W, frame_scores=False)                     # :83-100 (stable tie order)
+        widx, _ = ops.topk_windows(ws, K)
+        # every window counts as padded to max_v_l (the reference pads each to (max_v_l, max_q_l), :150-170)
+        wt = ops.window_table_rows(widx, c["q_ctx_l"], c["q_vid_off"], c["tok_off"], c["tok_len"], 0, 1, W,
+                                   batch_pad=c["batch_pad"], n_batches=1)
         vproj, tproj = m.project(0, vid), m.project(1, tok)
-        # the eval driver's path: first-layer q|k|v once per clip / token, position tables, fused layer tails (the reference
-        # replicates and re-projects per window, run_on_video/cone_localizator.py:150-182)
-        out = m.forward_packed(vproj, i32(start), i32(vlen), tproj, zeros, full(tok.shape[0]), W, a.max_q_l,
+        out = m.forward_packed(vproj, wt["vid_row0"], wt["vid_len"], tproj, wt["txt_row0"], wt["txt_len"], W, a.max_q_l,
                                l0=m.layer0_cache(vproj, tproj, W), saliency=False)
-        match = m.clip_matching_gathered(cls, zeros, vid, i32(start), i32(vlen), full(W), out["pred_spans"])
-        rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, full(W), i32(start), a.clip_length,
-                                sort=False)                                                   # :191, no sort
-        cand = rows.reshape(1, K * m.num_queries, 4).contiguous()
-        nv = torch.tensor([K * m.num_queries], dtype=torch.int32, device=dev)
-        kept, n, _ = ops.fuse_nms(cand, nv, 0.5, 100, 5)                                       # :200-219
-        return [[r[0], r[1], r[4]] for r in kept[0, 0, :int(n[0, 0])].cpu().tolist()]
+        match = m.clip_matching_gathered(cls, wt["cls_row"], vid, wt["vid_row0"], wt["vid_len"], wt["pad_len"],
+                                         out["pred_spans"])
+        rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, c["full_w"], wt["video_start"], a.clip_length,
+                                sort=False)                                                   # :191: scaled by max_v_l, no sort
+        kept, n, _ = ops.fuse_nms(rows.reshape(1, K * m.num_queries, 4), c["n_valid"], 0.5, 100, 5)      # :200-219
+        kept, n = kept[0, 0].cpu(), int(n[0, 0])        # the call's one read-back
+        return [[r[0], r[1], r[4]] for r in kept[:n].tolist()]
