@@ -11,17 +11,20 @@ fusion, 3x NMS, JSON rows) over BASELINE.json configs[1]: Ego4D-NLQ val-scale sy
 (1 000 queries over 50 videos, ctx_l~U[850,950), window_len 90, d 256, top-k 20 => 20 000 windows,
 NMS 0.5) with every feature already resident in HBM.
 
-Prints ONE JSON line (rank 0).  `value` (weak scaling): every rank runs its own split of that size, the kept
-rows of all shards are all-gathered over RCCL.  Extra objects on the same line:
+Prints ONE JSON line (rank 0).  `value` (strong scaling): ONE such split per step whatever N -- at N > 1 it is sharded by
+window over the ranks (BASELINE configs[3]: cone_amd.parallel.predict_split_distributed_async, one RCCL all_gather of the
+per-window proposal rows ahead of the global NMS).  Extra objects on the same line:
   * `roofline`      -- the dominant kernel (the fp32-MFMA GEMM tile that accumulates the most time) priced from
                        hipEvent timings taken around each of its launches inside the timed region (cone_prof_*),
                        FLOPs = 2*M*N*K with the M actually processed;
-  * `strong_scaling` (N > 1) -- BASELINE configs[3]: ONE such split sharded by window over the N ranks
-                       (cone_amd.parallel.predict_split_distributed, one all_gather of proposal rows);
+  * `weak_scaling` (N > 1) -- every rank its own split of that size, the kept rows of all shards all-gathered (the N > 1
+                       HEADLINE is BASELINE configs[3]: ONE split sharded by window, strong scaling -- see `value` below);
+  * `dropin_forward`, `localizer` (N = 1) -- the reference's own Python API on the same kernels: its 640-window padded
+                       batch through model(**inputs) + forward_clip_matching, and CONELocalizator.predict_moment;
   * `config5_sharded`, `prefilter_mad_ctx_sharded` (N > 1) -- BASELINE configs[4] and [2] over the N ranks: pre-filter
                        sharded along ctx_l, window model sharded by window;
-  * `shard_proxy_8` (N = 1) -- rank 0's share of the 8-rank window-sharded split replayed on one GPU (no collective)
-                       and the strong-scaling efficiency it projects;
+  * `shard_proxy_2 / _4 / _8` (N = 1) -- rank 0's share of the 2 / 4 / 8-rank window-sharded split replayed on one GPU (no
+                       collective) and the strong-scaling efficiency it projects;
   * `ms_per_step_dead_work_elided` -- the headline step WITHOUT the saliency head and the intermediate decoder layer's heads
                        (the headline computes both, as the reference's CONE.forward does -- and never reads them);
   * `config2_ragged` (N = 1) -- the headline workload on a ragged split (ctx_l ~ U[200, 1500)): per-window cost against the
@@ -556,16 +559,17 @@ def bench_config2_ragged(model, opt, queries, videos, us_per_window_dense, steps
 
 def bench_shard_proxy(model, store, opt, ms_1gpu, steps=5, warmup=2, world=8):
     """ONE GPU's share of BASELINE configs[3] at `world` ranks, measured on this GPU without a process group: what rank 0
-    of predict_split_distributed(mode="window") executes -- replicated stage A, project + window model + matching on its
-    1 / world slice of the window list, fusion + NMS over ALL queries (on a gather buffer filled with copies of the local
-    rows), the JSON rows of its own query shard.  projected_efficiency = ms_per_step(1 GPU) / (world x proxy ms): the
-    strong-scaling efficiency an 8-GPU run would show if the one 1.6 MB all_gather were free (it is latency-bound: one
-    hop to each peer over xGMI)."""
+    of predict_split_distributed_async(mode="window") executes -- stage A of its batch-aligned query hull, project + window
+    model + matching on its 1 / world slice of the window list, fusion + NMS over ALL queries (on a gather buffer filled with
+    copies of the local rows), the JSON rows of its own query shard -- stepped like the N > 1 headline (one step in flight).
+    projected_efficiency = ms_per_step(1 GPU) / (world x proxy ms): the strong-scaling efficiency a `world`-GPU run would show
+    if the one 1.6 MB all_gather were free (it is latency-bound: one hop to each peer over xGMI)."""
     from cone_amd import parallel as par
-    fn = lambda: par.predict_split_distributed(model, store, opt, mode="window", format_shard=True, virtual=(0, world))
-    dt, (_, info) = _timed(fn, steps, warmup)
+    fn = lambda: par.predict_split_distributed_async(model, store, opt, mode="window", format_shard=True, virtual=(0, world))
+    dt, (_, info) = _timed_in_flight(fn, steps, warmup)
     lo, hi = par.shard_range(info["n_windows"], 0, world)
-    return {"what": f"rank 0 of {world} of the window-sharded split (BASELINE configs[3]) replayed on one GPU, no collective",
+    return {"what": f"rank 0 of {world} of the window-sharded split (BASELINE configs[3]) replayed on one GPU, no collective, "
+                    "one step in flight (the N > 1 headline's stepping)",
             "world": world, "windows_of_rank": hi - lo, "queries_formatted": info["shard"][1] - info["shard"][0],
             "proxy_ms": round(dt * 1e3, 3), "ms_per_step_1gpu": round(ms_1gpu, 3),
             "projected_speedup": round(ms_1gpu / (dt * 1e3), 2),
@@ -641,16 +645,13 @@ def self_launch(n_gpus):
     """`python3 bench.py --gpus N` with N > 1 and no RANK in the environment: this process touches no GPU -- it starts
     `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (never an exec),
     relays the child's stdout (rank 0's one JSON line) and stderr, and exits with its return code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous picks a free port itself (no bind-then-close race with another process)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n_gpus), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -774,8 +775,13 @@ def main():
     sd = synth.make_state_dict(opt, 0)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    ann, vf, qf = synth.make_dataset(opt, args.queries, args.videos, seed=rank)
+    multi = use_dist and world > 1
+    # N > 1: the headline is BASELINE configs[3] -- ONE such split (the same on every rank: features replicated), sharded by
+    # window over the ranks.  Total work is fixed as N grows: strong scaling.  (N = 1: the same split on one GPU.)
+    ann, vf, qf = synth.make_dataset(opt, args.queries, args.videos, seed=0)
     store = inf.FeatureStore(opt, ann, vf, qf)          # features resident in HBM from here on
+    if multi:
+        from cone_amd import parallel as par
     lib = _lib.load()
     for kv in args.set_option:
         name, _, val = kv.partition("=")
@@ -788,24 +794,21 @@ def main():
         out, dp = h.result()                # waits for the kept rows in pinned memory, builds the submission lists
         last[0] = ([out], dp)
 
+    def start_headline():
+        # the product's own drivers: stages A->C + the submission rows, device half enqueued, host half handed back.
+        # N = 1: cone_amd.inference.predict_split_async; N > 1: cone_amd.parallel.predict_split_distributed_async -- the split
+        # sharded by window, ONE RCCL all_gather of the per-window proposal rows (enqueued on the stream like a kernel), fusion
+        # + NMS of all queries on every rank, the JSON rows of its own query shard on every rank
+        if multi:
+            return par.predict_split_distributed_async(model, store, opt, mode="window", format_shard=True)
+        return inf.predict_split_async(model, store, opt)
+
+    start = [start_headline]
+
     def step():
-        # the product's own driver (cone_amd.inference.predict_split_async / PendingSplit.result): stages A->C + the submission
-        # rows.  --steps_in_flight 2 (default): the GPU half of step i + 1 is enqueued before the host half of step i runs (the
-        # product's eval loop does the same across splits); 1: predict_split, one step at a time
-        h = inf.predict_split_async(model, store, opt)
-        dp = h.info
-        if use_dist:    # the one exchange step: kept rows of every shard on every rank (all_gather over RCCL,
-            # 1.2 MB per rank) -- rank 0 ends the step holding the whole result set as tensors; every rank has
-            # built the submission rows of ITS OWN shard (the host work shards with the queries)
-            rows, n = dp["rows"], dp["n"]
-            # output shaped (world * dim0, ...): the concatenation form every backend accepts
-            rows_all = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-            n_all = torch.empty((world * n.shape[0],) + tuple(n.shape[1:]), dtype=n.dtype, device=n.device)
-            dist.all_gather_into_tensor(rows_all, rows.contiguous())
-            dist.all_gather_into_tensor(n_all, n.contiguous())
-            dp["rows_all"] = rows_all.view((world,) + tuple(rows.shape))
-            dp["n_all"] = n_all.view((world,) + tuple(n.shape))
-        inflight.append(h)
+        # --steps_in_flight 2 (default): the GPU half of step i + 1 is enqueued before the host half of step i runs (the
+        # product's eval loop does the same across splits); 1: one step at a time
+        inflight.append(start[0]())
         while len(inflight) >= max(1, args.steps_in_flight):
             finish_oldest()
         return last[0]
@@ -852,19 +855,22 @@ def main():
         roof, kern = roofline_from_profile(rec)
         res = {
             "metric": "windows/sec + queries/sec, Ego4D-NLQ win_len=90 d=256 top-k=20",
-            "value": round(world * n_windows * args.steps / dt, 1),
+            "value": round(n_windows * args.steps / dt, 1),          # ONE split per step, whatever N: whole-job windows / s
             "unit": "windows/s",
-            "queries_per_s": round(world * args.queries * args.steps / dt, 1),
+            "queries_per_s": round(args.queries * args.steps / dt, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "ranks_seen": dist.get_world_size() if use_dist else 1,
             "ms_per_step_rank_max": round(max(timed_region.per_rank) / args.steps * 1e3, 3),
             "ms_per_step_rank_min": round(min(timed_region.per_rank) / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic, "
-                                   f"{args.queries} queries x {args.videos} videos per GPU, window_len=90, d=256, "
-                                   f"topk_window=20, NMS 0.5, {n_windows} windows per GPU per step",
+            "config": {"workload": (f"BASELINE.json configs[3]: ONE Ego4D-NLQ val-scale synthetic split sharded by window over "
+                                    f"{world} GPUs (one RCCL all_gather of the per-window proposal rows before the global NMS), "
+                                    if multi else "BASELINE.json configs[1]: Ego4D-NLQ val-scale synthetic, ")
+                                   + f"{args.queries} queries x {args.videos} videos, window_len=90, d=256, "
+                                   f"topk_window=20, NMS 0.5, {n_windows} windows per step",
+                       "collectives_per_step": 1 if multi else 0,
                        "window_batch": args.window_batch, "weights": "random-init (seed 0), reference architecture",
                        "steps_in_flight": max(1, args.steps_in_flight),
                        "query_chunks": [list(c) for c in dp.get("chunks", [(0, args.queries)])],
@@ -881,12 +887,17 @@ def main():
         if use_dist:
             res["collective_preflight"] = preflight
         wt = dp.get("windows")
+        if wt is None and multi:    # the sharded driver tabulates a rank's own windows only: the split's lengths, untimed
+            wt = inf.window_table(store, opt, inf.prefilter(model, store, opt))
         if wt is not None:      # SURVEY 8d's pipeline-level figure: the reference's algorithmic FLOPs / wall time
             fl = reference_window_flops(wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(),
                                         opt.v_appear_feat_dim, opt.t_feat_dim)
-            tf = world * float(fl.sum()) * args.steps / dt / 1e12
+            tf = float(fl.sum()) * args.steps / dt / 1e12           # ONE split per step
             ex = executed_mfma_flops(rec, wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy(), opt, args.steps)
-            etf = world * ex["total"] / dt / 1e12
+            if multi:           # the launch records are rank 0's (1 / world of the split's rows); the attention terms are
+                ex["dense_layers"] *= world                          # computed from the whole split's window lengths
+                ex["total"] = ex["dense_layers"] + ex["encoder_attention"] + ex["decoder_cross_attention"]
+            etf = ex["total"] / dt / 1e12
             res["window_model"] = {"reference_mflop_per_window": round(float(fl.mean()) / 1e6, 1),
                                    "reference_algorithmic_tflops": round(tf, 1),
                                    "reference_equivalent_frac": round(tf / (world * FP32_MFMA_PEAK_TFLOPS), 4),
@@ -951,7 +962,7 @@ def main():
                 args.steps_in_flight = keep
             serial_ms[0] = sdt1 / args.steps * 1e3
             note("ms_per_step_one_at_a_time", round(sdt1 / args.steps * 1e3, 2))
-            note("value_one_at_a_time", round(world * sdp1["n_windows"] * args.steps / sdt1, 1))
+            note("value_one_at_a_time", round(sdp1["n_windows"] * args.steps / sdt1, 1))
         guarded("one_at_a_time_error", serial)
 
     # ---- the eval pipeline's own default (cone_amd.inference): the outputs cone/inference.py never reads are not computed
@@ -963,7 +974,7 @@ def main():
             finally:
                 opt.need_saliency = opt.need_aux = True
             note("ms_per_step_dead_work_elided", round(fdt / args.steps * 1e3, 2))
-            note("value_dead_work_elided", round(world * fdp["n_windows"] * args.steps / fdt, 1))
+            note("value_dead_work_elided", round(fdp["n_windows"] * args.steps / fdt, 1))
         guarded("dead_work_elided_error", elided)
 
     if world == 1 and not args.no_extras and not any(kv.startswith("split_bf16") for kv in args.set_option):
@@ -1001,27 +1012,35 @@ def main():
                 model.set_option("split_bf16", 0)
         guarded("split_bf16x3", split_path)
 
-    if use_dist and world > 1:
-        # BASELINE configs[3]: ONE config-2 split (the same on every rank: features replicated), sharded by window
-        from cone_amd import parallel as par
-        ann0, vf0, qf0 = (ann, vf, qf) if rank == 0 else synth.make_dataset(opt, args.queries, args.videos, seed=0)
-        store0 = store if rank == 0 else inf.FeatureStore(opt, ann0, vf0, qf0)
+    if multi:
+        # the EASY curve beside the headline: every rank its own split of that size (seed = rank), the kept rows of all shards
+        # all-gathered over RCCL -- per-GPU work fixed as N grows (weak scaling)
+        def weak():
+            annr, vfr, qfr = synth.make_dataset(opt, args.queries, args.videos, seed=rank)
+            store_r = inf.FeatureStore(opt, annr, vfr, qfr)
 
-        def strong_step():
-            return par.predict_split_distributed(model, store0, opt, mode="window", format_shard=True)
-
-        def strong():
-            sdt, _, (_, sinfo) = timed_region(strong_step)
-            return {
-                "config": "BASELINE.json configs[3]: ONE Ego4D-NLQ val-scale split sharded by window over the ranks, "
-                          "one RCCL all_gather of the per-window proposal rows, fusion + NMS of all queries on every "
-                          "rank, JSON rows of its own query shard on every rank",
-                "scaling": "strong", "value": round(sinfo["n_windows"] * args.steps / sdt, 1), "unit": "windows/s",
-                "queries_per_s": round(args.queries * args.steps / sdt, 1),
-                "ms_per_step": round(sdt / args.steps * 1e3, 2), "n_windows": sinfo["n_windows"],
-                "ranks_seen": dist.get_world_size(), "collectives_per_step": 1}
-        guarded("strong_scaling", strong)
-        del store0
+            def start_weak():
+                h = inf.predict_split_async(model, store_r, opt)
+                dpw = h.info
+                rows, n = dpw["rows"], dpw["n"]
+                rows_all = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+                n_all = torch.empty((world * n.shape[0],) + tuple(n.shape[1:]), dtype=n.dtype, device=n.device)
+                dist.all_gather_into_tensor(rows_all, rows.contiguous())
+                dist.all_gather_into_tensor(n_all, n.contiguous())
+                dpw["rows_all"], dpw["n_all"] = rows_all, n_all
+                return h
+            start[0] = start_weak
+            try:
+                wdt, _, (_, wdp) = timed_region(step)
+            finally:
+                start[0] = start_headline
+            return {"config": "BASELINE.json configs[1] on every rank (its own split, seed = rank), kept rows of all shards "
+                              "all-gathered: per-GPU work fixed as N grows",
+                    "scaling": "weak", "value": round(world * wdp["n_windows"] * args.steps / wdt, 1), "unit": "windows/s",
+                    "queries_per_s": round(world * args.queries * args.steps / wdt, 1),
+                    "ms_per_step": round(wdt / args.steps * 1e3, 2), "ranks_seen": dist.get_world_size(),
+                    "collectives_per_step": 2}
+        guarded("weak_scaling", weak)
         if not args.no_extras:
             # the other multi-GPU configs of BASELINE.json, as stated (collectives inside: every rank runs them)
             guarded("config5_sharded", lambda: bench_config5_sharded(dist, world, timed_region))
@@ -1044,7 +1063,8 @@ def main():
         guarded("hip_graph", dense_graph)
         guarded("dropin_forward", lambda: bench_dropin_forward(
             model, store, opt, (res or {}).get("window_model", {}).get("executed_tflops")))
-        guarded("shard_proxy_8", lambda: bench_shard_proxy(model, store, opt, serial_ms[0]))
+        for w_ in (2, 4, 8):
+            guarded(f"shard_proxy_{w_}", lambda w_=w_: bench_shard_proxy(model, store, opt, dt / args.steps * 1e3, world=w_))
         guarded("config2_ragged", lambda: bench_config2_ragged(model, opt, args.queries, args.videos,
                                                                dt / args.steps * 1e6 / n_windows, steps=args.steps))
         del store, dp, out

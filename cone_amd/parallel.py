@@ -342,17 +342,52 @@ def _window_sharded(store, opt, hooks, group, virtual, format_shard):
     rows, n = hooks.fuse_nms(cand, n_valid, opt, cand_off, n_max)   # every rank, all queries: cheaper than a second collective
     q_lo, q_hi = shard_range(nq, rank, world)
     info = dict(rows=rows, n=n, win_idx=win_hull, win_idx_range=hull, n_windows=n_win, shard=(q_lo, q_hi), world=world)
+    return _pending(store, opt, rows, n, rank, format_shard, info)
+
+
+def _pending(store, opt, rows, n, rank, format_shard, info):
+    """The host half of a distributed step as a ``PendingSplit``: everything the GPU does -- the collective included -- is
+    enqueued when this returns (RCCL collectives are stream-ordered: the host does not wait for them); the rows this rank
+    formats (its own query shard, or everything on rank 0) are on their way to pinned host memory behind an event, and
+    ``result()`` waits for that event only, then builds the submission lists."""
+    from . import inference as inf
+    q_lo, q_hi = info["shard"]
     if format_shard:
-        return inf.format_results(store.ann[q_lo:q_hi], opt, rows[:, q_lo:q_hi], n[:, q_lo:q_hi]), info
-    if rank != 0:
-        return None, info
-    return inf.format_results(store.ann, opt, rows, n), info
+        ann, r, c = store.ann[q_lo:q_hi], rows[:, q_lo:q_hi], n[:, q_lo:q_hi]
+    elif rank == 0:
+        ann, r, c = store.ann, rows, n
+    else:
+        return inf.PendingSplit(info, lambda: (None, info))
+    ev = None
+    if r.is_cuda:
+        r, c = inf._to_pinned(r), inf._to_pinned(c)
+        ev = torch.cuda.Event()
+        ev.record()
+
+    def finish():
+        skel = inf.result_skeletons(ann, opt)          # host work that needs no result: under the GPU's time
+        if ev is not None:
+            ev.synchronize()
+        return inf.format_results(ann, opt, r, c, skel), info
+    return inf.PendingSplit(info, finish)
+
+
+def predict_split_distributed(model, store, opt, mode: str = "window", group=None, hooks=None,
+                              format_shard: bool = False, prefilter: str = "replicated", virtual=None):
+    """``predict_split_distributed_async(...).result()``: one step at a time."""
+    return predict_split_distributed_async(model, store, opt, mode, group, hooks, format_shard, prefilter, virtual).result()
 
 
 @torch.no_grad()
-def predict_split_distributed(model, store, opt, mode: str = "window", group=None, hooks=None,
-                              format_shard: bool = False, prefilter: str = "replicated", virtual=None):
-    """Stages A->C across the ranks of `group`.  Every rank holds the same FeatureStore (features replicated:
+def predict_split_distributed_async(model, store, opt, mode: str = "window", group=None, hooks=None,
+                                    format_shard: bool = False, prefilter: str = "replicated", virtual=None):
+    """Stages A->C across the ranks of `group`, in two halves like ``inference.predict_split_async``: the device half --
+    the rank's share of stages A / B, the collective(s), fusion + NMS -- is enqueued here and nothing waits for it; the host
+    half (wait for the kept rows this rank formats, build its submission lists) runs in ``PendingSplit.result()``.  A caller
+    that evaluates step after step keeps one in flight: the lists of step i are built while the GPU runs step i + 1 (every
+    rank issues its collectives in the same order, so steps in flight cannot cross).
+
+    Every rank holds the same FeatureStore (features replicated:
     an Ego4D split is < 1 GB, the MAD-scale stress video 12.7 GB of the 288 GB per GPU).
 
     ``prefilter="replicated"``: stage A runs on every rank (HBM-bound and cheap for a split of short videos);
@@ -371,14 +406,15 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     Returns ``(lists, info)``: ``info['rows'] / info['n']`` = the kept rows of ALL queries, on every rank (tensors);
     ``lists`` = the three submission lists -- of all queries on rank 0 and ``None`` elsewhere, or, with
     ``format_shard=True``, of the rank's own query shard ``info['shard']`` on every rank (the host formatting
-    shards with the queries; a caller that wants one file concatenates the shards in rank order)."""
+    shards with the queries; a caller that wants one file concatenates the shards in rank order).  (Both through
+    ``.result()`` of the returned PendingSplit; ``.info`` is valid at once, stream-ordered.)"""
     from . import inference as inf
     hooks = hooks or HipHooks(model)
     rank, world = _rank_world(group, virtual)
     nq = len(store.ann)
     Nq = hooks.num_queries
     if mode == "window" and prefilter == "replicated":
-        return _window_sharded(store, opt, hooks, group, virtual, format_shard)
+        return _window_sharded(store, opt, hooks, group, virtual, format_shard)      # a PendingSplit
     if prefilter == "ctx":
         if virtual is not None:
             raise ValueError("virtual ranks replay the replicated pre-filter only")
@@ -427,11 +463,7 @@ def predict_split_distributed(model, store, opt, mode: str = "window", group=Non
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
     info = dict(rows=rows, n=n, win_idx=win_idx, n_windows=n_windows, shard=(q_lo, q_hi), world=world)
-    if format_shard:
-        return inf.format_results(store.ann[q_lo:q_hi], opt, rows[:, q_lo:q_hi], n[:, q_lo:q_hi]), info
-    if rank != 0:
-        return None, info
-    return inf.format_results(store.ann, opt, rows, n), info
+    return _pending(store, opt, rows, n, rank, format_shard, info)
 
 
 def _video_row_range(store, q_lo, q_hi):

@@ -223,6 +223,61 @@ def test_gloo_window_and_query_sharded_drivers(world):
     assert out.get(timeout=5) == "ok"
 
 
+def _wide_worker(rank, world, port, out):
+    """World 4 / 8 on ONE ragged split (videos of 1 .. 5 windows, fewer than top-k for most; shard cuts inside reference
+    batches and inside queries; ranks that own a handful of windows): the window-sharded driver's hull / cut arithmetic,
+    through the ASYNC entry with two steps in flight."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)            # up to 8 ranks on the container's 8 cores
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cone_amd import inference as inf
+        opt = make_opt("ego4d", nms_thd=0.5, topk_window=4, eval_bsz=3, max_after_nms=5, eval_split_name="test")
+        sd = synth.make_state_dict(opt, 0)
+        ann, vf, qf = synth.make_dataset(opt, 11, 4, seed=6, ctx_range=(10, 200))
+        store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+        sel = inf.selection(store, opt)
+        assert not sel.dense and sel.n_rows >= world            # ragged, and every rank owns at least one window
+        hooks = CheckerHooks(opt, sd, ann, vf, qf, store)       # checks every window-table row it is asked for (H3 padding too)
+        (fo, po, mo), _, _ = O.eval_epoch(sd, opt, ann, vf, qf)
+        h1 = par.predict_split_distributed_async(None, store, opt, mode="window", hooks=hooks, format_shard=True)
+        served1 = hooks.served
+        h2 = par.predict_split_distributed_async(None, store, opt, mode="window", hooks=hooks)      # second step enqueued first
+        for h, shard_only in ((h1, True), (h2, False)):
+            lists, info = h.result()
+            assert info["world"] == world and info["n_windows"] == sel.n_rows
+            for t, ref in enumerate((fo, po, mo)):              # every rank holds every query's kept rows
+                for qi in range(len(ann)):
+                    assert info["rows"][t, qi, :int(info["n"][t, qi])].tolist() == ref[qi]["predicted_times"], (t, qi)
+            lo, hi = info["shard"]
+            if shard_only:
+                assert lists == tuple(x[lo:hi] for x in (fo, po, mo))
+            else:
+                assert (lists == (fo, po, mo)) if rank == 0 else (lists is None)
+            ha, hb = info["win_idx_range"]                      # stage A ran on the batch-aligned hull of the rank's queries
+            assert ha % opt.eval_bsz == 0 and (hb % opt.eval_bsz == 0 or hb == len(ann)) and hb - ha <= len(ann)
+        wlo, whi = par.shard_range(sel.n_rows, rank, world)
+        assert served1 == whi - wlo                             # the window model ran on the rank's slice, nothing more
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_gloo_window_sharded_async_driver_wide_worlds(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=400)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get(timeout=5) == "ok"
+
+
 # ---------------------------------------------------------------------------- ctx-sharded pre-filter
 def _cpu_window_scores(v, c, W):
     return torch.stack([O.window_scores(O.frame_scores(v, c[q]), W) for q in range(c.shape[0])])
