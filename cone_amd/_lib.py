@@ -102,7 +102,8 @@ _SIGNATURES = {
                                       C.POINTER(Taps), C.POINTER(Layer0), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_pos_table_rows": (C.c_int64, [C.c_int]),
     "cone_pos_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "cone_layer0_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cone_layer0_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "cone_layer0_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cone_clip_matching_workspace": (C.c_size_t, [C.c_void_p, C.c_int]),
     "cone_clip_matching_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

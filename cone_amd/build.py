@@ -68,6 +68,11 @@ def build(force: bool = False) -> str:
     try:
         build_pylists()
     except (RuntimeError, OSError) as e:    # no gcc / no Python.h on the box: the HIP library is complete without it,
+        try:                                # a helper built from an OLDER pylists.c must not be picked up in its place
+            if os.path.exists(PYLISTS) and os.path.getmtime(PYLISTS) < os.path.getmtime(os.path.join(CSRC, "pylists.c")):
+                os.remove(PYLISTS)
+        except OSError:
+            pass
         sys.stderr.write(f"cone_amd.build: _cone_pylists.so not built ({str(e).splitlines()[0]}); "      # the host falls
                          "submission lists will be built by the Python loop\n")                         # back (slower)
     return LIB

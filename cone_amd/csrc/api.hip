@@ -372,6 +372,17 @@ static int build_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, f
     return 0;
 }
 
+// First encoder layer's in_proj hoisted out of the window loop: q | k | v = in_proj(x) once per projected clip / text token
+// (post-norm, cone/transformer.py:237-239), resp. in_proj(norm1(x)) (--pre_norm, :250-252; tmp = n rows of scratch).
+static int layer0_rows(const cone_model* m, const float* rows, int n, const int* n_dev, float* qkv, float* tmp, hipStream_t s) {
+    const float* a = rows;
+    if (m->pre_norm) {
+        RUN(launch_layernorm(rows, 256, m->enc[0].n1.g, m->enc[0].n1.b, tmp, 256, n, n_dev, 256, s));
+        a = tmp;
+    }
+    return launch_gemm(G(m, a, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, qkv, 768, n, n_dev, 768, 256), s);
+}
+
 // input_{vid,txt}_proj: LN -> Linear -> ReLU (all but last) with the next LN fused into the GEMM epilogue.
 static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
     const size_t din = which == 0 ? m->dv : m->dt;
@@ -414,7 +425,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 //   legacy path (no cache: cone_forward_windows, and the A/B switches of the parity tests): additionally POS and
 //     XP = X + POS, and the stacked decoder K / V rows when the cross-attention fold is off.
 struct FwdBuffers {
-    int* off;
+    int* off; int* RIDX;
     float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
     float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS;
 };
@@ -423,7 +434,7 @@ struct FwdPlan { bool tables, fold; };
 // NULL cone_layer0, or one with the row caches only, still takes the table path), or nothing for --use_txt_pos / --pre_norm
 // (the general path: the caches / tables assume a zero text position term and the post-norm layer order).
 static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff) {
-    if (m->txt_pos_emb || m->pre_norm) return nullptr;
+    if (m->txt_pos_emb) return nullptr;
     *eff = l0 ? *l0 : cone_layer0{};
     if (!eff->qkv_vid || !eff->qkv_txt) eff->qkv_vid = eff->qkv_txt = nullptr;
     if (!eff->pos_rows || !eff->pos_qk) {
@@ -436,7 +447,14 @@ static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l
     FwdPlan p;
     const bool caches = l0 && l0->qkv_vid;
     p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && (!caches || m->opt_l0_gather);
-    p.fold = m->opt_dec_fold && dec_cross_supported(m->nq, Lmax) && !m->pre_norm;
+    p.fold = m->opt_dec_fold >= 2 ? dec_cross_mfma_supported(m->nq, Lmax, p.tables)
+                                  : (m->opt_dec_fold == 1 && dec_cross_supported(m->nq, Lmax));
+    if (m->pre_norm) {  // the fused pre-norm path needs all of: tables, the fused layer tail, the matrix-core fold; else the
+                        // general pre-norm path (plain LayerNorm / GEMM / attention launches)
+        const bool fused = p.tables && p.fold && m->opt_dec_fold >= 2 && m->opt_ffn_fused >= 2 && ffn_fused_supported(m->ff);
+        p.tables = p.fold = fused;
+        return p;
+    }
     // the unfolded decoder projects its keys from memory + pos rows: on the table path that matrix is written once behind the
     // encoder (launch_add_pos_rows) -- slot counts other than 5 keep the encoder's fast path.  The fold switched off BY OPTION
     // (parity tests) keeps meaning the whole general path
@@ -447,6 +465,7 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
     const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
     const size_t wide = m->ff > 1024 ? m->ff : 1024;
     f.off = c.take<int>(B + 1);
+    f.RIDX = m->pre_norm ? c.take<int>(M) : nullptr;    // (post-norm keeps the row index in the X1 region, unused on that path)
     f.X = c.take<float>(M * 256); f.X1 = c.take<float>(M * 256);
     f.H = c.take<float>(M * wide);
     f.QKV = f.H; f.ATT = f.H + M * 768;            // aliases of the FFN hidden region (see above)
@@ -562,6 +581,93 @@ static int forward_packed_prenorm(const cone_model* m, const float* vproj, const
     return 0;
 }
 
+// --pre_norm on the table path (ABI 6): the same launches as the post-norm step -- position tables, ONE N = 768 GEMM per
+// encoder layer, the fused layer tail in its pre-norm form (attention out_proj + residual, norm ahead of the feed-forward
+// block, the block, residual; the NEXT consumer's LayerNorm -- the next layer's norm1, the encoder's / decoder's final norm --
+// written as a second output), the folded decoder cross-attention.  What it does not have: the first layer's row caches (its
+// in_proj reads norm1(x)) and the first decoder layer's constants.
+static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
+                                        const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
+                                        float* logits, float* spans, float* saliency, const cone_taps* taps, FwdBuffers& f,
+                                        hipStream_t s, const cone_layer0* l0) {
+    const int Lmax = Lv_max + Lq_max, Mmax = B * Lmax, T = B * m->nq, nd = m->n_dec, ff = m->ff;
+    const int* Mdev = f.off + B;
+    const size_t pos_rows_n = (size_t)cone_pos_table_rows(l0->max_v_l);
+    RUN(launch_scan_lengths(vlen, qlen, B, f.off, s));
+    // with the row caches (q | k | v = in_proj(norm1(row)) once per clip / token: layer0_rows) the first layer is a pure gather:
+    // its attention reads the caches, its tail gathers the residual rows through a row index -- as on the post-norm path
+    const bool caches = l0->qkv_vid && m->opt_l0_gather && m->opt_res_gather;
+    float* Z = f.X1;                                                                                 // the normalised rows
+    if (caches) {
+        RUN(launch_row_index(vrow0, vlen, trow0, qlen, f.off, f.RIDX, B, Lmax, s));
+    } else {
+        RUN(launch_pack_l0(vproj, vrow0, vlen, tproj, trow0, qlen, f.off, m->dim_t, nullptr, nullptr, nullptr, f.X, nullptr,
+                           nullptr, nullptr, B, Lmax, s));                                           // the residual stream
+        RUN(launch_layernorm(f.X, 256, m->enc[0].n1.g, m->enc[0].n1.b, Z, 256, Mmax, Mdev, 256, s)); // norm1 of layer 0
+    }
+    for (int l = 0; l < m->n_enc; ++l) {    // cone/transformer.py:248-260
+        const EncLayer& e = m->enc[l];
+        const bool g0 = l == 0 && caches;
+        AttnSrc src{};
+        src.vlen = vlen; src.pos_zero_row = (int)pos_rows_n - 1;
+        src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512;
+        if (g0) {
+            src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.vrow0 = vrow0; src.trow0 = trow0;
+        } else {
+            RUN(launch_gemm(G(m, Z, 256, e.sa.in_w, 256, e.sa.in_b, f.QKV, 768, Mmax, Mdev, 768, 256), s));   // q | k | v of src2
+            src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + 512; src.ldq = src.ldk = src.ldv = 768;
+        }
+        RUN(launch_enc_attn(g0 ? ATTN_GATHER : ATTN_POSADD, src, f.ATT, f.off, B, Lmax, s));
+        const LNorm& nxt = l + 1 < m->n_enc ? m->enc[l + 1].n1 : m->enc_norm;
+        RUN(launch_proj_ffn_prenorm(f.ATT, 256, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, 256, e.n2.g, e.n2.b, e.l1.w, e.l1.b,
+                                    e.l2.w, e.l2.b, f.X, 256, nxt.g, nxt.b, Z, 256, Mmax, Mdev, ff, s,
+                                    g0 ? f.RIDX : nullptr, g0 ? tproj : nullptr));
+    }
+    const float* MEM = Z;                                                                            // encoder.norm(src)
+    CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));                    // tgt = 0 (:66)
+    GemmArgs g;
+    for (int l = 0; l < nd; ++l) {          // cone/transformer.py:319-342
+        const DecLayer& dl = m->dec[l];
+        RUN(launch_layernorm(f.TGT, 256, dl.n1.g, dl.n1.b, f.TGT1, 256, T, nullptr, 256, s));
+        g = G(m, f.TGT1, 256, dl.sa.in_w, 256, nullptr, f.DQK, 768, T, nullptr, 768, 256, EPI_RESIDUAL);
+        g.R = m->dec_sa_tab[l]; g.ldr = 768; g.r_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_small_attn(f.DQK, 768, f.DQK + 256, 768, f.DQK + 512, 768, f.DATT, 256, nullptr, B, m->nq, m->nq, s));
+        g = G(m, f.DATT, 256, dl.sa.out.w, 256, dl.sa.out.b, f.TGT, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+        g.R = f.TGT; g.ldr = 256;
+        RUN(launch_gemm(g, s));
+        RUN(launch_layernorm(f.TGT, 256, dl.n2.g, dl.n2.b, f.TGT1, 256, T, nullptr, 256, s));
+        g = G(m, f.TGT1, 256, dl.ca.in_w, 256, nullptr, f.DQ, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
+        g.R = m->dec_ca_tab[l]; g.ldr = 256; g.r_mod = m->nq;
+        RUN(launch_gemm(g, s));
+        RUN(launch_dec_cross_mfma(f.DQ, nullptr, MEM, l0->pos_rows, vlen, f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l],
+                                  dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, nullptr, s, 3));
+        RUN(launch_proj_ffn_prenorm(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT, 256, dl.n3.g, dl.n3.b, dl.l1.w, dl.l1.b, dl.l2.w,
+                                    dl.l2.b, f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
+                                    ff, s));
+    }
+    const int HT = nd * T;
+    RUN(launch_rowdot(f.HS, 256, m->class_embed.w, m->class_embed.b, f.LG, 2, HT, 2, 0, s));
+    RUN(launch_gemm(G(m, f.HS, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, f.SP, 2, HT, 2, 1, s));
+    const size_t last = (size_t)(nd - 1) * T * 2;
+    CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CONE_CHECK_HIP(hipMemcpyAsync(spans, f.SP + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (taps) {
+        if (taps->hs)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->hs, f.HS, (size_t)nd * T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_logits && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_logits, f.LG, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (taps->aux_spans && nd > 1)
+            CONE_CHECK_HIP(hipMemcpyAsync(taps->aux_spans, f.SP, last * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (saliency || (taps && taps->memory))
+        RUN(launch_saliency(MEM, f.off, vlen, qlen, m->saliency.w, m->saliency.b, saliency, Lv_max,
+                            taps ? taps->memory : nullptr, Lq_max, B, s));
+    return 0;
+}
+
 static int forward_packed(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
                           const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
                           float* logits, float* spans, float* saliency, const cone_taps* taps, void* ws,
@@ -584,6 +690,9 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     FwdBuffers f;
     carve_fwd(m, c, B, Lmax, plan, f);
     if (!c.ok) { set_error("forward: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
+    if (m->pre_norm && plan.tables)
+        return forward_packed_prenorm_fused(m, vproj, vrow0, vlen, tproj, trow0, qlen, B, Lv_max, Lq_max, logits, spans, saliency,
+                                            taps, f, s, l0);
     if (m->pre_norm)
         return forward_packed_prenorm(m, vproj, vrow0, vlen, tproj, trow0, qlen, B, Lv_max, Lq_max, logits, spans, saliency, taps,
                                       f, s);
@@ -899,12 +1008,15 @@ extern "C" int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows
     return build_pos_tables(m, max_v_l, pos_rows, pos_qk, (hipStream_t)stream);
 }
 
-extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv,
-                                   void* stream) {
+extern "C" size_t cone_layer0_project_workspace(const cone_model* m, int64_t n_rows) {
+    return m && m->pre_norm ? align_up((size_t)n_rows * 256 * 4, 256) : 0;
+}
+extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* ws,
+                                   size_t ws_bytes, void* stream) {
     CONE_REQUIRE(m && proj_rows && qkv && n_rows < (1ll << 31), "layer0_project: bad argument");
     if (n_rows <= 0) return 0;
-    return launch_gemm(G(m, proj_rows, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, qkv, 768, (int)n_rows, nullptr,
-                         768, 256), (hipStream_t)stream);
+    CONE_REQUIRE(ws_bytes >= cone_layer0_project_workspace(m, n_rows) && (ws || !m->pre_norm), "layer0_project: workspace too small");
+    return layer0_rows(m, proj_rows, (int)n_rows, nullptr, qkv, (float*)ws, (hipStream_t)stream);
 }
 
 // The padded entry.  A zero-padded batch is first COMPACTED: the valid clip rows and the valid token rows are gathered by the
@@ -967,8 +1079,8 @@ extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const
     RUN(project_tokens(m, 1, txt, nt, p.tp, p.pws, p.pw, s, p.tidx, p.toff + B));
     cone_layer0 l0{};
     if (caches) {   // the first encoder layer's in_proj once per compact row (cone_layer0_project's kernel)
-        RUN(launch_gemm(G(m, p.vp, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, p.qv, 768, (int)nv, p.voff + B, 768, 256), s));
-        RUN(launch_gemm(G(m, p.tp, 256, m->enc[0].sa.in_w, 256, m->enc[0].sa.in_b, p.qt, 768, (int)nt, p.toff + B, 768, 256), s));
+        RUN(layer0_rows(m, p.vp, (int)nv, p.voff + B, p.qv, (float*)p.pws, s));     // (scratch: the projections are done with it)
+        RUN(layer0_rows(m, p.tp, (int)nt, p.toff + B, p.qt, (float*)p.pws, s));
         l0.qkv_vid = p.qv; l0.qkv_txt = p.qt;
     }
     return forward_packed(m, p.vp, p.voff, vid_len, p.tp, p.toff, txt_len, B, Lv_pad, Lq_pad, logits, spans, saliency,

@@ -144,6 +144,12 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
                           const int* M_dev, int ff, hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr,
                           const float* Wq = nullptr, const float* qb = nullptr, float* QKV = nullptr, int ldq = 0,
                           int n_qkv = 0);
+int launch_proj_ffn_prenorm(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                            const float* pb, const float* W1, const float* b1, const float* W2, const float* b2, float* OUT,
+                            int ldo, const float* n2g, const float* n2b, float* OUT2, int ldo2, int M, const int* M_dev, int ff,
+                            hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
+// pre-norm form of the layer tail: OUT = x1 + FFN(LayerNorm(x1; pg, pb)), x1 = R + A Wo^T + bo (un-normalised stream);
+// OUT2 (may be null) = LayerNorm(OUT; n2g, n2b)
 // Wq != null: the kernel also writes QKV (M, n_qkv) = OUT Wq^T + qb (the next layer's q | k | v projection) from the
 // registers that hold OUT
 bool ffn_fused_qkv_fits(int ff, int n_qkv);
@@ -227,6 +233,7 @@ int launch_dec_cross(const float* DQ, const float* XP, const float* X, const flo
 // qk_slabs (dec_cross_mfma_slab_floats() floats of scratch, or null): the queries are the same rows for every window
 // (first decoder layer): the folded-key operand is built once instead of per window
 size_t dec_cross_mfma_slab_floats();
+bool dec_cross_mfma_supported(int nq, int Lmax, bool table);     // slot counts 3 / 8 / 10 as well (table form)
 // form 2 (default): windows of at most 128 tokens run dec_cross_x_kernel (rows read ONCE: the registers of stage A transposed
 // through LDS by channel quarters for stage C; two workgroups per CU), longer ones the two-read kernel; form 3: always the
 // two-read kernel; form 4 (opt-in): windows of at most 110 tokens on the LDS-resident persistent form (dec_cross_res_kernel:

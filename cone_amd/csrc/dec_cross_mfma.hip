@@ -30,9 +30,9 @@ typedef float g4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int dcm_swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
 
-template <int KTW>
+template <int KTW, int NQ = 5>
 struct DecCrossMfmaCfg {
-    static constexpr int NP = 40, NPT = 3, NPP = 48;   // pairs, pair tiles, padded pairs
+    static constexpr int NP = 8 * NQ, NPT = (NP + 15) / 16, NPP = 16 * NPT;   // pairs, pair tiles, padded pairs (5 slots: 40, 3, 48)
     static constexpr int KP = 128 * KTW;               // key capacity: 8 waves x KTW tiles x 16
     static constexpr int CTX_LD = 260;                 // ctx row stride (floats): 16-B aligned rows, spread banks
     static constexpr int QK_FLOATS = NPT * 16 * 256;   // operand slabs of qk (48 KiB)
@@ -40,10 +40,17 @@ struct DecCrossMfmaCfg {
     static constexpr int PT_FLOATS = KP * NPP;          // Pt[key][pair]; first the scaled queries, last stage D's partials
     static constexpr int RED_FLOATS = 2 * 8 * NPP;      // per-wave softmax maxima / sums
     static constexpr int LDS_FLOATS = A_FLOATS + PT_FLOATS + RED_FLOATS;
+    static_assert(A_FLOATS >= 8 * NQ * 256, "region A holds stage D's partial sums");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    // two workgroups per CU (<= 128 VGPRs) where the LDS allows it and the folds' accumulators (NQ float4 each) fit
+    static constexpr int MIN_WAVES = (KTW == 1 && NQ <= 5) ? 4 : 2;
 };
 
-template <int KTW, bool POSTAB>
-__global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel(const float* __restrict__ DQ,
+// NQ = decoder slots (num_queries, the first argument of the reference's training scripts): 5 = every shipped configuration;
+// 3 / 8 / 10 are instantiated for the table form too (Moment-DETR's own default is 10) -- more pair tiles, more LDS (one
+// workgroup per CU from 8 slots on), the same stages.
+template <int KTW, bool POSTAB, int NQ = 5>
+__global__ __launch_bounds__(512, (DecCrossMfmaCfg<KTW, NQ>::MIN_WAVES)) void dec_cross_mfma_kernel(const float* __restrict__ DQ,
                                                                  const float* __restrict__ XP,
                                                                  const float* __restrict__ X,
                                                                  const float* __restrict__ pos_rows,
@@ -60,10 +67,9 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
     // over the 2 GB of memory rows (0.4 ms per 20 000-window step).  Entries of padded clips are the caller's zeros.
     // QKS != null: the qk operand slabs are window-independent (first decoder layer: tgt = 0, the queries are the
     // same for every window) and were written once by a one-workgroup launch of this kernel with QKS_OUT set.
-    using C = DecCrossMfmaCfg<KTW>;
-    constexpr int NQ = 5;
+    using C = DecCrossMfmaCfg<KTW, NQ>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* qkf = smem;                          // [3][16] slabs of [16 pairs][16 channels]; later ctx[48][260]
+    float* qkf = smem;                          // [NPT][16] slabs of [16 pairs][16 channels]; later ctx[NPP][260]
     float* Pt = smem + C::A_FLOATS;             // [KP][48]
     float* smax = Pt + C::PT_FLOATS;            // [8][48]
     float* ssum = smax + 8 * C::NPP;            // [8][48]
@@ -111,10 +117,12 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
         for (int i = tid; i < C::QK_FLOATS / 4; i += 512)
             reinterpret_cast<g4v*>(qkf)[i] = reinterpret_cast<const g4v*>(QKS)[i];
     } else {
-    // rows 40 .. 47 of the last pair tile's slabs = 0
-    for (int i = tid; i < 16 * 8 * 16; i += 512) {          // (q, row 8 .. 15, 16 floats) of pair tile 2
-        const int q = i >> 7, r = 8 + ((i >> 4) & 7), c = i & 15;
-        qkf[(2 * 16 + q) * 256 + r * 16 + c] = 0.f;
+    // rows NP .. NPP - 1 of the last pair tile's slabs = 0 (an odd slot count fills half of its last tile)
+    if (C::NP < C::NPP) {
+        for (int i = tid; i < 16 * 8 * 16; i += 512) {      // (q, row 8 .. 15, 16 floats) of the last pair tile
+            const int q = i >> 7, r = 8 + ((i >> 4) & 7), c = i & 15;
+            qkf[((C::NPT - 1) * 16 + q) * 256 + r * 16 + c] = 0.f;
+        }
     }
     // ---- stage 0: qk[(s, h)][c] = sqrt(1/32) sum_d q[s][32 h + d] * Wk[32 h + d][c]: wave = head h, lane = channels 4 lane ..
     // + 3 -- a W_k row is ONE coalesced 1-KiB request per wave (a thread per channel made it four 256-B ones: 128 scalar loads
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(512, (KTW == 1 ? 4 : 2)) void dec_cross_mfma_kernel
             }
         }
         __syncthreads();                                    // every wave is done reading ctx
-        float* part = qkf;                                  // [8 waves][5][256] over the ctx rows
+        float* part = qkf;                                  // [8 waves][NQ][256] over the ctx rows
 #pragma unroll
         for (int s = 0; s < NQ; ++s) *reinterpret_cast<g4v*>(part + (wave * NQ + s) * 256 + 4 * lane) = o[s];
         __syncthreads();
@@ -1051,30 +1059,39 @@ static int launch_res_one(const float* DQ, const float* XP, const float* X, cons
     return 0;
 }
 
-template <int KTW, bool POSTAB>
+template <int KTW, bool POSTAB, int NQ = 5>
 static int launch_mfma_one(const float* DQ, const float* XP, const float* X, const float* pos_rows, const int* vlen,
                            const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B,
                            float* qk_slabs, hipStream_t s, const float* sal_w = nullptr, const float* sal_b = nullptr,
                            float* sal = nullptr, int sal_ld = 0) {
-    using C = DecCrossMfmaCfg<KTW>;
+    using C = DecCrossMfmaCfg<KTW, NQ>;
     static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
     CONE_CHECK_HIP(device_once(once, [] {
-        return hipFuncSetAttribute((const void*)dec_cross_mfma_kernel<KTW, POSTAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute((const void*)dec_cross_mfma_kernel<KTW, POSTAB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    C::LDS_FLOATS * 4);
     }));
     if (qk_slabs) {     // window-independent queries: the operand slabs once, by one workgroup (window 0's rows)
-        hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB>), dim3(1), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
+        hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB, NQ>), dim3(1), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
                            pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)nullptr, qk_slabs, (const float*)nullptr,
                            (const float*)nullptr, (float*)nullptr, 0);
         CONE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB>), dim3(B), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
+    hipLaunchKernelGGL((dec_cross_mfma_kernel<KTW, POSTAB, NQ>), dim3(B), dim3(512), C::LDS_FLOATS * 4, s, DQ, XP, X,
                        pos_rows, vlen, off, Wk, WvT, bv, OUT, (const float*)qk_slabs, (float*)nullptr, sal_w, sal_b, sal, sal_ld);
     CONE_LAUNCH_CHECK();
     return 0;
 }
 
-size_t dec_cross_mfma_slab_floats() { return DecCrossMfmaCfg<1>::QK_FLOATS; }
+// scratch of the shared-query operand slabs: the largest instantiated slot count's (10 slots: 5 pair tiles x 16 KiB)
+size_t dec_cross_mfma_slab_floats() { return DecCrossMfmaCfg<1, 10>::QK_FLOATS; }
+
+// the matrix-core forms: 5 slots everywhere (<= 192 tokens); 3 / 8 / 10 slots on the two-read kernel, table form (10 slots
+// with windows of more than 128 tokens would need 166 KiB of LDS: the unfolded decoder runs them)
+bool dec_cross_mfma_supported(int nq, int Lmax, bool table) {
+    if (nq == 5) return Lmax <= 192;
+    if (!table) return false;
+    return ((nq == 3 || nq == 8) && Lmax <= 192) || (nq == 10 && Lmax <= 128);
+}
 
 // qk_slabs != null: the NQ queries of every window are the SAME rows (DQ holds them for window 0 at least; first decoder
 // layer) -- the folded-key operand is built once into that scratch (dec_cross_mfma_slab_floats() floats).
@@ -1084,10 +1101,23 @@ int launch_dec_cross_mfma(const float* DQ, const float* XP, const float* X, cons
                           const int* off, const float* Wk, const float* WvT, const float* bv, float* OUT, int B, int nq,
                           int Lmax, float* qk_slabs, hipStream_t s, int form, const float* sal_w, const float* sal_b,
                           float* sal, int sal_ld) {
-    CONE_REQUIRE(dec_cross_supported(nq, Lmax), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
+    CONE_REQUIRE(dec_cross_mfma_supported(nq, Lmax, !XP), "fused decoder cross-attention: nq=%d Lmax=%d unsupported", nq, Lmax);
     CONE_REQUIRE(XP || (pos_rows && vlen), "fused decoder cross-attention: needs memory+pos rows or the sine table");
     if (B <= 0) return 0;
     ProfScope ps(PK_DEC_CROSS, B, Lmax, nq, nullptr, s);
+    if (nq != 5) {      // other slot counts: the two-read kernel, table form
+#define CONE_DCM_NQ(N)                                                                                                        \
+        if (nq == N)                                                                                                          \
+            return Lmax <= 128 ? launch_mfma_one<1, true, N>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, \
+                                                             sal_w, sal_b, sal, sal_ld)                                      \
+                               : launch_mfma_one<2, true, N>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, \
+                                                             sal_w, sal_b, sal, sal_ld);
+        CONE_DCM_NQ(3)
+        CONE_DCM_NQ(8)
+#undef CONE_DCM_NQ
+        return launch_mfma_one<1, true, 10>(DQ, nullptr, X, pos_rows, vlen, off, Wk, WvT, bv, OUT, B, qk_slabs, s, sal_w, sal_b,
+                                            sal, sal_ld);
+    }
     CONE_REQUIRE(!sal || (!XP && form != 4 && sal_w && sal_b && sal_ld > 0), "fused decoder cross-attention: the saliency "
                  "head rides only on the table form of the register-row kernels");
     // rows read once: registers transposed through LDS by channel quarters (two workgroups per CU).  Table form only: with a

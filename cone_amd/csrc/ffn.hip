@@ -71,6 +71,11 @@ struct FfnArgs {
     // QKV: the NEXT layer's q | k | v projection of the rows this kernel produces (Wq (n_qkv, 256), qb), computed from the
     // registers that hold them and written to QKV (M, n_qkv): no second pass over the rows, no extra launch
     const float* Wq; const float* qb; float* QKV; int ldq; int n_qkv;
+    // PRE (pre-norm layers, cone/transformer.py:248-260 / 319-342; PROJ only): OUT = x1 + W2 relu(W1 LN_p(x1) + b1) + b2 with
+    // x1 = R + A Wo^T + bo -- the residual stream stays un-normalised, (pg, pb) is the norm AHEAD of the feed-forward block --
+    // and OUT2 (may be null) = LayerNorm(OUT; ln_g, ln_b): what the next consumer reads (the next layer's norm1, the
+    // encoder's / decoder's final norm)
+    float* OUT2; int ldo2;
 };
 
 // LayerNorm over a token's 256 channels held as v[16] (channel 16 t + 4 lg + r in v[t][r]): 4 lanes x 64 registers.
@@ -96,8 +101,9 @@ __device__ __forceinline__ void ffn_layernorm_regs(f32x4f (&v)[16], float& rstd)
 // NW = 4 (64-row tiles, ONE wave per SIMD) is the small-M form: a wave runs the very same instruction sequence on its 16
 // rows (bit-identical results), but has its SIMD's matrix pipe to itself -- a tile takes half the time -- and the tile
 // grid is twice as fine; chosen by the launcher when the 128-row tiles would leave at least half of the CUs idle.
-template <bool PROJ, bool QKV, int NW>
+template <bool PROJ, bool QKV, int NW, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
+    static_assert(!PRE || (PROJ && !QKV), "the pre-norm form is the layer tail");
     constexpr int FFN_ROWS = 16 * NW, FFN_NPIECE = 32 / NW, NT = 64 * NW, HW = NW / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* b1s = smem + FFN_NST * FFN_STAGE;
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
         break;
     }
 
+    f32x4f y[16];
     if (PROJ) {
         load_res(tile);
         // ---- attention output projection + residual + LayerNorm: pair g computes channels [32 g, 32 g + 32) of
@@ -354,6 +361,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
         FFN_SB();
 #pragma unroll
         for (int t = 0; t < 16; ++t) xr[t] += *reinterpret_cast<const f32x4f*>(prm + 768 + 16 * t + 4 * lg);       // + bo
+        if (PRE) {      // the un-normalised stream x1 is the block's residual: the output accumulators START from x1 + b2
+                        // (no second copy of the tile in registers), then xr becomes the normalised block input
+#pragma unroll
+            for (int t = 0; t < 16; ++t) y[t] = xr[t] + *reinterpret_cast<const f32x4f*>(prm + 16 * t + 4 * lg);
+        }
         float rstd;
         ffn_layernorm_regs(xr, rstd);
 #pragma unroll
@@ -369,9 +381,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
     // ---- feed-forward block, software-pipelined across chunks: iteration i multiplies GEMM1 of chunk i (W1 half of
     // stage i) and GEMM2 of chunk i-1 (W2 half of stage i-1, hidden tile h of the previous iteration) in the same
     // units, so the GEMM1 -> bias/ReLU -> GEMM2 dependency spans a whole iteration instead of stalling every chunk.
-    f32x4f y[16];
+    if (!PRE) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) y[t] = f32x4f{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 16; ++t) y[t] = f32x4f{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4f h, hp[4];
     {   // iteration 0: GEMM1 of chunk 0 alone
         const float* st = FFN_STAGE_OF(NP);
@@ -456,16 +469,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ffn_fused_kernel(FfnArgs p) {
     }
     // ---- epilogue: + b2 + residual, LayerNorm over the token's 256 channels (4 lanes x 64 registers), store
     FFN_SB();
+    if (!PRE) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) y[t] = y[t] + *reinterpret_cast<const f32x4f*>(prm + 16 * t + 4 * lg) + xr[t];
+        for (int t = 0; t < 16; ++t) y[t] = y[t] + *reinterpret_cast<const f32x4f*>(prm + 16 * t + 4 * lg) + xr[t];
+    }
     FFN_SB();
     // in flight under the LayerNorm + stores (unconditional -- after the last tile a valid tile is simply re-read --
     // so that the register tiles have ONE definition per iteration)
     load_tile(tile + (int)gridDim.x < n_items ? tile + (int)gridDim.x : tile);
     FFN_SB();
+    if (PRE && my_row < M) {        // the un-normalised stream
+        float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4f*>(op + 16 * t) = y[t];
+    }
     float rstd;
-    ffn_layernorm_regs(y, rstd);
-    if (my_row < M) {
+    if (!PRE || p.OUT2) ffn_layernorm_regs(y, rstd);
+    if (PRE) {
+        if (p.OUT2 && my_row < M) {
+            float* op = p.OUT2 + (size_t)my_row * p.ldo2 + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4f g = *reinterpret_cast<const f32x4f*>(prm + 256 + 16 * t + 4 * lg);
+                const f32x4f be = *reinterpret_cast<const f32x4f*>(prm + 512 + 16 * t + 4 * lg);
+                f32x4f o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * g[r] + be[r];
+                *reinterpret_cast<f32x4f*>(op + 16 * t) = o;
+            }
+        }
+    } else if (my_row < M) {
         float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -552,7 +585,7 @@ bool ffn_fused_qkv_fits(int ff, int n_qkv) {
            (size_t)(FFN_NST * FFN_STAGE + ff + 6 * 256 + n_qkv) * sizeof(float) <= 160 * 1024;
 }
 
-template <bool PROJ, bool QKV, int NW>
+template <bool PROJ, bool QKV, int NW, bool PRE = false>
 static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     const size_t lds = (size_t)(FFN_NST * FFN_STAGE + a.ff + 6 * 256 + (QKV ? a.n_qkv : 0)) * sizeof(float);
     CONE_REQUIRE(lds <= 160 * 1024, "fused layer tail: %zu bytes of LDS (ff %d, q|k|v %d) exceed 160 KiB", lds, a.ff, a.n_qkv);
@@ -561,7 +594,7 @@ static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     static DeviceOnce once;
     int n_cu = 0;
     CONE_CHECK_HIP(device_once(once, [] {
-        return hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute((const void*)ffn_fused_kernel<PROJ, QKV, NW, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024);
     }, &n_cu));
     if (n_cu_out) { *n_cu_out = n_cu; return 0; }
@@ -571,7 +604,7 @@ static int launch_ffn_nw(const FfnArgs& a, hipStream_t s, int* n_cu_out) {
     // (+ 2 * M * n_qkv * 256 with the fused q | k | v projection: booked as n_qkv / 2 extra hidden units)
     ProfScope ps(NW == 8 ? (PROJ ? PK_FFN_PROJ : PK_FFN_FUSED) : (PROJ ? PK_FFN_PROJ_NW4 : PK_FFN_FUSED_NW4), a.M,
                  a.ff + (QKV ? a.n_qkv / 2 : 0), 256, a.M_dev, s);
-    hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL((ffn_fused_kernel<PROJ, QKV, NW, PRE>), dim3((unsigned)grid), dim3(64 * NW), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -655,6 +688,26 @@ int launch_proj_ffn_fused(const float* A, int lda, const float* Wo, const float*
     return launch_proj_ffn_wide(A + (size_t)m1 * lda, lda, Wo, bo, r_idx ? R : R + (size_t)m1 * ldr, ldr, pg, pb, W1, b1, W2, b2,
                                 ln_g, ln_b, OUT + (size_t)m1 * ldo, ldo, M - m1, M_dev, ff, s, r_idx ? r_idx + m1 : nullptr, R2,
                                 m1);
+}
+
+// The pre-norm layer tail (--pre_norm): OUT = x1 + FFN(LN(x1; pg, pb)), x1 = R + A Wo^T + bo; OUT2 (may be null) =
+// LN(OUT; n2g, n2b).  The persistent 128-row kernel for every row count (the option is off in every shipped configuration:
+// no wide / 64-row forms).  OUT may be R (in place).
+int launch_proj_ffn_prenorm(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                            const float* pb, const float* W1, const float* b1, const float* W2, const float* b2, float* OUT,
+                            int ldo, const float* n2g, const float* n2b, float* OUT2, int ldo2, int M, const int* M_dev, int ff,
+                            hipStream_t s, const int* r_idx, const float* R2) {
+    CONE_REQUIRE(!r_idx || R2, "pre-norm layer tail: a gathered residual needs both source matrices");
+    CONE_REQUIRE(ffn_fused_supported(ff), "pre-norm layer tail: dim_feedforward=%d unsupported", ff);
+    CONE_REQUIRE(A && Wo && bo && R && pg && pb && W1 && b1 && W2 && b2 && OUT && (!OUT2 || (n2g && n2b)),
+                 "pre-norm layer tail: null argument");
+    CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0 && ldo2 % 4 == 0, "pre-norm layer tail: row strides must be multiples of 4");
+    if (M <= 0) return 0;
+    FfnArgs a{};
+    a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = n2g ? n2g : pg; a.ln_b = n2b ? n2b : pb;
+    a.OUT = OUT; a.ldo = ldo; a.OUT2 = OUT2; a.ldo2 = ldo2; a.M = M; a.M_dev = M_dev; a.ff = ff; a.r_idx = r_idx; a.R2 = R2;
+    return launch_ffn_nw<true, false, 8, true>(a, s, nullptr);
 }
 
 }  // namespace cone

@@ -825,7 +825,12 @@ class PendingSplit:
     """A split whose device work is enqueued (``predict_split_async``).  ``info`` -- the run-info dict with the device-side
     result tensors -- is valid at once (stream-ordered); ``result()`` waits for the kept rows in pinned host memory, builds
     the submission lists and returns what ``predict_split`` returns.  A caller that evaluates split after split keeps one
-    in flight: the lists of split i are built while the GPU runs split i + 1."""
+    in flight: the lists of split i are built while the GPU runs split i + 1.
+
+    With ``opt.hip_graph`` the tensors of ``info`` are the graph's STATIC outputs: the next replay of the same graph overwrites
+    them, so they are valid only until the next ``predict_split_async`` on that store is enqueued (read them stream-ordered
+    before it, or ``clone()`` them).  What ``result()`` returns is always safe: the kept rows were copied to this handle's own
+    pinned buffers ahead of the next replay."""
 
     def __init__(self, info, finish):
         self.info, self._finish, self._res = info, finish, None

@@ -270,7 +270,10 @@ class CONE:
         text token (cone_layer0_project)."""
         lib, h = _lib.load(), self._h()
         qkv = torch.empty(proj_rows.shape[0], 3 * self.hidden_dim, device=proj_rows.device)
-        _lib.check(lib.cone_layer0_project(h, _lib.ptr(proj_rows), proj_rows.shape[0], _lib.ptr(qkv), _lib.stream()))
+        nbytes = lib.cone_layer0_project_workspace(h, proj_rows.shape[0])        # (--pre_norm: norm1 of the rows first)
+        ws = self._ws.get(nbytes, proj_rows.device) if nbytes else None
+        _lib.check(lib.cone_layer0_project(h, _lib.ptr(proj_rows), proj_rows.shape[0], _lib.ptr(qkv), _lib.ptr(ws),
+                                           ws.numel() if ws is not None else 0, _lib.stream()))
         return qkv
 
     def pos_tables(self, max_v_l: int):

@@ -231,7 +231,11 @@ typedef struct {
 } cone_layer0;
 int64_t cone_pos_table_rows(int max_v_l);
 int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream);
-int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* stream);
+/* (ABI 6) ws >= cone_layer0_project_workspace(m, n_rows) bytes: 0 for a post-norm model; a --pre_norm model's first in_proj
+ * reads norm1(row) (cone/transformer.py:250-252), normalised into the scratch first. */
+size_t cone_layer0_project_workspace(const cone_model* m, int64_t n_rows);
+int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows) with the tables, 13 KiB without. */
 size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,

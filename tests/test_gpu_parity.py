@@ -1464,6 +1464,27 @@ def test_predict_split_pipeline_is_chunk_invariant():
     assert inf.query_chunks(100, tail) == [(0, 100)]
 
 
+def test_chunks_straddling_a_kernel_form_threshold_are_invariant():
+    """The library picks kernel forms from Lv_max + Lq_max (the rows-once decoder cross-attention up to 128 tokens, the
+    two-read form above).  The bound is the SPLIT's longest query, never the chunk's: a split whose head chunk holds only short
+    queries (110 + 18 = 128 tokens) and whose tail holds a 25-token one must give the same bits chunked or not."""
+    from cone_amd import inference as inf
+    model, _, _ = get_model("ego4d", 3, max_v_l=110, max_q_l=30)
+    outs = []
+    for chunks in (1, 3):
+        opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=5, eval_bsz=4, pipeline_chunks=chunks,
+                       max_v_l=110, max_q_l=30)
+        ann, vf, qf = synth.make_dataset(opt, 24, 3, seed=8, ctx_range=(400, 600), lq_range=(5, 19))
+        last = qf[ann[-1]["query_id"]]
+        last["token_features"] = np.random.default_rng(1).standard_normal((25, opt.t_feat_dim)).astype(np.float32)
+        store = inf.FeatureStore(opt, ann, vf, qf)
+        assert store.max_tok_len == 25 and max(store.view(0, 8).tok_len) <= 18 and store.view(0, 8).max_tok_len == 25
+        outs.append(inf.predict_split(model, store, opt))
+    assert len(outs[1][1]["chunks"]) == 3
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1]["rows"], outs[1][1]["rows"])
+
+
 def test_predict_split_async_keeps_splits_in_flight():
     """predict_split_async enqueues a split's device work and hands the host half back: two splits (different stores, one of
     them under hipGraph replay, whose outputs are overwritten by the next replay) in flight at once, finished out of order,
@@ -2052,6 +2073,57 @@ def test_window_table_kernel_matches_index_arithmetic(q_base):
     assert set(got) == set(ref)
     for k in ref:
         assert torch.equal(got[k].to(torch.int64), ref[k].to(torch.int64)), k
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("nq,Lcap", [(3, 128), (3, 190), (8, 128), (8, 190), (10, 128)])
+def test_fused_decoder_cross_attention_other_slot_counts_match_float64(nq, Lcap, shared):
+    """The two-read folded cross-attention instantiated for 3 / 8 / 10 decoder slots (NUM_QUERIES is argument 1 of the
+    reference's training scripts; Moment-DETR's default is 10): 24 / 64 / 80 (slot, head) pairs = 2 / 4 / 5 pair tiles, windows
+    of up to 128 tokens and (3, 8 slots) up to 192, against nn.MultiheadAttention's arithmetic in float64."""
+    from cone_amd import _lib
+    dev = _gpu()
+    g = torch.Generator().manual_seed(50 + nq)
+    rng = np.random.default_rng(nq)
+    vmax = Lcap - 30
+    vl = [vmax, 1, 0, vmax, 16] + rng.integers(0, vmax + 1, 59).tolist()
+    tl = [30, 0, 7, 0, 0] + rng.integers(1, 31, 59).tolist()
+    B = len(vl)
+    L = [a + b for a, b in zip(vl, tl)]
+    off = np.concatenate([[0], np.cumsum(L)]).astype(np.int32)
+    M = int(off[-1])
+    X = torch.randn(M, 256, generator=g)
+    pos = torch.randn(vmax * (vmax + 1) // 2 + 1, 256, generator=g)
+    DQ = torch.randn(nq, 256, generator=g).repeat(B, 1) if shared else torch.randn(B * nq, 256, generator=g)
+    Wk = torch.randn(256, 256, generator=g) / 16
+    Wv = torch.randn(256, 256, generator=g) / 16
+    bv = torch.randn(256, generator=g)
+    ref = torch.zeros(B * nq, 256, dtype=torch.float64)
+    for b in range(B):
+        mem = X[off[b]:off[b + 1]].double()
+        keys = mem.clone()
+        lv = vl[b]
+        if lv:
+            keys[:lv] += pos[lv * (lv - 1) // 2:lv * (lv - 1) // 2 + lv].double()
+        K = keys @ Wk.double().t()
+        V = mem @ Wv.double().t() + bv.double()
+        q = DQ[b * nq:(b + 1) * nq].double() * (1.0 / 32 ** 0.5)
+        for h in range(8):
+            sl = slice(32 * h, 32 * h + 32)
+            ref[b * nq:(b + 1) * nq, sl] = torch.softmax(q[:, sl] @ K[:, sl].t(), dim=1) @ V[:, sl]
+    d = lambda t: t.to(dev).contiguous()
+    lib = _lib.load()
+    out = torch.full((B * nq + 2, 256), float("nan"), device=dev)
+    slabs = torch.empty(lib.cone_test_dec_cross_slab_floats(), device=dev) if shared else None
+    Xd, pd, DQd, Wkd, WvTd, bvd = d(X), d(pos), d(DQ), d(Wk), d(Wv.t()), d(bv)
+    vld, offd = torch.tensor(vl, dtype=torch.int32, device=dev), torch.from_numpy(off).to(dev)
+    _lib.check(lib.cone_test_dec_cross(_lib.ptr(DQd), _lib.ptr(Xd), _lib.ptr(pd), _lib.ptr(vld), _lib.ptr(offd),
+                                       _lib.ptr(Wkd), _lib.ptr(WvTd), _lib.ptr(bvd), _lib.ptr(out), B, nq, max(L), 2,
+                                       _lib.ptr(slabs), _lib.stream()))
+    torch.cuda.synchronize()
+    assert max(L) == Lcap
+    assert maxdiff(out[:B * nq], ref) < 2e-5
+    assert bool(torch.isnan(out[B * nq:]).all())
 
 
 @pytest.mark.parametrize("variant", [2, 5, 3, 4, 1])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE configs[1] with 5 and with 10 decoder slots (NUM_QUERIES of the reference's training scripts): ms per step, one step in
-flight.  3 / 8 / 10 slots run the folded cross-attention instantiated for them (two-read form); other counts run the encoder on
-the table path and the decoder unfolded (K / V GEMMs + small attention)."""
+"""BASELINE configs[1] with a post-norm and a --pre_norm checkpoint (cone/config.py:120): ms per step, one step in flight.
+Pre-norm runs the table path with the fused layer tail in its pre-norm form and the folded decoder cross-attention; it has no
+first-layer row caches (its in_proj reads norm1(x)) and no first-decoder-layer constants."""
 import os
 import sys
 import time
@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cone_amd import inference as inf, synth
 from cone_amd.config import make_opt
 from cone_amd.model import build_model
-for nq in [int(a) for a in sys.argv[1:]] or (5, 10, 3, 8, 16):
-    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32, num_queries=nq)
+for pre in (False, True):
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32, pre_norm=pre)
     model, _ = build_model(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
     ann, vf, qf = synth.make_dataset(opt, 1000, 50, seed=0)
@@ -26,4 +26,4 @@ for nq in [int(a) for a in sys.argv[1:]] or (5, 10, 3, 8, 16):
         if prev: prev.result()
         prev = h
     prev.result(); torch.cuda.synchronize()
-    print(nq, "slots:", round((time.perf_counter() - t0) / 6 * 1e3, 2), "ms per step")
+    print("pre_norm" if pre else "post_norm", round((time.perf_counter() - t0) / 6 * 1e3, 2), "ms per step")

@@ -23,13 +23,23 @@ model, _ = build_model(opt)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
 ann, vf, qf = synth.make_dataset(opt, 1000, 50, seed=0)
 store = inf.FeatureStore(opt, ann, vf, qf)
-fn = lambda: par.predict_split_distributed(model, store, opt, mode="window", format_shard=True, virtual=(rank, world))
-for _ in range(3):
-    fn()
+start = lambda: par.predict_split_distributed_async(model, store, opt, mode="window", format_shard=True, virtual=(rank, world))
+
+
+def run(n):     # one step in flight, like bench.py's N > 1 headline
+    prev = None
+    for _ in range(n):
+        h = start()
+        if prev is not None:
+            prev.result()
+        prev = h
+    prev.result()
+
+
+run(3)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
-    fn()
+run(steps)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(json.dumps({"world": world, "rank": rank, "ms_per_step": round(dt * 1e3, 3)}))
