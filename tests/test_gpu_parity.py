@@ -1243,8 +1243,11 @@ def test_fused_decoder_cross_attention_equals_unfused(preset):
         model.set_option("dec_fold", 2)
     with pytest.raises(_lib.ConeHipError):
         model.set_option("no_such_option", 1)
+    # (since ABI 6 CONE.forward runs the table path; switching the fold OFF selects the whole general path -- materialised
+    # x + pos, unfused q | k and v GEMMs -- so the encoder's sums are re-associated too: the cross-path tolerance of
+    # test_position_tables_equal_materialised_pos_path)
     for k in ("pred_logits", "pred_spans", "hs"):
-        assert maxdiff(outs[0][k], outs[1][k]) < 2e-5, k
+        assert maxdiff(outs[0][k], outs[1][k]) < 5e-5, k
         assert maxdiff(outs[0][k], outs[2][k]) < 2e-5, ("valu fold", k)
     # the first decoder layer's window-independent rows (tgt = 0) computed once and replicated: identical bits
     try:
