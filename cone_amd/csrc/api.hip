@@ -103,7 +103,7 @@ static int build_model(const cone_weights* w, cone_model** out) {
                  "model_create: unsupported model shape hidden_dim=%d nheads=%d -- the attention / layer-tail kernels of this "
                  "build are instantiated for hidden_dim 256 with 8 heads (head_dim 32: every shipped CONE configuration, "
                  "cone/config.py:101-104); also required: dim_feedforward a multiple of 128, num_queries <= 16, feature dims "
-                 "multiples of 32 up to 1024, at most 192 tokens (clips + words) per window", w->hidden_dim, w->nheads);
+                 "multiples of 32 up to 1024, at most 256 tokens (clips + words) per window", w->hidden_dim, w->nheads);
     CONE_REQUIRE(w->dim_ff % 128 == 0 && w->dim_ff >= 128, "model_create: dim_feedforward=%d must be a multiple of 128", w->dim_ff);
     CONE_REQUIRE(w->enc_layers >= 1 && w->enc_layers <= CONE_MAX_LAYERS && w->dec_layers >= 1 &&
                      w->dec_layers <= CONE_MAX_LAYERS, "model_create: layer counts out of range");
@@ -674,7 +674,13 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                           size_t ws_bytes, hipStream_t s, const cone_layer0* l0 = nullptr) {
     CONE_REQUIRE(B > 0 && Lv_max > 0 && Lq_max >= 0, "forward: bad sizes B=%d Lv=%d Lq=%d", B, Lv_max, Lq_max);
     const int Lmax = Lv_max + Lq_max;
-    CONE_REQUIRE(Lmax <= 192, "forward: window length %d + %d exceeds 192 tokens", Lv_max, Lq_max);
+    CONE_REQUIRE(Lmax <= CONE_MAX_WINDOW_TOKENS, "forward: window length %d + %d exceeds %d tokens", Lv_max, Lq_max,
+                 CONE_MAX_WINDOW_TOKENS);
+    // beyond 192 tokens only the default path exists (the 256-key forms of the encoder attention and of the folded cross-
+    // attention): the A/B forms and the unfolded decoder stop at 192 keys
+    CONE_REQUIRE(Lmax <= 192 || (m->opt_dec_fold >= 2 && dec_cross_mfma_supported(m->nq, Lmax, true) && !m->txt_pos_emb &&
+                                 m->opt_pos_tables),
+                 "forward: windows of %d tokens (> 192) run only on the default table path with 3 / 5 / 8 decoder slots", Lmax);
     CONE_REQUIRE((int64_t)B * Lmax < (1ll << 24), "forward: batch too large (B * L >= 2^24 tokens)");
     if (m->txt_pos_emb)
         CONE_REQUIRE(Lq_max <= m->txt_pos_rows, "forward: %d text tokens but txt_position_embed has %d rows (max_q_l)", Lq_max,

@@ -107,12 +107,19 @@ __device__ __forceinline__ void attn_normalise(f32x4m& o0, f32x4m& o1, float inv
 // are scalars (t0, vrow0[b], trow0[b], the table row of (lv, 0)), a lane contributes token * stride + column.  A text token
 // reads the table's ZERO row (AttnSrc::pos_zero_row: the last row of cone_pos_tables) instead of skipping the add, so the
 // adds are unconditional and no 64-bit pointer is ever selected per lane except the gather mode's clip / text source.
+// Windows of 193 .. 256 tokens (NKT 13 .. 16: WINDOW_LENGTH is a user argument of the reference's scripts, README.md:94-98) need
+// 57 .. 70 KiB for the two images: dynamic LDS (opt-in above 64 KiB), one workgroup of up to 1 024 threads; the shipped
+// window lengths (NKT <= 12) keep their static images and their instruction sequence.
 template <int NKT, int MODE>
-__global__ __launch_bounds__(64 * NKT, 6) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
+__global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
                                                                  const int* __restrict__ off) {
     constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
-    __shared__ float KsT[32 * LDK];
-    __shared__ __attribute__((aligned(16))) float Vs[KP * LDV];
+    constexpr bool DYN = NKT > 12;
+    __shared__ float KsT_s[DYN ? 4 : 32 * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs_s[DYN ? 4 : KP * LDV];
+    extern __shared__ __attribute__((aligned(16))) float attn_dyn[];
+    float* const KsT = DYN ? attn_dyn : KsT_s;
+    float* const Vs = DYN ? attn_dyn + 32 * LDK : Vs_s;
     const int b = blockIdx.y, head = blockIdx.x;        // the 8 heads of a window are dispatched together
     const int t0 = off[b];
     const int L = off[b + 1] - t0;
@@ -377,17 +384,30 @@ static int launch_enc_attn_t(const AttnSrc& a, float* OUT, const int* off, int B
     }
     dim3 grid(8, B);
 #define CONE_ATTN16(N) case N: hipLaunchKernelGGL((enc_attn16_kernel<N, MODE>), grid, dim3(64 * N), 0, s, a, OUT, off); break;
+    // 13 .. 16 key tiles: both images in dynamic LDS (the opt-in above 64 KiB once per device)
+#define CONE_ATTN16D(N)                                                                                                     \
+    case N: {                                                                                                               \
+        constexpr int bytes = (32 * (16 * N + 2) + 16 * N * 36) * 4;                                                        \
+        static DeviceOnce once;                                                                                             \
+        CONE_CHECK_HIP(device_once(once, [] {                                                                               \
+            return hipFuncSetAttribute((const void*)enc_attn16_kernel<N, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+        }));                                                                                                                \
+        hipLaunchKernelGGL((enc_attn16_kernel<N, MODE>), grid, dim3(64 * N), bytes, s, a, OUT, off);                        \
+        break;                                                                                                              \
+    }
     switch (nkt) {
         CONE_ATTN16(6)
         CONE_ATTN16(7) CONE_ATTN16(8) CONE_ATTN16(9) CONE_ATTN16(10) CONE_ATTN16(11) CONE_ATTN16(12)
+        CONE_ATTN16D(13) CONE_ATTN16D(14) CONE_ATTN16D(15) CONE_ATTN16D(16)
     }
 #undef CONE_ATTN16
+#undef CONE_ATTN16D
     CONE_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_enc_attn(int mode, const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
-    CONE_REQUIRE(Lmax >= 1 && Lmax <= 192, "enc attention: window length %d not in [1,192]", Lmax);
+    CONE_REQUIRE(Lmax >= 1 && Lmax <= 256, "enc attention: window length %d not in [1,256]", Lmax);
     if (B <= 0) return 0;
     ProfScope ps(PK_ENC_ATTN, B, Lmax, mode, nullptr, s);
     switch (mode) {

@@ -1085,12 +1085,12 @@ static int launch_mfma_one(const float* DQ, const float* XP, const float* X, con
 // scratch of the shared-query operand slabs: the largest instantiated slot count's (10 slots: 5 pair tiles x 16 KiB)
 size_t dec_cross_mfma_slab_floats() { return DecCrossMfmaCfg<1, 10>::QK_FLOATS; }
 
-// the matrix-core forms: 5 slots everywhere (<= 192 tokens); 3 / 8 / 10 slots on the two-read kernel, table form (10 slots
-// with windows of more than 128 tokens would need 166 KiB of LDS: the unfolded decoder runs them)
+// the matrix-core forms: 5 slots everywhere (<= 256 tokens); 3 / 8 / 10 slots on the two-read kernel, table form (10 slots
+// with windows of more than 128 tokens would need 166 KiB of LDS: the unfolded decoder runs them, up to 192 tokens)
 bool dec_cross_mfma_supported(int nq, int Lmax, bool table) {
-    if (nq == 5) return Lmax <= 192;
+    if (nq == 5) return Lmax <= 256;        // (two key tiles per wave: 8 waves x 2 x 16 keys)
     if (!table) return false;
-    return ((nq == 3 || nq == 8) && Lmax <= 192) || (nq == 10 && Lmax <= 128);
+    return ((nq == 3 || nq == 8) && Lmax <= 256) || (nq == 10 && Lmax <= 128);
 }
 
 // qk_slabs != null: the NQ queries of every window are the SAME rows (DQ holds them for window 0 at least; first decoder

@@ -40,7 +40,8 @@ extern "C" {
 
 #define CONE_MAX_LAYERS 8
 #define CONE_MAX_PROJ 3
-#define CONE_TABLE_MAX_V_L 192 /* longest window (clips) the handle's own position tables cover */
+#define CONE_TABLE_MAX_V_L 255 /* longest window (clips) the handle's own position tables cover */
+#define CONE_MAX_WINDOW_TOKENS 256 /* clips + text tokens of one window (WINDOW_LENGTH + max_q_l of the reference's scripts) */
 
 typedef struct cone_model cone_model;
 

@@ -429,11 +429,12 @@ def test_stage_b_matches_oracle_random(preset, B, seed, entry, split_bf16):
     assert np.abs(match.cpu().numpy() - ref_match.numpy())[ok].max() < TOL
 
 
-@pytest.mark.parametrize("Lv,Lq", [(160, 32), (129, 2), (96, 32), (1, 1)])
+@pytest.mark.parametrize("Lv,Lq", [(160, 32), (129, 2), (96, 32), (1, 1), (230, 25), (224, 32), (161, 32)])
 def test_stage_b_window_length_boundaries(Lv, Lq):
-    """Maximum supported window (192 tokens: 6 key blocks in the encoder attention, the 192-key variant of the
-    fused decoder cross-attention), the 128/129 boundary of both, and the 1 + 1 token minimum, against the
-    oracle; one token more than 192 is rejected loudly."""
+    """Window lengths (WINDOW_LENGTH is argument 3 of the reference's scripts, README.md:94-98): the maximum of 256 tokens (16
+    key tiles in the encoder attention with both images in dynamic LDS, the 256-key form of the folded decoder cross-
+    attention), the 192 / 193 and 128 / 129 boundaries of the kernel forms, and the 1 + 1 token minimum, against the oracle; one
+    token more than 256 is rejected loudly."""
     from cone_amd.model import build_model
     from cone_amd import _lib
     opt = make_opt("ego4d", max_v_l=Lv, max_q_l=Lq)
@@ -456,9 +457,9 @@ def test_stage_b_window_length_boundaries(Lv, Lq):
     assert maxdiff(out["pred_spans"], ref["pred_spans"]) < TOL
     vm = _valid_token_mask(lens_v, lens_q, Lv, Lq)[:, :Lv]
     assert np.abs(out["saliency_scores"].cpu().numpy() - ref["saliency_scores"].numpy())[vm].max() < TOL
-    if Lv + Lq == 192:
+    if Lv + Lq == 256:
         big = gi.stage_b_inputs(opt, 32, [Lv], [Lq])
-        txt = np.concatenate([big["src_txt"], big["src_txt"][:, :1]], axis=1)       # 193 tokens
+        txt = np.concatenate([big["src_txt"], big["src_txt"][:, :1]], axis=1)       # 257 tokens
         msk = np.concatenate([big["txt_mask"], big["txt_mask"][:, :1]], axis=1)
         with pytest.raises(_lib.ConeHipError):
             model.forward(g(txt), g(msk), g(big["src_vid"]), g(big["vid_mask"]))
