@@ -82,8 +82,8 @@ typedef struct {
     const float* txt_pos_embed; int32_t txt_pos_rows; cone_ln_w txt_pos_ln;
     /* (ABI 5) --pre_norm (cone/config.py:120 -> normalize_before, cone/transformer.py:19-36): pre_norm != 0 = every layer
      * normalises its input (forward_pre) and the encoder ends with enc_norm = transformer.encoder.norm, which exists only
-     * then.  0 (every shipped configuration) = post-norm.  Such a model runs on the general path (plain LayerNorm / GEMM /
-     * attention launches: no fused layer tails, no layer-0 caches). */
+     * then.  0 (every shipped configuration) = post-norm.  (ABI 6) such a model runs the table path as well: the fused layer
+     * tail in its pre-norm form, first-layer row caches of in_proj(norm1(row)), the folded decoder cross-attention. */
     int32_t pre_norm; cone_ln_w enc_norm;
 } cone_weights;
 
@@ -196,6 +196,11 @@ typedef struct {
 /* A6-A11, CONE.forward (cone/model.py:82-128) on zero-padded tensors exactly as
  * prepare_batch_inputs delivers them: vid (B,Lv_pad,v_dim), txt (B,Lq_pad,t_dim); masks are prefix
  * masks given as valid lengths vid_len[B], txt_len[B] (int32, device).
+ * (ABI 6) The batch is compacted first -- the valid clip / token rows are gathered by the first LayerNorm of their input
+ * projection, padding is never projected -- the projections and the first encoder layer's q | k | v rows run once per compact
+ * row (device-side row counts), and the windows enter the packed forward below as (row0, len) pairs with those row caches:
+ * the SAME launches as the eval driver's arena path (gathering first layer, the handle's position tables, fused layer tails,
+ * folded decoder cross-attention), the same bits for the same windows.  Lv_pad + Lq_pad <= CONE_MAX_WINDOW_TOKENS.
  * Outputs: logits (B,Nq,2), spans (B,Nq,2) = sigmoid(center,width), saliency (B,Lv_pad; may be NULL: the
  * saliency head is then skipped -- cone/inference.py computes and never reads it, :54-59; likewise the heads and
  * decoder.norm of the intermediate decoder layers run only when taps ask for hs / aux_logits / aux_spans)
@@ -211,7 +216,7 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
  * [txt_row0[b], +txt_len[b]).  This is how the eval driver avoids re-projecting the clips shared by
  * overlapping windows and the text replicated across a query's windows.
  * Lv_max/Lq_max bound the lengths (host-known); saliency is (B, Lv_max). */
-/* Optional row caches + static position tables.  Everything ahead of the first attention is row-wise, and the
+/* Optional row caches (+ caller-owned position tables).  Everything ahead of the first attention is row-wise, and the
  * position term enters every attention through a LINEAR map, so it can be split off and tabulated:
  *   (x + pos) W^T + b = (x W^T + b) + pos W^T.
  * qkv_vid (n_clips, 3d) / qkv_txt (n_tokens, 3d) = cone_layer0_project of the projected arenas: the FIRST encoder
@@ -223,8 +228,12 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
  * pos_qk (enc_layers, R, 2d): pos_rows [W_q | W_k]^T of every encoder layer (no bias).
  * With the tables the later encoder layers run ONE N = 3d GEMM on x (the attention kernel adds the pos_qk row to
  * q | k in its staging loads) and the decoder's cross-attention forms its keys memory + pos from pos_rows: no
- * x + pos matrix is ever written.  pos_rows may be NULL: then only layer 0 uses the cache (pos_qk layer 0) and the
- * later layers read an x + pos matrix written by the previous layer's epilogue. */
+ * x + pos matrix is ever written.
+ * (ABI 6) The model handle OWNS such tables (built at cone_model_create for windows of up to CONE_TABLE_MAX_V_L clips: row
+ * lv (lv - 1) / 2 + p is the same row whatever the bound).  pos_rows / pos_qk == NULL -- or the whole cone_layer0 == NULL --
+ * means "the handle's": every call runs the table path.  qkv_vid / qkv_txt == NULL (no row caches): the packed layer input is
+ * written once and the first layer runs like the later ones (one N = 3d GEMM on x, position rows from the table) -- the same
+ * bits as with the caches, ~10 % more FLOPs when windows share clips / text.  max_v_l describes caller-owned tables only. */
 typedef struct {
     const float* qkv_vid; const float* qkv_txt;
     const float* pos_qk; const float* pos_rows;
@@ -238,7 +247,7 @@ size_t cone_layer0_project_workspace(const cone_model* m, int64_t n_rows);
 int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* ws, size_t ws_bytes,
                         void* stream);
 
-/* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows) with the tables, 13 KiB without. */
+/* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows); 13 KiB on the general path (--use_txt_pos, A/B switches). */
 size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
                                      const cone_layer0* l0 /* as passed to cone_forward_packed */);
 int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,

@@ -104,8 +104,22 @@ for it in range(iters):
                     window_batch=32768 if opt.window_batch != 32768 else 5)
     again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
     assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
+    # the reference's own call on its own zero-padded batch (cone/inference.py:45-50: model(**model_inputs) on eval_bsz queries
+    # x top-k windows) = cone_forward_windows: compaction + projection of the valid rows + row caches inside the call, then the
+    # arena path's launches -- the same bits as the arena entry on the same windows
+    import bench as B_
+    inputs, wt1, sub1 = B_.reference_batch_tensors(model, store, opt)
+    o1 = model(**{k: inputs[k] for k in ("src_txt", "src_txt_mask", "src_vid_motion", "src_vid_motion_mask")})
+    f1 = inf.project_features(model, sub1)
+    a1 = model.forward_packed(f1["vproj"], wt1["vid_row0"], wt1["vid_len"], f1["tproj"], wt1["txt_row0"], wt1["txt_len"],
+                              int(inputs["src_vid_motion"].shape[1]), int(inputs["src_txt"].shape[1]), l0=f1.get("l0"),
+                              saliency=True, aux=True)
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert torch.equal(o1[k], a1[k]), f"{tag}: padded entry differs from the arena entry in {k}"
+    tot["dropin"] = tot.get("dropin", 0) + int(o1["pred_logits"].shape[0])
 print(f"fuzz ok: {iters} random splits ({preset}, split_bf16={split_bf16}{', ' + str(model_kw) if model_kw else ''}) in {time.time() - t_start:.0f} s; worst proposal diff {worst['prop']:.2e}, "
       f"worst span diff {worst['sec']:.2e} s; matching: every proposal within {worst['match_alt']:.1e} of the oracle's pooling of its "
       f"own span, {tot['bad']} of {tot['rows']} rows ({tot['bad'] / max(tot['rows'], 1):.2%}) beyond 2e-4 of the oracle's rows "
       f"({tot['bnd']} proposals next to a clip boundary; worst split {worst['match_bad']:.0%}); "
-      f"{tot['reordered']} windows with near-tied proposals in the other order")
+      f"{tot['reordered']} windows with near-tied proposals in the other order; {tot.get('dropin', 0)} windows through the padded "
+      f"entry (CONE.forward) bit-identical to the arena entry")
