@@ -61,9 +61,10 @@ HBM_PEAK_GBS = 8000.0           # same guide: HBM3E peak BW (spec); 6.29 TB/s me
 HBM_COPY_GBS = 6290.0           # ... that measured copy rate (MI355X_MICROARCH.md, chip level)
 KERNEL_NAMES = {0: "gemm_f32_kernel<128,128,false>", 1: "gemm_f32_kernel<128,128,true>",
                 2: "gemm_f32_kernel<64,256,false>", 3: "enc_attn16_kernel", 4: "frame_score_kernel",
-                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_mfma_kernel", 8: "ffn_fused_kernel<false, false, 8>",
-                9: "ffn_fused_kernel<true, false, 8>", 10: "ffn_wide_kernel<false>", 11: "ffn_wide_kernel<true>",
-                12: "ffn_fused_kernel<false, false, 4>", 13: "ffn_fused_kernel<true, false, 4>", 14: "gemm_rows_small_kernel"}
+                5: "gemm_rows_kernel<16>", 6: "gemm_rows16_kernel", 7: "dec_cross_mfma_kernel", 8: "ffn_fused_kernel<false, false, 8, false>",
+                9: "ffn_fused_kernel<true, false, 8, false>", 10: "ffn_wide_kernel<false>", 11: "ffn_wide_kernel<true>",
+                12: "ffn_fused_kernel<false, false, 4, false>", 13: "ffn_fused_kernel<true, false, 4, false>",
+                14: "gemm_rows_small_kernel"}
 # one kind per KERNEL (include/cone_hip.h, cone_prof_collect): a record is one launch of that kernel and its own rows
 GEMM_KINDS = (0, 1, 2, 5, 6, 8, 9, 10, 11, 12, 13, 14)   # records (kind, M, N, K, ms): 2*M*N*K FLOPs; the layer-tail kinds
 #                                      (N = ff, K = 256): the feed-forward block = two such GEMMs, + the 256 x 256 output
@@ -92,8 +93,8 @@ def csrc_hashes():
             for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".c"))}
 
 
-PMC_FILES = ("r04_pmc_traffic.json",)
-PMC_PREFILTER_FILES = ("r04_pmc_prefilter.json",)
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json")
+PMC_PREFILTER_FILES = ("r05_pmc_prefilter.json", "r04_pmc_prefilter.json")
 
 
 def collect_profile():

@@ -21,9 +21,13 @@
 // into the wave's private 8-slab ring and read back as the MFMA operand (row = lane % 16, chunk = lane / 16) with
 // gemm.hip's chunk XOR swizzle (conflict-free).  [Measured: the same bytes loaded straight into the operand layout --
 // 16 B per lane, adjacent lanes 1 KiB apart -- cost 9 us per GEMM on top of 18 us of MFMA; one coalesced instruction per
-// slab 1.3 us.]  The ring runs through the three phases without a break (their slab counts are multiples of 8): pair
-// step p multiplies slabs 2p, 2p + 1 (already in registers), reads 2p + 2, 2p + 3 from the ring and refills the two
-// slots with slabs 2p + 8, 2p + 9 -- 6 to 8 KiB in flight per wave, one counted s_waitcnt vmcnt per pair.
+// slab 1.3 us.]  The stream is a sequence of BLOCKS of 8 slab pairs -- projection (2 blocks), then per pass of 8 hidden chunks
+// one GEMM1 block (this wave's chunk of the pass) and one GEMM2 block (its two output tiles over the pass's 8 chunks) -- through
+// a 16-slab ring: pair u of every block lives in slots 2u, 2u + 1; step u multiplies pair u (already in registers), reads pair
+// u + 1 from the ring and refills pair u's slots with pair u of the NEXT block: 14 KiB in flight per wave (round 5; an 8-slab
+// ring with 6 KiB in flight left the wave waiting on the L2 for 23 of 54 us), one counted s_waitcnt vmcnt per pair.  The
+// hidden tile passes through LDS one pass (8 chunks, 8 KiB) at a time -- GEMM2 accumulates the chunks in the same order as
+// before, so the bits do not change -- which is what frees the LDS for the deeper ring.
 #include "common.h"
 
 namespace cone {
@@ -39,7 +43,8 @@ struct FfnWideArgs {
 };
 
 constexpr int FW_XLD = 260;     // row stride (floats) of the 16 x 256 exchange tile
-constexpr int FW_RING = 8 * 256;    // floats per wave: 8 slabs of [16 rows][16 floats]
+constexpr int FW_RING = 16 * 256;   // floats per wave: 16 slabs of [16 rows][16 floats] = 8 slab pairs = one block
+constexpr int FW_PASS = 8;          // hidden chunks per pass (one per wave in GEMM1)
 
 #define FW_GLDS16(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
@@ -77,21 +82,22 @@ __device__ __forceinline__ void fw_layernorm_regs(f32x4w (&v)[16], float& rstd) 
         __builtin_amdgcn_s_barrier();                          \
         FW_SB();                                               \
     }
-// slabs 2p + 2, 2p + 3 have landed (at most the four issued after them are still in flight) -> registers
-#define FW_STEP_BEGIN(s0, s1)                                  \
+// step u of a block: the NEXT pair (pair (u + 1) % 8: of this block, or pair 0 of the next one) has landed -- the six pairs
+// issued after it may still be in flight -- and goes to registers
+#define FW_STEP_BEGIN(u)                                       \
     {                                                          \
         FW_SB();                                               \
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       \
-        n0 = *reinterpret_cast<const f32x4w*>(ring + (s0) * 256 + rdo); \
-        n1 = *reinterpret_cast<const f32x4w*>(ring + (s1) * 256 + rdo); \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      \
+        n0 = *reinterpret_cast<const f32x4w*>(ring + (2 * (((u) + 1) & 7)) * 256 + rdo);     \
+        n1 = *reinterpret_cast<const f32x4w*>(ring + (2 * (((u) + 1) & 7) + 1) * 256 + rdo); \
         FW_SB();                                               \
     }
-// the pair's slots (read one step ago, consumed by the MFMAs above) take slabs 2p + 8, 2p + 9
-#define FW_STEP_END(src0, src1, s0, s1)                        \
+// pair u's slots (read one step ago, consumed by the MFMAs above) take pair u of the next block
+#define FW_STEP_END(src0, src1, u)                             \
     {                                                          \
         FW_SB();                                               \
-        FW_GLDS16(src0, ring + (s0) * 256);                    \
-        FW_GLDS16(src1, ring + (s1) * 256);                    \
+        FW_GLDS16(src0, ring + (2 * (u)) * 256);               \
+        FW_GLDS16(src1, ring + (2 * (u) + 1) * 256);           \
         c0 = n0; c1 = n1;                                      \
         FW_SB();                                               \
     }
@@ -101,8 +107,8 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ff = p.ff, nc = ff >> 4;
     float* XS = smem;                               // [16 tokens][FW_XLD]: projected rows, later the block's output rows
-    float* HS = XS + 16 * FW_XLD;                   // [ff / 16 chunks][64 lanes][4]: hidden tiles in accumulator layout
-    float* B1 = HS + ff * 16;                       // b1 (no ordinary global load inside the DMA-counted loops)
+    float* HS = XS + 16 * FW_XLD;                   // [8 chunks of the pass][64 lanes][4]: hidden tiles in accumulator layout
+    float* B1 = HS + FW_PASS * 256;                 // b1 (no ordinary global load inside the DMA-counted loops)
     int M = p.M;
     if (p.M_dev) { const int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
     const int row0 = blockIdx.x * 16;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     float* ring = B1 + ff + wave * FW_RING;         // this wave's slab ring
     const int my_row = row0 + li;
     const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);       // rows past M feed unstored outputs
-    const int n1c = nc >> 3;                        // hidden chunks per wave
+    const int npass = nc / FW_PASS;                 // passes of 8 hidden chunks (one GEMM1 chunk per wave and pass)
 
     // slab sources: uniform base + lane offset (row = lane / 4, source chunk = the one that lands in physical chunk lane % 4)
     const int drow = lane >> 2;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     f32x4w xr[16];
     if (PROJ) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { FW_GLDS16(srcA(j, 0), ring + (2 * j) * 256); FW_GLDS16(srcA(j, 1), ring + (2 * j + 1) * 256); }
+        for (int j = 0; j < 8; ++j) { FW_GLDS16(srcA(j, 0), ring + (2 * j) * 256); FW_GLDS16(srcA(j, 1), ring + (2 * j + 1) * 256); }
         FW_SB();
         f32x4w ar[16];
         const float* ap = p.A + ld_row * p.lda + 4 * lg;
@@ -156,15 +162,15 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
         f32x4w ha[2], hb[2];
         ha[0] = f32x4w{0.f, 0.f, 0.f, 0.f}; ha[1] = ha[0]; hb[0] = ha[0]; hb[1] = ha[0];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            FW_STEP_BEGIN((2 * q + 2) & 7, (2 * q + 3) & 7);
+        for (int q = 0; q < 16; ++q) {              // two blocks of 8 pairs
+            FW_STEP_BEGIN(q & 7);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 FW_MFMA(ha[r & 1], c0[r], ar[q][r]);
                 FW_MFMA(hb[r & 1], c1[r], ar[q][r]);
             }
-            if (q + 4 < 16) { FW_STEP_END(srcA(q + 4, 0), srcA(q + 4, 1), (2 * q) & 7, (2 * q + 1) & 7); }
-            else { FW_STEP_END(srcB(0, 2 * (q - 12)), srcB(0, 2 * (q - 12) + 1), (2 * q) & 7, (2 * q + 1) & 7); }
+            if (q < 8) { FW_STEP_END(srcA(q + 8, 0), srcA(q + 8, 1), q & 7); }
+            else { FW_STEP_END(srcB(0, 2 * (q - 8)), srcB(0, 2 * (q - 8) + 1), q & 7); }      // GEMM1 block of pass 0
         }
         // residual + projection of this wave's two tiles -> LDS; register r of lane (li, lg) = channel 16 t + 4 lg + r
         const f32x4w x0 = r0 + (ha[0] + ha[1]);
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) FW_GLDS16(srcB(0, j), ring + j * 256);
+        for (int j = 0; j < 8; ++j) { FW_GLDS16(srcB(0, 2 * j), ring + (2 * j) * 256); FW_GLDS16(srcB(0, 2 * j + 1), ring + (2 * j + 1) * 256); }
         FW_SB();
         const float* xp = p.X + ld_row * p.ldx + 4 * lg;
 #pragma unroll
@@ -199,57 +205,49 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
         FW_BARRIER();                                       // b1 is in LDS
     }
 
-    // ---- GEMM1: hidden chunks c = wave, wave + 8, ...: four partial chains over the 16 k-slabs, as ffn.hip's FFN_MM_A
     f32x4w r0 = xr[0], r1 = xr[1];                          // the block input of this wave's two output tiles (residual)
 #pragma unroll
     for (int g = 1; g < 8; ++g)
         if (wave == g) { r0 = xr[2 * g]; r1 = xr[2 * g + 1]; }
-    for (int i = 0; i < n1c; ++i) {
-        const int c = wave + 8 * i;
-        const bool last = i + 1 >= n1c;                     // the look-ahead of the last chunk's second half: GEMM2's first slabs
+    f32x4w y0 = f32x4w{0.f, 0.f, 0.f, 0.f}, y1 = y0;
+    for (int s = 0; s < npass; ++s) {
+        // ---- GEMM1 block: hidden chunk c = wave + 8 s: four partial chains over the 16 k-slabs, as ffn.hip's FFN_MM_A
+        const int c = wave + FW_PASS * s;
         f32x4w hp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) hp[r] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            FW_STEP_BEGIN((2 * u + 2) & 7, (2 * u + 3) & 7);
+            FW_STEP_BEGIN(u);
 #pragma unroll
             for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c0[r], xr[2 * u][r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c1[r], xr[2 * u + 1][r]);
-            if (u < 4) { FW_STEP_END(srcB(i, 2 * u + 8), srcB(i, 2 * u + 9), (2 * u) & 7, (2 * u + 1) & 7); }
-            else {
-                const float* s0 = last ? srcC(u - 4, 0) : srcB(i + 1, 2 * u - 8);
-                const float* s1 = last ? srcC(u - 4, 1) : srcB(i + 1, 2 * u - 7);
-                FW_STEP_END(s0, s1, (2 * u) & 7, (2 * u + 1) & 7);
-            }
+            FW_STEP_END(srcC(FW_PASS * s + u, 0), srcC(FW_PASS * s + u, 1), u);       // this pass's GEMM2 block
         }
         f32x4w h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + *reinterpret_cast<const f32x4w*>(B1 + 16 * c + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
-        *reinterpret_cast<f32x4w*>(HS + (size_t)c * 256 + lane * 4) = h;        // k slot lg of step r <-> hidden unit 16 c + 4 lg + r
-    }
-    FW_BARRIER();                                           // the hidden tile is complete
-
-    // ---- GEMM2: output tiles 2 w, 2 w + 1 over all hidden chunks in order, as ffn.hip's FFN_MM_Y
-    const int t0 = 2 * wave;
-    f32x4w y0 = f32x4w{0.f, 0.f, 0.f, 0.f}, y1 = y0;
-    for (int cb = 0; cb < nc; cb += 4) {
+        *reinterpret_cast<f32x4w*>(HS + wave * 256 + lane * 4) = h;        // k slot lg of step r <-> hidden unit 16 c + 4 lg + r
+        FW_BARRIER();                                       // the pass's hidden tiles are complete
+        // ---- GEMM2 block: output tiles 2 w, 2 w + 1 over the pass's chunks in order, as ffn.hip's FFN_MM_Y
+        const bool more = s + 1 < npass;                    // past the end: dummy lines (keep the wait count exact)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4w hh = *reinterpret_cast<const f32x4w*>(HS + (size_t)(cb + j) * 256 + lane * 4);
-            FW_STEP_BEGIN((2 * j + 2) & 7, (2 * j + 3) & 7);
+        for (int j = 0; j < 8; ++j) {
+            const f32x4w hh = *reinterpret_cast<const f32x4w*>(HS + j * 256 + lane * 4);
+            FW_STEP_BEGIN(j);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 FW_MFMA(y0, c0[r], hh[r]);
                 FW_MFMA(y1, c1[r], hh[r]);
             }
-            const bool more = cb + 4 + j < nc;              // past the end: one dummy line (keeps the wait count exact)
-            const float* s0 = more ? srcC(cb + 4 + j, 0) : p.W2;
-            const float* s1 = more ? srcC(cb + 4 + j, 1) : p.W2;
-            FW_STEP_END(s0, s1, (2 * j) & 7, (2 * j + 1) & 7);
+            const float* s0 = more ? srcB(s + 1, 2 * j) : p.W2;
+            const float* s1 = more ? srcB(s + 1, 2 * j + 1) : p.W2;
+            FW_STEP_END(s0, s1, j);                         // the next pass's GEMM1 block
         }
+        FW_BARRIER();                                       // every wave is done reading the hidden tiles
     }
+    const int t0 = 2 * wave;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup's LDS allocation
     // ---- epilogue: + b2 + residual of this wave's tiles -> LDS, full rows back, LayerNorm (same routine, same layout)
     y0 = y0 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t0 + 4 * lg) + r0;
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
 #undef FW_BARRIER
 #undef FW_MFMA
 
-static size_t fw_lds_bytes(int ff) { return (size_t)(16 * FW_XLD + ff * 17 + 8 * FW_RING) * sizeof(float); }
+static size_t fw_lds_bytes(int ff) { return (size_t)(16 * FW_XLD + FW_PASS * 256 + ff + 8 * FW_RING) * sizeof(float); }
 
 bool ffn_wide_supported(int ff) { return ff >= 128 && ff % 128 == 0 && fw_lds_bytes(ff) <= 160 * 1024; }
 

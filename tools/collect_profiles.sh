@@ -66,6 +66,18 @@ python3 tools/rocpd_summary.py $out/prof_${tag}_ragged/t_results.db $win --gaps 
 rm -rf $out/lat
 rocprofv3 --kernel-trace -d $out/lat -o t -- python3 tools/latency_bench.py 1x1 > $out/lat.log 2>&1
 python3 tools/latency_trace.py $out/lat/t_results.db > $out/${tag}_latency_trace.txt 2>&1
+# (10) the reference's own entry (INTEGRATION Option A): CONE.forward + forward_clip_matching on the 640-window padded batch
+rm -rf $out/dropin
+rocprofv3 --kernel-trace --stats -d $out/dropin -o t -- python3 tools/dropin_bench.py dropin 20 > $out/${tag}_dropin.json 2> $out/dropin.log
+python3 tools/dropin_trace.py $out/dropin/t_results.db scan_lengths_kernel 6 > $out/${tag}_dropin_trace.txt 2>&1
+# (11) rank 0's share of the 8-rank window-sharded split (no collective), one step in flight: the launch sequence of one step
+rm -rf $out/proxy8
+rocprofv3 --kernel-trace -d $out/proxy8 -o t -- python3 tools/proxy_bench.py 8 0 10 > $out/${tag}_proxy8.json 2> $out/proxy8.log
+python3 tools/step_trace.py $out/proxy8/t_results.db > $out/${tag}_proxy8_trace.txt 2>&1
+python3 tools/rocpd_summary.py $out/proxy8/t_results.db 60 > $out/${tag}_proxy8_kernel_stats.csv 2>> $out/proxy8.log
+# (12) other slot counts / pre-norm: ms per step
+python3 tools/slots_step.py 5 10 8 3 16 > $out/${tag}_slots_step.txt 2>&1
+python3 tools/prenorm_step.py > $out/${tag}_prenorm_step.txt 2>&1
 # the bench line last: roofline.traffic is read from profiles/<tag>_pmc_*.json of THIS collection
 cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv $out/${tag}_pmc_prefilter.json $out/${tag}_pmc_prefilter_counters.csv profiles/
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
@@ -75,4 +87,4 @@ mkdir -p $out/${tag}_profiles
 cp $out/${tag}_*.csv $out/${tag}_*.json $out/${tag}_*.txt $out/${tag}_profiles/ 2>/dev/null
 rm -rf $out/prof_$tag $out/prof_${tag}_step $out/prof_${tag}_split $out/pmc_fetch $out/pmc_write $out/pmc_mfma \
        $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf $out/pmc_inst $out/pmc_coexec $out/pmc_fetch_dc \
-       $out/prof_${tag}_ragged $out/lat
+       $out/prof_${tag}_ragged $out/lat $out/dropin $out/proxy8
