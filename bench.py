@@ -459,6 +459,10 @@ def bench_dropin_forward(model, store, opt, arena_exec_tflops, steps=20, warmup=
     rec = collect_profile()
     lib.cone_prof_enable(0)
     roof, kern = roofline_from_profile(rec)
+    if roof:        # the committed counter table is per launch of the 20 000-window STEP: not this batch's launches
+        for k in [k for k in roof if k.startswith("traffic")]:
+            roof.pop(k)
+        roof["traffic"] = None
     vl, tl = wt["vid_len"].cpu().numpy(), wt["txt_len"].cpu().numpy()
     ex = executed_mfma_flops(rec, vl, tl, opt, steps)
     etf = ex["total"] / (dt * steps) / 1e12         # FLOPs of the recorded pass = FLOPs of the timed pass (same batch)

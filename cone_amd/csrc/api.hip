@@ -688,9 +688,9 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     cone_layer0 eff;
     l0 = effective_l0(m, l0, Lv_max, &eff);
     const bool caches = l0 && l0->qkv_vid;
-    if (caches)
+    if (l0)     // (the handle's own tables or the caller's: either must cover the longest window of the call)
         CONE_REQUIRE(l0->pos_qk && l0->max_v_l >= Lv_max,
-                     "forward: layer-0 cache incomplete or built for a shorter window (%d < %d)", l0->max_v_l, Lv_max);
+                     "forward: position tables / layer-0 cache built for a shorter window (%d < %d clips)", l0->max_v_l, Lv_max);
     const FwdPlan plan = plan_of(m, l0, Lmax);
     Carver c(ws, ws_bytes);
     FwdBuffers f;

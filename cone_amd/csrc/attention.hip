@@ -559,10 +559,16 @@ int launch_small_attn(const float* Q, int ldq, const float* K, int ldk, const fl
     CONE_REQUIRE(nq >= 1 && nq <= 16, "decoder attention: num_queries=%d not in [1,16]", nq);
     CONE_REQUIRE(Lmax <= kSmallMaxKeys, "decoder attention: %d keys > %d", Lmax, kSmallMaxKeys);
     if (B <= 0) return 0;
-    if (!off && nq == 5 && (ldq | ldk | ldv | ldo) % 4 == 0) {     // self-attention over the slots, the shipped slot count
-        hipLaunchKernelGGL(dec_self_attn_kernel<5>, dim3((B + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, B);
-        CONE_LAUNCH_CHECK();
-        return 0;
+    if (!off && (ldq | ldk | ldv | ldo) % 4 == 0) {     // self-attention over the slots: the shipped slot count (5) and the
+                                                        // other counts the folded cross-attention is instantiated for
+#define CONE_DSA(N)                                                                                                            \
+        if (nq == N) {                                                                                                         \
+            hipLaunchKernelGGL(dec_self_attn_kernel<N>, dim3((B + 3) / 4), dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, B); \
+            CONE_LAUNCH_CHECK();                                                                                               \
+            return 0;                                                                                                          \
+        }
+        CONE_DSA(5) CONE_DSA(3) CONE_DSA(8) CONE_DSA(10)
+#undef CONE_DSA
     }
     if (nq <= 8)
         hipLaunchKernelGGL(small_attn_kernel<8>, dim3(B, 8), dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, OUT, ldo, off, nq);

@@ -314,6 +314,21 @@ def test_bench_plain_entry_starts_its_own_ranks():
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_views_inherit_the_split_level_query_length_bound():
+    """Kernel forms are chosen from Lv_max + Lq_max; the Lq bound handed to the library is the SPLIT's longest query
+    (FeatureStore.max_tok_len), also for a pipeline chunk / rank shard whose own queries are all shorter: a window's bits must
+    not depend on the chunk it rides in (the rows-once cross-attention switches forms at 128 tokens)."""
+    from cone_amd import inference as inf
+    opt = make_opt("ego4d", topk_window=3, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(opt, 12, 2, seed=5, ctx_range=(30, 120), lq_range=(3, 9))
+    qf[ann[-1]["query_id"]]["token_features"] = np.ones((17, opt.t_feat_dim), np.float32)
+    store = inf.FeatureStore(opt, ann, vf, qf, device=torch.device("cpu"))
+    assert store.max_tok_len == 17
+    head = store.view(0, 8)
+    assert max(head.tok_len) <= 8 and head.max_tok_len == 17 and head.view(2, 4).max_tok_len == 17
+    assert inf.FeatureStore.subset(store, 4, 12).max_tok_len == 17
+
+
 def test_store_views_are_cached_and_follow_replaced_arenas():
     """FeatureStore.view: the same (lo, hi) view object step after step (its static index tables are uploaded once), rebuilt
     when the parent's arenas are REPLACED by new tensors (an in-place refill keeps the view: it aliases the arena)."""
