@@ -1839,6 +1839,87 @@ def test_config2_full_size():
     record_measured("config2_full_size", **{f"{k}.{kk}": vv for k, v in stats.items() for kk, vv in v.items()})
 
 
+def test_dropin_entry_runs_the_reference_loop_at_full_size():
+    """INTEGRATION Option A at BASELINE configs[1]'s size: the reference's own loop (cone/inference.py:40-84) -- batches of
+    eval_bsz 32 queries x top-20 windows, zero-padded and collated like start_end_collate, ``outputs = model(**model_inputs)``,
+    ``model.forward_clip_matching(...)``, row composition -- driven through cone_amd.model.CONE for three reference batches
+    (the first, one in the middle, the ragged last one of 8 queries) of the 1 000-query split: the composed window rows equal
+    the arena driver's rows for the same windows BIT FOR BIT (same kernels on the same rows), and the raw logits / spans /
+    saliency of the first batch are within 1e-4 of the oracle's CONE.forward on the same padded tensors."""
+    from cone_amd import inference as inf, ops
+    model, _, sd = get_model("ego4d", 0)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, eval_bsz=32)
+    ann, vf, qf = synth.make_dataset(opt, 1000, 50, seed=0)
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    win_idx = inf.prefilter(model, store, opt)
+    bp = inf.reference_batch_pad(store, opt, win_idx)
+    tok = ops.l2_normalize(store.tok_raw, 1e-5)
+    cls = ops.l2_normalize(store.cls_raw, 1e-5)
+    dev = store.device
+    for lo, hi in ((0, 32), (512, 544), (992, 1000)):
+        sub = inf.FeatureStore.subset(store, lo, hi)
+        wt = inf.window_table(sub, opt, win_idx[lo:hi].contiguous(), bp)
+        arena = inf.run_windows(model, sub, opt, wt)
+        # the reference's collate: pad to the batch's longest window / query, replicate the query's tokens into each window
+        vrow0, vlen = wt["vid_row0"].long(), wt["vid_len"].long()
+        trow0, tlen = wt["txt_row0"].long() + int(store.tok_off[lo]), wt["txt_len"].long()
+        Lv, Lq = int(vlen.max()), int(tlen.max())
+        assert Lv == int(wt["pad_len"].max())                               # the batch's own padding (hazard H3)
+        av, aq = torch.arange(Lv, device=dev)[None], torch.arange(Lq, device=dev)[None]
+        vmask, tmask = av < vlen[:, None], aq < tlen[:, None]
+        src_vid = (store.vid_raw[(vrow0[:, None] + av).clamp_(max=store.vid_raw.shape[0] - 1)] * vmask[..., None]).contiguous()
+        src_txt = (tok[(trow0[:, None] + aq).clamp_(max=tok.shape[0] - 1)] * tmask[..., None]).contiguous()
+        src_cls = cls[wt["cls_row"].long() + lo].contiguous()
+        out = model(src_txt=src_txt, src_txt_mask=tmask.float(), src_vid_motion=src_vid, src_vid_motion_mask=vmask.float())
+        match = model.forward_clip_matching(src_cls, src_vid, vmask.float(), proposal=out["pred_spans"])
+        rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, wt["vid_len"], wt["video_start"],
+                                opt.clip_length, not opt.no_sort_results)
+        for k in ("pred_logits", "pred_spans"):
+            assert torch.equal(out[k], arena[k]), (lo, k)
+        assert torch.equal(match, arena["matching"]) and torch.equal(rows, arena["rows"]), lo
+        if lo == 0:
+            c = lambda t: t.detach().cpu()
+            with torch.no_grad():
+                ref = O.cone_forward(sd, opt, c(src_txt), c(tmask.float()), c(src_vid), c(vmask.float()))
+            errs = dict(pred_logits=maxdiff(out["pred_logits"], ref["pred_logits"]),
+                        pred_spans=maxdiff(out["pred_spans"], ref["pred_spans"]),
+                        saliency=float((c(out["saliency_scores"]) - ref["saliency_scores"]).abs()[c(vmask)].max()))
+            record_measured("dropin_full_size_first_batch_vs_oracle", windows=int(vlen.shape[0]), **errs)
+            assert max(errs.values()) < TOL, errs
+
+
+def test_dropin_forward_captures_as_a_hip_graph():
+    """The reference's two calls (``model(**model_inputs)``, ``model.forward_clip_matching``) enqueue without a host round
+    trip and take every size from their arguments: after one eager warm-up (workspace) they capture as a hipGraph whose
+    replay on refilled input tensors gives the eager bits -- the serving form of the drop-in entry."""
+    model, opt, _ = get_model("ego4d", 0)
+    dev = _gpu()
+    lens_v, lens_q = [90, 45, 17, 90, 3, 61, 88, 90], [12, 5, 17, 9, 1, 20, 7, 13]
+    a = gi.stage_b_inputs(opt, 71, lens_v, lens_q)
+    b = gi.stage_b_inputs(opt, 72, lens_v, lens_q)                 # same shapes and masks, other features
+    t = lambda x: torch.from_numpy(x).to(dev)
+    ins = {k: t(a[k]) for k in ("src_txt", "txt_mask", "src_vid", "vid_mask", "src_cls_txt")}
+
+    def call():
+        o = model(ins["src_txt"], ins["txt_mask"], ins["src_vid"], ins["vid_mask"])
+        m = model.forward_clip_matching(ins["src_cls_txt"], ins["src_vid"], ins["vid_mask"], proposal=o["pred_spans"])
+        return o["pred_logits"], o["pred_spans"], o["saliency_scores"], m
+    eager_a = [x.clone() for x in call()]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = call()
+    for k in ("src_txt", "src_vid", "src_cls_txt"):
+        ins[k].copy_(t(b[k]))
+    g.replay()
+    torch.cuda.synchronize()
+    replay_b = [x.clone() for x in outs]
+    eager_b = call()
+    for x, y in zip(replay_b, eager_b):
+        assert torch.equal(x, y)
+    assert not torch.equal(replay_b[0], eager_a[0])                # the replay saw the new features
+
+
 def test_config2_ragged_full_size_is_sync_free_and_matches_oracle():
     """BASELINE configs[1] at full size on a RAGGED split -- 1 000 queries x 50 videos with ctx_l ~ U[200, 1500): videos of
     fewer than top-20 windows (ctx_l <= 810) sit next to long ones -- through the same sync-free path as the dense split
