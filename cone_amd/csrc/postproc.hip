@@ -153,8 +153,11 @@ __global__ __launch_bounds__(256) void fuse_nms_kernel(const T* __restrict__ can
     const int nu = s_nu;
 
     // 4. per score type: stable descending order of the unique entries, truncate, NMS
+    // gridDim.y == 3 (few queries: the launch is latency-bound): the three score types of a query run in three workgroups,
+    // each repeating steps 1 - 3 for itself (the same arithmetic: the same outputs as one workgroup walking all three)
     const int order[3] = {2, 0, 1};  // fused, proposal, matching  (cone/inference.py:152-164)
-    for (int t = 0; t < 3; ++t) {
+    const int t_lo = gridDim.y == 3 ? (int)blockIdx.y : 0, t_hi = gridDim.y == 3 ? t_lo + 1 : 3;
+    for (int t = t_lo; t < t_hi; ++t) {
         const double* val = c_val[order[t]];
         for (int u = tid; u < nu; u += 256) uval[u] = val[u_last[u]];
         __syncthreads();
@@ -272,7 +275,10 @@ static int fuse_nms_launch(const T* cand, const int64_t* cand_off, const int32_t
                  cone::kMaxCand);
     CONE_REQUIRE(max_after >= 1 && max_after <= cone::kMaxCand && max_before >= 1, "fuse_nms: bad limits");
     if (nq <= 0) return 0;
-    hipLaunchKernelGGL(cone::fuse_nms_kernel<T>, dim3(nq), dim3(256), 0, (hipStream_t)stream, cand, cand_off, n_valid, nq,
+    // up to 128 queries (one workgroup each would leave most of the chip idle and the launch bound by ONE workgroup's serial
+    // walk over the three score types): a workgroup per (query, score type).  The outputs do not depend on the choice
+    const unsigned ty = nq <= 128 ? 3u : 1u;
+    hipLaunchKernelGGL(cone::fuse_nms_kernel<T>, dim3(nq, ty), dim3(256), 0, (hipStream_t)stream, cand, cand_off, n_valid, nq,
                        n_max, nms_thd, max_before, max_after, out_rows, out_n, out_idx);
     CONE_LAUNCH_CHECK();
     return 0;

@@ -308,15 +308,19 @@ class FeatureStore:
 
 # ------------------------------------------------------------------------------------ stage A
 @torch.no_grad()
-def prefilter(model, store: FeatureStore, opt, k=None):
+def prefilter(model, store: FeatureStore, opt, k=None, keep=None):
     """cone/inference.py:241-301.  Returns win_idx (nq, topk) int32 on device (-1 = no such window);
     ``k`` overrides opt.topk_window (the window-recall table ranks deeper than the model consumes).  Only the clip rows of
-    the videos ``store``'s queries refer to are normalised, adapted and scored (the whole arena for a whole split)."""
+    the videos ``store``'s queries refer to are normalised, adapted and scored (the whole arena for a whole split).
+    ``keep`` (a dict): receives ``cls_norm``, the normalised cls vectors stage B's matching reads too (dataloader :473 / :280:
+    the same vectors) -- one launch less per step."""
     plan = store.prefilter_plan()
     r0, r1 = plan["band"]
     vid_norm = ops.l2_normalize(store.vid_raw[r0:r1], 1e-5)   # PreFilteringDataset :459
     ctx = model.adapter_norm(vid_norm)                        # :254-258, all videos in one pass
     cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :473
+    if keep is not None:
+        keep["cls_norm"] = cls_norm
     win_idx, _, _ = ops.prefilter_batched(ctx, cls_norm, plan, opt.max_v_l, k or opt.topk_window)
     return win_idx
 
@@ -475,16 +479,18 @@ def project_video(model, store: FeatureStore, row_range=None):
 
 
 @torch.no_grad()
-def project_features(model, store: FeatureStore, video=None):
+def project_features(model, store: FeatureStore, video=None, cls_norm=None):
     """Row-wise work shared by every window that contains a clip and by all windows of a query
     (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors.  ``video`` =
-    project_video() of the arena ``store`` shares (computed once per split, reused by its views)."""
+    project_video() of the arena ``store`` shares (computed once per split, reused by its views); ``cls_norm`` = the
+    normalised cls vectors of ``store`` when the pre-filter of the same call already made them."""
     video = video or project_video(model, store)
     tok = store.tok_raw
     if not (store.tok_normalized or getattr(store.opt, "no_norm_tfeat", False)):
         tok = ops.l2_normalize(tok, 1e-5)                                   # dataloader :277-278 (normalize_t)
     tproj = model.project(1, tok)
-    cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :280
+    if cls_norm is None:
+        cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :280
     feats = dict(vproj=video["vproj"], vid_base=video["vid_base"], tproj=tproj, cls_norm=cls_norm)
     if "l0_vid" in video:
         feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=model.layer0_rows(tproj), max_v_l=store.opt.max_v_l)
@@ -662,10 +668,11 @@ def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=Non
     ``batch_pad`` / ``video``: results of prefilter / reference_batch_pad / project_video on the split ``store``
     was cut from (a view shares them instead of recomputing them over the whole arena).  Nothing in here synchronises
     with the device or reads a result back, whatever the video lengths (``Selection``)."""
+    keep = {}
     if win_idx is None:
-        win_idx = prefilter(model, store, opt)
+        win_idx = prefilter(model, store, opt, keep=keep)
     wt = window_table(store, opt, win_idx, batch_pad)
-    res = run_windows(model, store, opt, wt, project_features(model, store, video))
+    res = run_windows(model, store, opt, wt, project_features(model, store, video, keep.get("cls_norm")))
     rows = res["rows"]
     cand, cand_off, n_valid, n_max = candidate_lists(rows, store, opt, win_idx.shape[1])
     out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms,

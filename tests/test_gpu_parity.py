@@ -796,6 +796,12 @@ def test_fuse_nms_random_batches_bit_exact(seed):
                 ref = O.post_processing_mr_nms(opt, rd, idx)
                 got = out[t, q, :int(cnt[t, q])].cpu().tolist()
                 assert got == ref, (seed, thd, mb, ma_, q, t)
+        # the launch runs a workgroup per (query, score type) up to 128 queries and one per query above: the same lists tiled to
+        # 192 queries must come out identical, element for element
+        out3, cnt3, idx3 = ops.fuse_nms(cd.repeat(3, 1, 1), nvd.repeat(3), thd, mb, ma_)
+        o1, c1, i1 = ops.fuse_nms(cd, nvd, thd, mb, ma_)
+        assert torch.equal(out3[:, :nq], o1) and torch.equal(cnt3[:, :nq], c1) and torch.equal(idx3[:, :nq], i1)
+        assert torch.equal(out3[:, 2 * nq:], o1)
 
 
 def test_compose_rows_matches_torch_arithmetic():
