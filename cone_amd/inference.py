@@ -465,35 +465,48 @@ def window_table(store: FeatureStore, opt, win_idx, batch_pad=None):
 
 # ------------------------------------------------------------------------------------ stage B
 @torch.no_grad()
-def project_video(model, store: FeatureStore, row_range=None):
+def project_video(model, store: FeatureStore, row_range=None, ws=None):
     """Clip-side row work shared by every window that contains a clip: the input projection of each clip once
     (raw features: hazard H2) and, with the layer-0 cache, its first-layer q|k|v rows + the static position
     tables.  ``row_range`` = (r0, r1) restricts it to arena rows [r0, r1) (a rank that only runs the windows of
     some videos); ``vid_base`` is what window rows must be rebased by."""
     r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
-    vproj = model.project(0, store.vid_raw[r0:r1])
+    vproj = model.project(0, store.vid_raw[r0:r1], ws=ws)
     out = dict(vproj=vproj, vid_base=r0)
     if getattr(store.opt, "layer0_cache", True):
-        out["l0_vid"] = model.layer0_rows(vproj)      # (the position tables are the model handle's own)
+        out["l0_vid"] = model.layer0_rows(vproj, ws=ws)      # (the position tables are the model handle's own)
     return out
 
 
 @torch.no_grad()
-def project_features(model, store: FeatureStore, video=None, cls_norm=None):
+def project_text(model, store: FeatureStore, ws=None):
+    """Text-side row work shared by all windows of a query: normalised tokens, their input projection and --
+    with the layer-0 cache -- their first-layer q|k|v rows."""
+    tok = store.tok_raw
+    if not (store.tok_normalized or getattr(store.opt, "no_norm_tfeat", False)):
+        tok = ops.l2_normalize(tok, 1e-5)                                   # dataloader :277-278 (normalize_t)
+    tproj = model.project(1, tok, ws=ws)
+    out = dict(tproj=tproj)
+    if getattr(store.opt, "layer0_cache", True):
+        out["l0_txt"] = model.layer0_rows(tproj, ws=ws)
+    return out
+
+
+@torch.no_grad()
+def project_features(model, store: FeatureStore, video=None, cls_norm=None, text=None):
     """Row-wise work shared by every window that contains a clip and by all windows of a query
     (SURVEY.md H12): input projections of each clip / text token once, normalised cls vectors.  ``video`` =
     project_video() of the arena ``store`` shares (computed once per split, reused by its views); ``cls_norm`` = the
     normalised cls vectors of ``store`` when the pre-filter of the same call already made them."""
     video = video or project_video(model, store)
-    tok = store.tok_raw
-    if not (store.tok_normalized or getattr(store.opt, "no_norm_tfeat", False)):
-        tok = ops.l2_normalize(tok, 1e-5)                                   # dataloader :277-278 (normalize_t)
-    tproj = model.project(1, tok)
+    text = text or project_text(model, store)
+    tproj = text["tproj"]
     if cls_norm is None:
         cls_norm = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)     # :280
     feats = dict(vproj=video["vproj"], vid_base=video["vid_base"], tproj=tproj, cls_norm=cls_norm)
     if "l0_vid" in video:
-        feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=model.layer0_rows(tproj), max_v_l=store.opt.max_v_l)
+        feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=text["l0_txt"] if "l0_txt" in text else model.layer0_rows(tproj),
+                           max_v_l=store.opt.max_v_l)
     return feats
 
 
@@ -662,17 +675,39 @@ def candidate_lists(rows, store: FeatureStore, opt, K: int):
 
 
 @torch.no_grad()
-def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=None, video=None):
+def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=None, video=None, concurrent=False):
     """Stages A->C on the device only: returns the kept rows per query as tensors
     (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables.  ``win_idx`` /
     ``batch_pad`` / ``video``: results of prefilter / reference_batch_pad / project_video on the split ``store``
     was cut from (a view shares them instead of recomputing them over the whole arena).  Nothing in here synchronises
-    with the device or reads a result back, whatever the video lengths (``Selection``)."""
+    with the device or reads a result back, whatever the video lengths (``Selection``).
+
+    ``concurrent`` (the latency form: a split of a few queries, whose launches leave most of the chip idle): the three
+    independent fronts of a step -- the pre-filter (stage A), the clip-side projections, the text-side projections -- are
+    FORKED onto the current stream and two side streams of the model (each with its own scratch) and joined ahead of the
+    window model; the same kernels on the same data, hence the same bits.  Captured into a hipGraph (``opt.hip_graph``) the
+    fork becomes three parallel branches of the graph: the front's critical path is its longest branch, not their sum."""
     keep = {}
+    text = None
+    fork = concurrent and win_idx is None and video is None and store.vid_raw.is_cuda
+    if fork:
+        cur = torch.cuda.current_stream()
+        (s1, ws1), (s2, ws2) = model.side(0), model.side(1)
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            video = project_video(model, store, ws=ws1)
+        with torch.cuda.stream(s2):
+            text = project_text(model, store, ws=ws2)
     if win_idx is None:
         win_idx = prefilter(model, store, opt, keep=keep)
     wt = window_table(store, opt, win_idx, batch_pad)
-    res = run_windows(model, store, opt, wt, project_features(model, store, video, keep.get("cls_norm")))
+    if fork:
+        cur.wait_stream(s1); cur.wait_stream(s2)
+        if not torch.cuda.is_current_stream_capturing():            # (a capture's blocks live in the graph's own pool)
+            for t in list(video.values()) + list(text.values()):   # made on a side stream, consumed on this one
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+    res = run_windows(model, store, opt, wt, project_features(model, store, video, keep.get("cls_norm"), text))
     rows = res["rows"]
     cand, cand_off, n_valid, n_max = candidate_lists(rows, store, opt, win_idx.shape[1])
     out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms,
@@ -816,14 +851,16 @@ def _graph_replay(model, store: FeatureStore, opt):
     key = _graph_key(model, opt)
     hit = cache.get(key)
     if hit is None:
-        device_pipeline(model, store, opt)              # warm-up: workspace, static tables, kernel attributes
+        # a split of a few queries is latency-bound: its three independent fronts become parallel branches of the graph
+        fork = len(store.ann) <= int(getattr(opt, "graph_fork_queries", 64))
+        device_pipeline(model, store, opt, concurrent=fork)     # warm-up: workspaces, kernel attributes
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            dp = device_pipeline(model, store, opt)
+            dp = device_pipeline(model, store, opt, concurrent=fork)
         # everything the captured launches point at must outlive the graph: the model (weights, position tables) and the
         # workspace buffer of THIS capture (the model's grow-only workspace may be replaced by a larger one later)
-        hit = cache[key] = (g, dp, model, model._ws.buf)
+        hit = cache[key] = (g, dp, model, model._ws.buf, [w.buf for _, w in getattr(model, "_side", None) or []])
     hit[0].replay()
     return dict(hit[1])
 

@@ -249,13 +249,21 @@ class CONE:
                                          ws.numel(), _lib.stream()))
         return out
 
-    def project(self, which: int, rows):
-        """input_vid_proj (which=0) / input_txt_proj (which=1) on (n, din) rows -> (n, d)."""
+    def side(self, i: int):
+        """(stream, Workspace) of concurrent branch ``i`` of a forked step (inference.device_pipeline(concurrent=True)): the
+        branches of a step run on their own HIP streams and MUST NOT share scratch with the main branch."""
+        if getattr(self, "_side", None) is None:
+            self._side = [(torch.cuda.Stream(), Workspace()) for _ in range(2)]
+        return self._side[i]
+
+    def project(self, which: int, rows, ws=None):
+        """input_vid_proj (which=0) / input_txt_proj (which=1) on (n, din) rows -> (n, d).  ``ws``: the scratch to use (default:
+        the model's own; a concurrent branch passes its own)."""
         lib, h = _lib.load(), self._h()
         x = self._f32(rows)
         out = torch.empty(x.shape[0], self.hidden_dim, device=x.device)
         nbytes = lib.cone_project_workspace(h, which, x.shape[0])
-        ws = self._ws.get(nbytes, x.device)
+        ws = (ws or self._ws).get(nbytes, x.device)
         _lib.check(lib.cone_project_tokens(h, which, _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.ptr(ws),
                                            ws.numel(), _lib.stream()))
         return out
@@ -265,13 +273,13 @@ class CONE:
         _lib.check(_lib.load().cone_model_set_option(self._h(), name.encode(), int(value)))
         return self
 
-    def layer0_rows(self, proj_rows):
+    def layer0_rows(self, proj_rows, ws=None):
         """First encoder layer's in_proj hoisted out of the window loop: q|k|v rows once per projected clip /
         text token (cone_layer0_project)."""
         lib, h = _lib.load(), self._h()
         qkv = torch.empty(proj_rows.shape[0], 3 * self.hidden_dim, device=proj_rows.device)
         nbytes = lib.cone_layer0_project_workspace(h, proj_rows.shape[0])        # (--pre_norm: norm1 of the rows first)
-        ws = self._ws.get(nbytes, proj_rows.device) if nbytes else None
+        ws = (ws or self._ws).get(nbytes, proj_rows.device) if nbytes else None
         _lib.check(lib.cone_layer0_project(h, _lib.ptr(proj_rows), proj_rows.shape[0], _lib.ptr(qkv), _lib.ptr(ws),
                                            ws.numel() if ws is not None else 0, _lib.stream()))
         return qkv
