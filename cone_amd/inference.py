@@ -42,6 +42,16 @@ logger = logging.getLogger(__name__)
 
 
 # ------------------------------------------------------------------------------------ data
+class AnnList(list):
+    """The annotation rows of a store: a list that can carry its own derived metadata (the parsed submission keys), so that
+    nothing about it has to be cached in a module-level table keyed by ``id()``."""
+    __slots__ = ("_ego4d_keys",)
+
+    def __getitem__(self, i):
+        r = list.__getitem__(self, i)
+        return AnnList(r) if isinstance(i, slice) else r
+
+
 class FeatureStore:
     """Device-resident features of one evaluation split (replaces PreFilteringDataset +
     StartEndDataset of cone/ego4d_mad_dataloader.py for the eval path)."""
@@ -55,7 +65,7 @@ class FeatureStore:
         a second time."""
         self.opt = opt
         self.tok_normalized, self.cls_normalized = bool(tok_normalized), bool(cls_normalized)
-        self.ann = list(annotations)
+        self.ann = AnnList(annotations)
         if opt.data_ratio != 1:
             self.ann = self.ann[:int(len(self.ann) * opt.data_ratio)]   # dataloader :116-121
         dev = device or torch.device("cuda", torch.cuda.current_device())
@@ -280,7 +290,7 @@ class FeatureStore:
         st.tok_normalized = st.cls_normalized = False
         dev = device or torch.device("cuda", torch.cuda.current_device())
         st.device = dev
-        st.ann = list(head["ann"])
+        st.ann = AnnList(head["ann"])
         nq = len(st.ann) if opt.data_ratio == 1 else int(len(st.ann) * opt.data_ratio)
         st.ann = st.ann[:nq]
         st.clip_ids = list(head["clip_ids"])
@@ -735,22 +745,20 @@ def format_results(ann, opt, rows, n, skeletons=None):
         return _format_results(ann, opt, rows, n, skeletons)
 
 
-_EGO4D_KEYS = {}        # id(annotation list) -> (the list, parsed keys): the keys depend on the annotation file only
-
-
 def _ego4d_keys(ann):
-    hit = _EGO4D_KEYS.get(id(ann))
-    if (hit is not None and hit[0] is ann and len(hit[1]) == len(ann) and len(ann)
-            and hit[2] == (ann[0]["query_id"], ann[-1]["query_id"])):       # the same list object, not edited since
+    """(query_idx, annotation_uid, clip_uid) of every row (cone/inference.py:133-140).  They depend on the annotation rows
+    only: a store's own list (``AnnList``) keeps them (checked against its length and end points, in case it was edited)."""
+    stamp = (len(ann), ann[0]["query_id"], ann[-1]["query_id"]) if len(ann) else (0, None, None)
+    hit = getattr(ann, "_ego4d_keys", None) if isinstance(ann, AnnList) else None
+    if hit is not None and hit[0] == stamp:
         return hit[1]
     keys = []
-    for meta in ann:                                                # cone/inference.py:133-140
+    for meta in ann:
         parts = meta["query_id"].split("_")
         assert len(parts) == 2
         keys.append((int(parts[1]), parts[0], meta["clip_id"]))
-    if len(_EGO4D_KEYS) > 64:
-        _EGO4D_KEYS.clear()
-    _EGO4D_KEYS[id(ann)] = (ann, keys, (ann[0]["query_id"], ann[-1]["query_id"]) if len(ann) else None)
+    if isinstance(ann, AnnList):
+        ann._ego4d_keys = (stamp, keys)
     return keys
 
 

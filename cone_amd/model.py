@@ -20,6 +20,9 @@ import torch
 from . import _lib
 from .synth import state_dict_spec
 
+import os as _os
+
+_CHECK_MASKS = _os.environ.get("CONE_AMD_CHECK_MASKS", "0") == "1"
 _TXT_POS_PREFIX = "txt_position_embed."  # present in checkpoints, read only with --use_txt_pos
 
 
@@ -182,8 +185,16 @@ class CONE:
 
     @staticmethod
     def _lengths(mask):
-        """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths."""
-        return mask.to(torch.float32).sum(dim=1).to(torch.int32).contiguous()
+        """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths.  The reference's collate
+        (pad_sequences_1d) only ever produces PREFIX masks and the packed kernels take lengths; a mask with holes is not
+        representable.  ``CONE_AMD_CHECK_MASKS=1`` verifies it (one device round trip per call) and raises ValueError."""
+        m = mask.to(torch.float32)
+        n = m.sum(dim=1).to(torch.int32).contiguous()
+        if _CHECK_MASKS:
+            ar = torch.arange(m.shape[1], device=m.device)[None]
+            if not bool(((ar < n[:, None]) == (m != 0)).all()):
+                raise ValueError("CONE.forward takes prefix masks (1 ... 1 0 ... 0), as the reference's collate produces")
+        return n
 
     # ---- CONE.forward (cone/model.py:82-128) ----------------------------------------------------
     def forward(self, src_txt, src_txt_mask, src_vid_motion, src_vid_motion_mask, taps: bool = False):
