@@ -422,8 +422,8 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 //     turn, the layer's q|k|v (M, 768) + attention output (M, 256) and then the FFN hidden rows -- q|k|v are dead
 //     once the attention has run, its output once out_proj has, and FFN1 writes only after that: 4 * (2 * 256 +
 //     max(ff, 1024)) = 6 KiB per token row at ff = 1024;
-//   legacy path (no cache: cone_forward_windows, and the A/B switches of the parity tests): additionally POS and
-//     XP = X + POS, and the stacked decoder K / V rows when the cross-attention fold is off.
+//   general path (--use_txt_pos, and the A/B switches of the parity tests): additionally POS and XP = X + POS, and the
+//     stacked decoder K / V rows when the cross-attention fold is off.
 struct FwdBuffers {
     int* off; int* RIDX;
     float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
@@ -431,22 +431,22 @@ struct FwdBuffers {
 };
 struct FwdPlan { bool tables, fold; };
 // What a call runs on: the caller's cone_layer0 with the handle's position tables filled in where it brings none (ABI 6: a
-// NULL cone_layer0, or one with the row caches only, still takes the table path), or nothing for --use_txt_pos / --pre_norm
-// (the general path: the caches / tables assume a zero text position term and the post-norm layer order).
+// NULL cone_layer0, or one with the row caches only, still takes the table path), or nothing for --use_txt_pos (the general
+// path: the caches / tables assume a zero text position term) and for windows longer than the handle's tables cover.
 static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff) {
     if (m->txt_pos_emb) return nullptr;
     *eff = l0 ? *l0 : cone_layer0{};
     if (!eff->qkv_vid || !eff->qkv_txt) eff->qkv_vid = eff->qkv_txt = nullptr;
-    if (!eff->pos_rows || !eff->pos_qk) {
-        if (!m->tab_pos_rows || Lv_max > m->tab_max_v_l) return (eff->qkv_vid && eff->pos_qk) ? eff : nullptr;
+    if (!eff->pos_rows || !eff->pos_qk) {                   // no (complete) tables of the caller's: the handle's
+        if (Lv_max > m->tab_max_v_l) return nullptr;
         eff->pos_rows = m->tab_pos_rows; eff->pos_qk = m->tab_pos_qk; eff->max_v_l = m->tab_max_v_l;
     }
     return eff;
 }
-static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l0 */, int Lmax) {
+// have_tables / caches: what effective_l0 resolved to (position tables available; first-layer row caches given)
+static FwdPlan plan_for(const cone_model* m, bool have_tables, bool caches, int Lmax) {
     FwdPlan p;
-    const bool caches = l0 && l0->qkv_vid;
-    p.tables = l0 && l0->pos_rows && l0->pos_qk && m->opt_pos_tables && (!caches || m->opt_l0_gather);
+    p.tables = have_tables && m->opt_pos_tables && (!caches || m->opt_l0_gather);
     p.fold = m->opt_dec_fold >= 2 ? dec_cross_mfma_supported(m->nq, Lmax, p.tables)
                                   : (m->opt_dec_fold == 1 && dec_cross_supported(m->nq, Lmax));
     if (m->pre_norm) {  // the fused pre-norm path needs all of: tables, the fused layer tail, the matrix-core fold; else the
@@ -460,6 +460,9 @@ static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l
     // (parity tests) keeps meaning the whole general path
     if (!p.fold && !(m->opt_dec_fold && m->nq != 5)) p.tables = false;
     return p;
+}
+static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l0 */, int Lmax) {
+    return plan_for(m, l0 && l0->pos_rows && l0->pos_qk, l0 && l0->qkv_vid, Lmax);
 }
 static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const FwdPlan& p, FwdBuffers& f) {
     const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
@@ -1057,11 +1060,9 @@ extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad,
     Carver c(nullptr, ~(size_t)0);
     PaddedCarve p;
     carve_padded(m, c, B, Lv_pad, Lq_pad, caches, p);
-    cone_layer0 l0{};
-    if (caches) { l0.qkv_vid = l0.qkv_txt = reinterpret_cast<const float*>(16); }    // presence only: sizes the same plan
     cone_layer0 eff;
-    return c.cur + fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_of(m, effective_l0(m, caches ? &l0 : nullptr, Lv_pad, &eff),
-                                                               Lv_pad + Lq_pad));
+    const bool have_tables = effective_l0(m, nullptr, Lv_pad, &eff) != nullptr;
+    return c.cur + fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_for(m, have_tables, caches, Lv_pad + Lq_pad));
 }
 extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len, const float* txt,
                                     const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,

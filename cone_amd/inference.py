@@ -685,39 +685,21 @@ def candidate_lists(rows, store: FeatureStore, opt, K: int):
 
 
 @torch.no_grad()
-def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=None, video=None, concurrent=False):
+def device_pipeline(model, store: FeatureStore, opt, win_idx=None, batch_pad=None, video=None):
     """Stages A->C on the device only: returns the kept rows per query as tensors
     (rows (3, nq, max_after, 5) fp64, n (3, nq) int32) plus the intermediate tables.  ``win_idx`` /
     ``batch_pad`` / ``video``: results of prefilter / reference_batch_pad / project_video on the split ``store``
     was cut from (a view shares them instead of recomputing them over the whole arena).  Nothing in here synchronises
     with the device or reads a result back, whatever the video lengths (``Selection``).
 
-    ``concurrent`` (the latency form: a split of a few queries, whose launches leave most of the chip idle): the three
-    independent fronts of a step -- the pre-filter (stage A), the clip-side projections, the text-side projections -- are
-    FORKED onto the current stream and two side streams of the model (each with its own scratch) and joined ahead of the
-    window model; the same kernels on the same data, hence the same bits.  Captured into a hipGraph (``opt.hip_graph``) the
-    fork becomes three parallel branches of the graph: the front's critical path is its longest branch, not their sum."""
+    (Measured and not kept, round 5: forking the three independent fronts of a small split's step -- pre-filter, clip
+    projections, text projections -- onto side streams, i.e. parallel branches of its hipGraph: 0.589 against 0.591 ms per
+    single-query replay -- the runtime replays the branches one after the other.)"""
     keep = {}
-    text = None
-    fork = concurrent and win_idx is None and video is None and store.vid_raw.is_cuda
-    if fork:
-        cur = torch.cuda.current_stream()
-        (s1, ws1), (s2, ws2) = model.side(0), model.side(1)
-        s1.wait_stream(cur); s2.wait_stream(cur)
-        with torch.cuda.stream(s1):
-            video = project_video(model, store, ws=ws1)
-        with torch.cuda.stream(s2):
-            text = project_text(model, store, ws=ws2)
     if win_idx is None:
         win_idx = prefilter(model, store, opt, keep=keep)
     wt = window_table(store, opt, win_idx, batch_pad)
-    if fork:
-        cur.wait_stream(s1); cur.wait_stream(s2)
-        if not torch.cuda.is_current_stream_capturing():            # (a capture's blocks live in the graph's own pool)
-            for t in list(video.values()) + list(text.values()):   # made on a side stream, consumed on this one
-                if torch.is_tensor(t):
-                    t.record_stream(cur)
-    res = run_windows(model, store, opt, wt, project_features(model, store, video, keep.get("cls_norm"), text))
+    res = run_windows(model, store, opt, wt, project_features(model, store, video, keep.get("cls_norm")))
     rows = res["rows"]
     cand, cand_off, n_valid, n_max = candidate_lists(rows, store, opt, win_idx.shape[1])
     out_rows, out_n, out_idx = ops.fuse_nms(cand, n_valid, opt.nms_thd, opt.max_before_nms, opt.max_after_nms,
@@ -859,16 +841,14 @@ def _graph_replay(model, store: FeatureStore, opt):
     key = _graph_key(model, opt)
     hit = cache.get(key)
     if hit is None:
-        # a split of a few queries is latency-bound: its three independent fronts become parallel branches of the graph
-        fork = len(store.ann) <= int(getattr(opt, "graph_fork_queries", 64))
-        device_pipeline(model, store, opt, concurrent=fork)     # warm-up: workspaces, kernel attributes
+        device_pipeline(model, store, opt)              # warm-up: workspace, kernel attributes
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            dp = device_pipeline(model, store, opt, concurrent=fork)
+            dp = device_pipeline(model, store, opt)
         # everything the captured launches point at must outlive the graph: the model (weights, position tables) and the
         # workspace buffer of THIS capture (the model's grow-only workspace may be replaced by a larger one later)
-        hit = cache[key] = (g, dp, model, model._ws.buf, [w.buf for _, w in getattr(model, "_side", None) or []])
+        hit = cache[key] = (g, dp, model, model._ws.buf)
     hit[0].replay()
     return dict(hit[1])
 
@@ -895,6 +875,17 @@ class PendingSplit:
 
 def _to_pinned(t):
     return torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t, non_blocking=True)
+
+
+def _kept_to_pinned(rows, n):
+    """[rows, n] in pinned host memory, enqueued: one transfer when they share a buffer (ops.fuse_nms lays them out back to
+    back), else one each."""
+    buf = getattr(rows, "kept_buf", None)
+    if buf is None or buf.numel() != rows.numel() * 8 + n.numel() * 4:
+        return [_to_pinned(rows), _to_pinned(n)]
+    host = _to_pinned(buf)
+    R = rows.numel() * 8
+    return [host[:R].view(torch.float64).view(rows.shape), host[R:].view(torch.int32).view(n.shape)]
 
 
 def predict_split_async(model, store: FeatureStore, opt) -> PendingSplit:
@@ -930,7 +921,7 @@ def predict_split_async(model, store: FeatureStore, opt) -> PendingSplit:
             info = None
     # kept rows to pinned host memory behind an event per chunk (a graph replay's outputs are only valid until the next
     # replay: the copy is stream-ordered ahead of it)
-    pend = [(sub, dp, ([_to_pinned(dp["rows"]), _to_pinned(dp["n"])], torch.cuda.Event())) for sub, dp, _ in pend]
+    pend = [(sub, dp, (_kept_to_pinned(dp["rows"], dp["n"]), torch.cuda.Event())) for sub, dp, _ in pend]
     for _, _, (_, ev) in pend:
         ev.record()
     if info is None:

@@ -260,16 +260,9 @@ class CONE:
                                          ws.numel(), _lib.stream()))
         return out
 
-    def side(self, i: int):
-        """(stream, Workspace) of concurrent branch ``i`` of a forked step (inference.device_pipeline(concurrent=True)): the
-        branches of a step run on their own HIP streams and MUST NOT share scratch with the main branch."""
-        if getattr(self, "_side", None) is None:
-            self._side = [(torch.cuda.Stream(), Workspace()) for _ in range(2)]
-        return self._side[i]
-
     def project(self, which: int, rows, ws=None):
         """input_vid_proj (which=0) / input_txt_proj (which=1) on (n, din) rows -> (n, d).  ``ws``: the scratch to use (default:
-        the model's own; a concurrent branch passes its own)."""
+        the model's own)."""
         lib, h = _lib.load(), self._h()
         x = self._f32(rows)
         out = torch.empty(x.shape[0], self.hidden_dim, device=x.device)

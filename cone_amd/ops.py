@@ -153,9 +153,15 @@ def fuse_nms(cand: torch.Tensor, n_valid: torch.Tensor, nms_thd: float, max_befo
             raise ValueError("fuse_nms with cand_off takes a (rows, 4) matrix and the bound n_max")
     dev = cand.device
     # (the kernel writes every element: kept rows, zero rows / -1 past them, the counts -- no fill launches)
-    rows = torch.empty(3, nq, max_after, 5, dtype=torch.float64, device=dev)
-    n = torch.empty(3, nq, dtype=torch.int32, device=dev)
-    idx = torch.empty(3, nq, max_after, dtype=torch.int32, device=dev)
+    # rows | n | idx live in ONE buffer: a caller that ships the kept rows to the host copies rows + counts in one transfer
+    # (``rows.kept_buf``: the byte range of both)
+    R, N = 3 * nq * max_after * 5 * 8, 3 * nq * 4
+    N8 = (N + 7) // 8 * 8
+    buf = torch.empty(R + N8 + 3 * nq * max_after * 4, dtype=torch.uint8, device=dev)
+    rows = buf[:R].view(torch.float64).view(3, nq, max_after, 5)
+    n = buf[R:R + N].view(torch.int32).view(3, nq)
+    idx = buf[R + N8:].view(torch.int32).view(3, nq, max_after)
+    rows.kept_buf = buf[:R + N]
     fn = lib.cone_fuse_nms_f64 if cand.dtype == torch.float64 else lib.cone_fuse_nms
     _lib.check(fn(_lib.ptr(cand), _lib.ptr(cand_off, torch.int64), _lib.ptr(n_valid, torch.int32), nq, int(n_max), float(nms_thd), int(max_before),
                   int(max_after), _lib.ptr(rows), _lib.ptr(n), _lib.ptr(idx), _lib.stream()))

@@ -2482,14 +2482,6 @@ def test_hip_graph_replay_equals_eager_pipeline():
         got, info = inf.predict_split(model, store, gopt)
         assert got == eager
     assert len(store._graphs) == 1
-    # a split of a few queries is captured with its three fronts (pre-filter, clip projections, text projections) forked onto
-    # side streams = parallel branches of the graph; the same fork run eagerly gives the same rows
-    assert getattr(model, "_side", None) is not None
-    plain = inf.device_pipeline(model, store, opt)
-    forked = inf.device_pipeline(model, store, opt, concurrent=True)
-    torch.cuda.synchronize()
-    for k in ("rows", "n", "cand", "win_idx"):
-        assert torch.equal(plain[k], forked[k]), k
     # same shapes, other features: refill the arenas in place, replay
     ann2, vf2, qf2 = synth.make_dataset(opt, 3, 1, seed=6, ctx_range=(900, 901), lq_range=(12, 13))
     other = inf.FeatureStore(opt, ann2, vf2, qf2)
