@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "rows_chain.h"
 
 namespace cone {
 
@@ -76,6 +77,8 @@ struct cone_model {
     int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
                               // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
     int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
+    int opt_chain = 1;        // few rows: decoder.norm + class head + span MLP + span head, and the adapter pair of the proposal
+                              // matching, as ONE launch each (rows_chain.h: the same arithmetic, bit-identical); 0 = separate launches
     int opt_ffn_fused = 2;    // 1: linear1 + ReLU + linear2 + residual + LayerNorm as one kernel (ffn.hip); 2: the attention
                               // output projection + residual + LayerNorm ahead of it in the same kernel as well; 0: GEMMs
 };
@@ -815,6 +818,16 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     const bool fold = plan.fold;
     const bool want_aux = taps && (taps->hs || taps->aux_logits || taps->aux_spans);
     bool sal_done = false;
+    const int h0 = want_aux ? 0 : nd - 1;               // first decoder layer whose heads are needed
+    const int HT = (nd - h0) * T;
+    const size_t hoff = (size_t)h0 * T;
+    // only the last layer's heads wanted (the eval pipeline): they write straight into the caller's logits / spans; with the
+    // intermediate layers' too, all layers go to the workspace and the last layer's rows are copied out
+    float* LGo = want_aux ? f.LG + hoff * 2 : logits;
+    float* SPo = want_aux ? f.SP + hoff * 2 : spans;
+    // (the chain only where launch_gemm itself would run its 16-row form, and only on the automatic tile family: the A/B
+    // families walk k in other orders)
+    const bool heads_chain = m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T);
     if (!fold) {
         if (plan.tables) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s));
         GemmArgs g = G(m, f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
@@ -893,22 +906,36 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         }
         // decoder.norm + heads on an intermediate layer only feed aux_outputs / the hs tap (unused by inference,
         // cone/inference.py:54-59): computed on request only
-        if (l == nd - 1 || want_aux)
-            RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
-                                 256, s));
+        if (l == nd - 1 || want_aux) {
+            if (heads_chain) {
+                // few rows: decoder.norm -> class head, span MLP -> span head of THIS layer's rows in one launch (rows_chain.h);
+                // the normalised rows are written only when the hs tap asks for them
+                ChainArgs ca{};
+                ca.A = f.TGT; ca.lda = 256; ca.M = T; ca.n_stages = 3;
+                const size_t ro = (size_t)(l - h0) * T * 2;
+                ChainStage& c0 = ca.st[0];
+                c0.kind = 1; c0.ln_g = m->dec_norm.g; c0.ln_b = m->dec_norm.b;
+                c0.C = taps && taps->hs ? f.HS + (size_t)l * T * 256 : nullptr; c0.ldc = 256;
+                c0.hw = m->class_embed.w; c0.hb = m->class_embed.b; c0.hout = LGo + ro; c0.hld = 2; c0.hnout = 2; c0.hact = 0;
+                ChainStage& c1 = ca.st[1];
+                c1.kind = 0; c1.K = 256; c1.W = m->span[0].w; c1.bias = m->span[0].b; c1.flags = EPI_RELU;
+                ChainStage& c2 = ca.st[2];
+                c2.kind = 0; c2.K = 256; c2.W = m->span[1].w; c2.bias = m->span[1].b; c2.flags = EPI_RELU;
+                c2.hw = m->span[2].w; c2.hb = m->span[2].b; c2.hout = SPo + ro; c2.hld = 2; c2.hnout = 2; c2.hact = 1;
+                RUN(launch_rows_chain(ca, s));
+            } else {
+                RUN(launch_layernorm(f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
+                                     256, s));
+            }
+        }
     }
     // heads (cone/model.py:112-117); the last layer is the prediction
-    const int h0 = want_aux ? 0 : nd - 1;               // first decoder layer whose heads are needed
-    const int HT = (nd - h0) * T;
-    const size_t hoff = (size_t)h0 * T;
-    // only the last layer's heads wanted (the eval pipeline): they write straight into the caller's logits / spans; with the
-    // intermediate layers' too, all layers go to the workspace and the last layer's rows are copied out
-    float* LGo = want_aux ? f.LG + hoff * 2 : logits;
-    float* SPo = want_aux ? f.SP + hoff * 2 : spans;
-    RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, LGo, 2, HT, 2, 0, s));
-    RUN(launch_gemm(G(m, f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
-    RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
-    RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, SPo, 2, HT, 2, 1, s));
+    if (!heads_chain) {
+        RUN(launch_rowdot(f.HS + hoff * 256, 256, m->class_embed.w, m->class_embed.b, LGo, 2, HT, 2, 0, s));
+        RUN(launch_gemm(G(m, f.HS + hoff * 256, 256, m->span[0].w, 256, m->span[0].b, f.S1, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+        RUN(launch_gemm(G(m, f.S1, 256, m->span[1].w, 256, m->span[1].b, f.S2, 256, HT, nullptr, 256, 256, EPI_RELU), s));
+        RUN(launch_rowdot(f.S2, 256, m->span[2].w, m->span[2].b, SPo, 2, HT, 2, 1, s));
+    }
     const size_t last = (size_t)(nd - 1) * T * 2;
     if (want_aux) {
         CONE_CHECK_HIP(hipMemcpyAsync(logits, f.LG + last, (size_t)T * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1113,7 +1140,15 @@ extern "C" int cone_clip_matching_gathered(const cone_model* m, const float* cls
     if (!c.ok) { set_error("clip_matching: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     RUN(launch_proposal_mean(vid, vid_row0, vid_len, pad_len, spans, B, m->nq, dv, pf, s));
     const float* feat = pf;
-    if (m->has_adapter) {
+    if (m->has_adapter && dv == 256 && m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T)) {
+        ChainArgs ca{};     // few proposals: both adapter layers in one launch (rows_chain.h; the same arithmetic)
+        ca.A = pf; ca.lda = dv; ca.M = T; ca.n_stages = 2;
+        ca.st[0].kind = 0; ca.st[0].K = dv; ca.st[0].W = m->adapter[0].w; ca.st[0].bias = m->adapter[0].b; ca.st[0].flags = EPI_RELU;
+        ca.st[1].kind = 0; ca.st[1].K = 256; ca.st[1].W = m->adapter[1].w; ca.st[1].bias = m->adapter[1].b;
+        ca.st[1].flags = EPI_RESIDUAL; ca.st[1].R = pf; ca.st[1].ldr = dv; ca.st[1].C = pa; ca.st[1].ldc = dv;
+        RUN(launch_rows_chain(ca, s));
+        feat = pa;
+    } else if (m->has_adapter) {
         RUN(launch_gemm(G(m, pf, dv, m->adapter[0].w, dv, m->adapter[0].b, h, 256, T, nullptr, 256, dv, EPI_RELU), s));
         GemmArgs g = G(m, h, 256, m->adapter[1].w, 256, m->adapter[1].b, pa, dv, T, nullptr, dv, 256, EPI_RESIDUAL);
         g.R = pf; g.ldr = dv;
@@ -1165,6 +1200,7 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
         return 0;
     }
     if (!strcmp(name, "res_gather")) { m->opt_res_gather = value != 0; return 0; }
+    if (!strcmp(name, "rows_chain")) { m->opt_chain = value != 0; return 0; }
     if (!strcmp(name, "gemm")) {
         CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
         m->opt_gemm = value;

@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "rows_chain.h"
 
 namespace cone {
 
@@ -723,6 +724,176 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// rows_chain_kernel (rows_chain.h): up to four row-wise stages over the 16 rows of a workgroup, the rows on chip in between.
+// A GEMM stage is gemm_rows_small_kernel's body on operand slabs that the PREVIOUS stage left in LDS (instead of LDS-DMA from
+// global memory): the same accumulation chain -- for kt, for j: acc[t] = mfma(a[j], b[j], acc[t]) -- the same epilogue image
+// and per-row code.  A LayerNorm stage is layernorm_kernel's arithmetic on a row held as one float4 per lane (wave w owns
+// rows 2w, 2w + 1, exactly the rows it walks in a GEMM stage's epilogue); a head is rowdot_kernel's dot on those registers.
+// Between stages the rows go back to LDS in the operand-slab format (row r, column c -> slab c / 16, 16-B chunk
+// ((c / 4) % 4) ^ swz16(r)).  Stores and parameter loads count in vmcnt like the weight DMAs: every GEMM stage drains the
+// queue before it starts its counted stream.
+__device__ __forceinline__ void chain_rows_to_slabs(float* As, int r, int c4, const float4& x) {
+    *reinterpret_cast<float4*>(As + (c4 >> 4) * 256 + r * 16 + ((((c4 >> 2) & 3) ^ swz16(r)) << 2)) = x;
+}
+
+__global__ __launch_bounds__(512, 2) void rows_chain_kernel(ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int M = p.M;
+    const int m0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int K0 = p.st[0].kind == 0 ? p.st[0].K : 256;
+    const int a_floats = 16 * K0 > 16 * RS_EP_LD ? 16 * K0 : 16 * RS_EP_LD;
+    float* As = smem;                                             // operand slabs of the current GEMM stage's input
+    float* ep = smem + a_floats;                                  // [16][RS_EP_LD] epilogue image (its own region here)
+    float* ring = ep + 16 * RS_EP_LD + wave * RS_RING;
+    const int drow = lane >> 2;
+    const int dq = ((lane & 3) ^ swz16(drow)) << 2;
+    const int rdo = li * 16 + ((lg ^ swz16(li)) << 2);            // operand read: row li, chunk lg
+    const int c4 = lane * 4;
+    float4 x[2];                                                  // this wave's rows 2w, 2w + 1 (columns c4 .. c4 + 3)
+    bool in_regs = false;                                         // x holds the current rows (else: As holds them as slabs)
+
+    if (p.st[0].kind == 0) {                                      // the input as operand slabs, by LDS-DMA (as the small form)
+        const int nk0 = K0 / 16;
+        const int arow = min(m0 + drow, M - 1);
+        const float* __restrict__ asrc = p.A + (size_t)arow * p.lda + dq;
+        for (int kt = wave; kt < nk0; kt += 8) GLDS16(asrc + 16 * kt, As + kt * 256);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const size_t m = (size_t)min(m0 + 2 * wave + k, M - 1);
+            x[k] = *reinterpret_cast<const float4*>(p.A + m * p.lda + c4);
+        }
+        in_regs = true;
+    }
+
+    for (int si = 0; si < p.n_stages; ++si) {
+        const ChainStage& st = p.st[si];
+        if (st.kind == 1) {
+            // ---- LayerNorm (layernorm_kernel, dim = 256: one float4 per lane)
+            const float4 gg = reinterpret_cast<const float4*>(st.ln_g)[lane];
+            const float4 bb = reinterpret_cast<const float4*>(st.ln_b)[lane];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float4 v = x[k];
+                float s = 0.f;
+                s += (v.x + v.y) + (v.z + v.w);
+                const float mean = wave_sum(s) / (float)256;
+                float q = 0.f;
+                {
+                    const float a = v.x - mean, bq = v.y - mean, cq = v.z - mean, d = v.w - mean;
+                    q += __builtin_fmaf(a, a, bq * bq) + __builtin_fmaf(cq, cq, d * d);
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)256 + 1e-5f);
+                float4 o;
+                o.x = __builtin_fmaf((v.x - mean) * rstd, gg.x, bb.x);
+                o.y = __builtin_fmaf((v.y - mean) * rstd, gg.y, bb.y);
+                o.z = __builtin_fmaf((v.z - mean) * rstd, gg.z, bb.z);
+                o.w = __builtin_fmaf((v.w - mean) * rstd, gg.w, bb.w);
+                x[k] = o;
+            }
+        } else {
+            // ---- GEMM stage: gemm_rows_small_kernel on the slabs in As
+            const int K = st.K, nk = K / 16;
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) chain_rows_to_slabs(As, 2 * wave + k, c4, x[k]);
+            }
+            const float* __restrict__ wsrc = st.W + (size_t)(32 * wave + drow) * K + dq;      // + 16 t * K + 16 kt
+            const size_t wt = (size_t)16 * K;
+            __builtin_amdgcn_sched_barrier(0);
+            if (si > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores / parameter loads of the stage before
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const bool live = kt < nk;
+                GLDS16(live ? wsrc + 16 * kt : st.W, ring + (2 * kt) * 256);
+                GLDS16(live ? wsrc + wt + 16 * kt : st.W, ring + (2 * kt + 1) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (stage 0: this wave's input slabs, older than the W slabs)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's rows are in the slabs
+            __builtin_amdgcn_s_barrier();                         // every wave's
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W slabs of k-step 0
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4a acc[2];
+            acc[0] = f32x4a{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+            f32x4a a = *reinterpret_cast<const f32x4a*>(As + rdo);
+            f32x4a b0 = *reinterpret_cast<const f32x4a*>(ring + rdo), b1 = *reinterpret_cast<const f32x4a*>(ring + 256 + rdo);
+            int slot = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int nslot = slot == 2 ? 0 : slot + 1;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                const int kn = kt + 1 < nk ? kt + 1 : kt;
+                const f32x4a an = *reinterpret_cast<const f32x4a*>(As + kn * 256 + rdo);
+                const f32x4a bn0 = *reinterpret_cast<const f32x4a*>(ring + (2 * nslot) * 256 + rdo);
+                const f32x4a bn1 = *reinterpret_cast<const f32x4a*>(ring + (2 * nslot + 1) * 256 + rdo);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool more = kt + 3 < nk;
+                GLDS16(more ? wsrc + 16 * (kt + 3) : st.W, ring + (2 * slot) * 256);
+                GLDS16(more ? wsrc + wt + 16 * (kt + 3) : st.W, ring + (2 * slot + 1) * 256);
+                a = an; b0 = bn0; b1 = bn1;
+                slot = nslot;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // accumulator (t, r) of lane (li, lg) = row 4 lg + r, column 32 wave + 16 t + li
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(4 * lg + r) * RS_EP_LD + 32 * wave + 16 * t + li] = acc[t][r];
+            __syncthreads();                                      // the image is complete; every wave is done with the slabs
+            const int flags = st.flags;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st.bias) bias4 = *reinterpret_cast<const float4*>(st.bias + c4);
+            float4 v[2], rr[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const size_t m = (size_t)min(m0 + 2 * wave + k, M - 1);
+                if (flags & EPI_RESIDUAL) rr[k] = *reinterpret_cast<const float4*>(st.R + m * st.ldr + c4);
+                v[k] = *reinterpret_cast<const float4*>(ep + (2 * wave + k) * RS_EP_LD + c4);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float4 xx = v[k];
+                xx.x += bias4.x; xx.y += bias4.y; xx.z += bias4.z; xx.w += bias4.w;
+                if (flags & EPI_RELU) { xx.x = fmaxf(xx.x, 0.f); xx.y = fmaxf(xx.y, 0.f); xx.z = fmaxf(xx.z, 0.f); xx.w = fmaxf(xx.w, 0.f); }
+                if (flags & EPI_RESIDUAL) { xx.x += rr[k].x; xx.y += rr[k].y; xx.z += rr[k].z; xx.w += rr[k].w; }
+                x[k] = xx;
+            }
+        }
+        in_regs = true;
+        // ---- the stage's outputs: rows, head
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = m0 + 2 * wave + k;
+            if (st.C && m < M) *reinterpret_cast<float4*>(st.C + (size_t)m * st.ldc + c4) = x[k];
+            if (st.hout) {
+                for (int n = 0; n < st.hnout; ++n) {
+                    const float4 xv = x[k];
+                    const float4 wv = reinterpret_cast<const float4*>(st.hw + n * 256)[lane];
+                    float s = __builtin_fmaf(xv.x, wv.x, xv.y * wv.y) + __builtin_fmaf(xv.z, wv.z, xv.w * wv.w);
+                    s = wave_sum(s) + st.hb[n];
+                    if (st.hact == 1) s = 1.0f / (1.0f + expf(-s));
+                    if (lane == 0 && m < M) st.hout[(size_t)m * st.hld + n] = s;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+
 // The small form streams every weight byte from L2 once per 16 rows: 8.7 us per 256 tiles at K = 256 (13.3 at K = 512), i.e.
 // tools/gemm_small_bench.py, N = 256, K = 256: 9 / 17.5 / 31 us at 4 096 / 8 192 / 16 384 rows against 38 - 41 us of the 128-row
 // tile, behind from ~20 000 rows (57 vs 46 us at 32 768); N = 768: 24 us at 4 096 rows (768 tiles) against 40, level at 8 192.
@@ -817,6 +988,37 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((gemm_f32_kernel<128, 128, false>), grid, dim3(256), 0, s, a);
         }
     }
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+bool rows_chain_supported(int M) { return M > 0 && (M + 15) / 16 <= RS_MAX_WGS; }
+
+int launch_rows_chain(const ChainArgs& a, hipStream_t s) {
+    CONE_REQUIRE(a.A && a.n_stages >= 1 && a.n_stages <= CHAIN_MAX_STAGES && a.lda % 4 == 0, "rows chain: bad arguments");
+    if (a.M <= 0) return 0;
+    CONE_REQUIRE(rows_chain_supported(a.M), "rows chain: %d rows are beyond the small-M regime", a.M);
+    for (int i = 0; i < a.n_stages; ++i) {
+        const ChainStage& st = a.st[i];
+        if (st.kind == 0) {
+            CONE_REQUIRE(st.W && st.K % 16 == 0 && st.K >= 16 && st.K <= 1024 && (i == 0 || st.K == 256),
+                         "rows chain: stage %d: K=%d (stage 0: a multiple of 16 up to 1024; later stages: 256)", i, st.K);
+            CONE_REQUIRE(!(st.flags & EPI_RESIDUAL) || (st.R && st.ldr % 4 == 0), "rows chain: residual flag without R");
+            CONE_REQUIRE(!(st.flags & EPI_LN), "rows chain: a LayerNorm epilogue is a stage of its own (kind 1)");
+        } else {
+            CONE_REQUIRE(st.kind == 1 && st.ln_g && st.ln_b, "rows chain: stage %d: bad LayerNorm stage", i);
+        }
+        CONE_REQUIRE(!st.C || st.ldc % 4 == 0, "rows chain: output row stride must be a multiple of 4");
+        CONE_REQUIRE(!st.hout || (st.hw && st.hb && st.hnout >= 1 && st.hnout <= 2), "rows chain: bad head");
+    }
+    CONE_REQUIRE(a.st[0].kind == 0 || a.lda >= 256, "rows chain: a LayerNorm first stage reads 256-wide rows");
+    const int K0 = a.st[0].kind == 0 ? a.st[0].K : 256;
+    const size_t lds = (size_t)((16 * K0 > 16 * RS_EP_LD ? 16 * K0 : 16 * RS_EP_LD) + 16 * RS_EP_LD + 8 * RS_RING) * sizeof(float);
+    static DeviceOnce once;     // the opt-in to > 64 KiB of LDS: once per device
+    CONE_CHECK_HIP(device_once(once, [] {
+        return hipFuncSetAttribute((const void*)rows_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }));
+    hipLaunchKernelGGL(rows_chain_kernel, dim3((unsigned)((a.M + 15) / 16)), dim3(512), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
 }

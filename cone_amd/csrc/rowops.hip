@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
+            // (every product is an operand of an EXPLICIT fma: under -ffp-contract=fast the backend otherwise picks, per kernel,
+            // which product of a sum of two it fuses -- and rows_chain_kernel (gemm.hip) must reproduce these bits)
             const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + bq * bq) + (cq * cq + d * d);
+            q += __builtin_fmaf(a, a, bq * bq) + __builtin_fmaf(cq, cq, d * d);
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + 1e-5f);
@@ -46,10 +48,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 gg = reinterpret_cast<const float4*>(g)[c];
             const float4 bb = reinterpret_cast<const float4*>(b)[c];
             float4 o;
-            o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
-            o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
-            o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
-            o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            o.x = __builtin_fmaf((v[i].x - mean) * rstd, gg.x, bb.x);
+            o.y = __builtin_fmaf((v[i].y - mean) * rstd, gg.y, bb.y);
+            o.z = __builtin_fmaf((v[i].z - mean) * rstd, gg.z, bb.z);
+            o.w = __builtin_fmaf((v[i].w - mean) * rstd, gg.w, bb.w);
             reinterpret_cast<float4*>(orow)[c] = o;
         }
     }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X
     const float4 xv = reinterpret_cast<const float4*>(X + row * ldx)[lane];
     for (int n = 0; n < nout; ++n) {
         const float4 wv = reinterpret_cast<const float4*>(W + n * 256)[lane];
-        float s = (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+        float s = __builtin_fmaf(xv.x, wv.x, xv.y * wv.y) + __builtin_fmaf(xv.z, wv.z, xv.w * wv.w);   // (pinned: see layernorm_kernel)
         s = wave_sum(s) + b[n];
         if (act == 1) s = 1.0f / (1.0f + expf(-s));
         if (lane == 0) out[row * ldo + n] = s;

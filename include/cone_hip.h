@@ -395,6 +395,9 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  * "res_gather" (default 1, with ffn_fused 2 + l0_gather + pos_tables): the first encoder layer's residual rows are read
  *   by the fused layer tail straight from the projected clip / text rows through a row index; 0 = from a packed copy of
  *   the layer input written by a packing pass.  Bit-identical.
+ * "rows_chain" (default 1): for few rows (the regime of the row GEMM's 16-row form) decoder.norm + class head + span MLP +
+ *   span head of a decoder layer, and the adapter pair of the proposal matching (d = 256 features), run as ONE launch each
+ *   with the rows on chip in between (rows_chain.h); 0 = the separate launches.  Bit-identical.
  * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
  *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
  *   exact-fp32 fma chains per output element that walk k in different orders. */

@@ -533,6 +533,44 @@ def test_position_tables_equal_materialised_pos_path(preset):
     assert float(d[safe].max()) < 5e-5
 
 
+@pytest.mark.parametrize("preset", ["ego4d", "mad"])
+def test_rows_chain_is_bit_identical(preset):
+    """Few rows: decoder.norm + class head + span MLP + span head run as ONE launch per decoder layer and the adapter pair of
+    the proposal matching as one more (rows_chain.h; d = 256 features) -- every stage the arithmetic of the launch it replaces.
+    Against the separate launches (``rows_chain`` 0): every output bit for bit, on the padded entry with the aux heads and taps
+    (both decoder layers through the chain, normalised rows written) and through the eval pipeline (last layer only)."""
+    from cone_amd import inference as inf
+    model, opt, _ = get_model(preset, 0 if preset == "ego4d" else 1)
+    dev = _gpu()
+    rng = np.random.default_rng(3)
+    B = 21
+    lens_v = [opt.max_v_l] + [int(x) for x in rng.integers(1, opt.max_v_l + 1, B - 1)]
+    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
+    inp = gi.stage_b_inputs(opt, 17, lens_v, lens_q)
+    g = lambda a: torch.from_numpy(a).to(dev)
+    popt = make_opt(preset, nms_thd=0.5, eval_split_name="test", topk_window=7, eval_bsz=4)
+    ann, vf, qf = synth.make_dataset(popt, 9, 2, seed=31, ctx_range=(100, 700))
+    store = inf.FeatureStore(popt, ann, vf, qf)
+    res = {}
+    try:
+        for on in (1, 0):
+            model.set_option("rows_chain", on)
+            o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+            mt = model.forward_clip_matching(g(inp["src_cls_txt"]), g(inp["src_vid"]), g(inp["vid_mask"]), proposal=o["pred_spans"])
+            dp = inf.device_pipeline(model, store, popt)
+            res[on] = (o, mt, {k: dp[k].clone() for k in ("rows", "n", "cand")})
+    finally:
+        model.set_option("rows_chain", 1)
+    a, b = res[1], res[0]
+    for k in ("pred_logits", "pred_spans", "hs", "saliency_scores"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    for k in ("pred_logits", "pred_spans"):
+        assert torch.equal(a[0]["aux_outputs"][0][k], b[0]["aux_outputs"][0][k]), ("aux", k)
+    assert torch.equal(a[1], b[1])
+    for k in ("rows", "n", "cand"):
+        assert torch.equal(a[2][k], b[2][k]), k
+
+
 def test_padding_independence_and_determinism():
     """Masked keys make the result independent of how far the batch is padded (H12) and the packed
     kernels are batch-composition independent: bit-identical outputs."""
