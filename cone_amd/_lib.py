@@ -92,6 +92,7 @@ _SIGNATURES = {
     "cone_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),
     "cone_project_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    "cone_mask_lengths": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cone_forward_workspace": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "cone_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Taps),

@@ -963,6 +963,10 @@ __global__ void fill_int_kernel(int* a, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = v;
 }
+__global__ void iota_fill_kernel(int* a, int* b, int n, int stride, int v) {    // a[i] = i * stride, b[i] = v
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = i * stride; b[i] = v; }
+}
 
 }  // namespace cone
 
@@ -1167,8 +1171,7 @@ extern "C" int cone_clip_matching(const cone_model* m, const float* cls, const f
     int* vrow0 = c.take<int>(B);
     int* padl = c.take<int>(B);
     if (!c.ok) { set_error("clip_matching: workspace too small"); return CONE_E_WORKSPACE; }
-    hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, vrow0, B, Lv_pad);
-    hipLaunchKernelGGL(fill_int_kernel, dim3((B + 255) / 256), dim3(256), 0, s, padl, B, Lv_pad);
+    hipLaunchKernelGGL(iota_fill_kernel, dim3((B + 255) / 256), dim3(256), 0, s, vrow0, padl, B, Lv_pad, Lv_pad);
     CONE_LAUNCH_CHECK();
     return cone_clip_matching_gathered(m, cls, nullptr, vid, vrow0, vid_len, padl, spans, B, match,
                                        (char*)ws + c.cur, ws_bytes - c.cur, stream);

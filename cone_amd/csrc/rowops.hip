@@ -172,4 +172,24 @@ int launch_rowdot(const float* X, int ldx, const float* W, const float* b, float
     return 0;
 }
 
+// Valid lengths of prefix masks (utils/tensor_utils.py:50-52: 1 = valid): len[b] = (int) sum_j mask[b][j], one wave per row --
+// what the host mirror computed with two torch launches per mask (sum, cast).
+__global__ __launch_bounds__(256) void mask_lengths_kernel(const float* __restrict__ mask, int B, int L, int* __restrict__ len) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += mask[(size_t)b * L + j];
+    s = wave_sum(s);
+    if (lane == 0) len[b] = (int)s;
+}
+
 }  // namespace cone
+
+extern "C" int cone_mask_lengths(const float* mask, int B, int L, int32_t* len, void* stream) {
+    CONE_REQUIRE(mask && len && B >= 0 && L >= 0, "mask_lengths: bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(cone::mask_lengths_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask, B, L, len);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}

@@ -183,17 +183,25 @@ class CONE:
     def _f32(t):
         return t.to(dtype=torch.float32).contiguous()
 
-    @staticmethod
-    def _lengths(mask):
-        """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths.  The reference's collate
-        (pad_sequences_1d) only ever produces PREFIX masks and the packed kernels take lengths; a mask with holes is not
-        representable.  ``CONE_AMD_CHECK_MASKS=1`` verifies it (one device round trip per call) and raises ValueError."""
-        m = mask.to(torch.float32)
-        n = m.sum(dim=1).to(torch.int32).contiguous()
+    def _lengths(self, mask):
+        """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths (cone_mask_lengths: one launch).  The
+        reference's collate (pad_sequences_1d) only ever produces PREFIX masks and the packed kernels take lengths; a mask with
+        holes is not representable.  ``CONE_AMD_CHECK_MASKS=1`` verifies it (one device round trip per call) and raises
+        ValueError.  The lengths of the last mask are kept: ``forward_clip_matching`` is called with the very mask tensor
+        ``forward`` just saw (cone/inference.py:45-50)."""
+        cache = self.__dict__.setdefault("_len_cache", [])          # [(mask tensor, its version, lengths)], the last two masks
+        for t, ver, n in cache:
+            if t is mask and ver == mask._version:                   # the SAME tensor object, not modified since
+                return n
+        m = mask.to(torch.float32).contiguous()
+        n = torch.empty(m.shape[0], dtype=torch.int32, device=m.device)
+        _lib.check(_lib.load().cone_mask_lengths(_lib.ptr(m), m.shape[0], m.shape[1], _lib.ptr(n), _lib.stream()))
         if _CHECK_MASKS:
             ar = torch.arange(m.shape[1], device=m.device)[None]
             if not bool(((ar < n[:, None]) == (m != 0)).all()):
                 raise ValueError("CONE.forward takes prefix masks (1 ... 1 0 ... 0), as the reference's collate produces")
+        cache.insert(0, (mask, mask._version, n))
+        del cache[2:]
         return n
 
     # ---- CONE.forward (cone/model.py:82-128) ----------------------------------------------------

@@ -211,6 +211,10 @@ int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* v
                          float* logits, float* spans, float* saliency, const cone_taps* taps,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Valid lengths of the reference's prefix masks (pad_sequences_1d, utils/tensor_utils.py:50-52: 1 = valid, (B, L) fp32):
+ * len[b] = sum_j mask[b][j] as int32 -- the vid_len / txt_len arguments of the two entry points above. */
+int cone_mask_lengths(const float* mask, int B, int L, int32_t* len, void* stream);
+
 /* Same computation on already-projected token arenas (cone_project_tokens outputs), windows given
  * by index: window b = vproj rows [vid_row0[b], +vid_len[b]) followed by tproj rows
  * [txt_row0[b], +txt_len[b]).  This is how the eval driver avoids re-projecting the clips shared by
