@@ -26,6 +26,6 @@ else:
     for kv in os.environ.get("CONE_SET_OPTION", "").split():
         name, _, val = kv.partition("=")
         model.set_option(name, int(val))
-    ann, vf, qf = synth.make_dataset(opt, 64, 4, seed=0)
+    ann, vf, qf = synth.make_dataset(opt, 320, 16, seed=0)
     store = inf.FeatureStore(opt, ann, vf, qf)
     print(json.dumps(bench.bench_dropin_forward(model, store, opt, None, steps=steps)))
