@@ -84,6 +84,20 @@ __global__ __launch_bounds__(512, (DecCrossMfmaCfg<KTW, NQ>::MIN_WAVES)) void de
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
 
+    // More than 5 slots: the window's query rows go through LDS (stage 0 reads them as wave-uniform broadcasts).  As scalar
+    // operands 8 / 10 slots x 32 values are hoisted into more SGPRs than there are: 235 / 281 spilled to VGPR lanes, 448 / 745
+    // v_readlane per wave.  Requested FIRST, so that the wait for them does not cover the key rows behind them.
+    constexpr bool QLDS = NQ > 5;
+    constexpr int QREG = QLDS ? (NQ * 64 + 511) / 512 : 1;
+    g4v qreg[QREG];
+    if (QLDS && !QKS) {
+        const g4v* qsrc = reinterpret_cast<const g4v*>(DQ + (size_t)b * NQ * 256);
+#pragma unroll
+        for (int j = 0; j < QREG; ++j) {
+            const int i = tid + 512 * j;
+            if (i < NQ * 64) qreg[j] = qsrc[i];
+        }
+    }
     // ---- this wave's key rows (A operand of stage A: lane = key, float4 = channels 16 q + 4 lg ..) are requested first:
     // their HBM / L2 latency runs under stage 0
     g4v xk[KTW][16];
@@ -113,6 +127,15 @@ __global__ __launch_bounds__(512, (DecCrossMfmaCfg<KTW, NQ>::MIN_WAVES)) void de
         }
     }
 
+    if (QLDS && !QKS) {     // (Pt is free until stage B)
+#pragma unroll
+        for (int j = 0; j < QREG; ++j) {
+            const int i = tid + 512 * j;
+            if (i < NQ * 64) reinterpret_cast<g4v*>(Pt)[i] = qreg[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (an LDS-only barrier: __syncthreads would wait out the key rows)
+        __builtin_amdgcn_s_barrier();
+    }
     if (QKS) {      // precomputed slabs: 48 KiB from the L2 instead of 256 KiB of W_k
         for (int i = tid; i < C::QK_FLOATS / 4; i += 512)
             reinterpret_cast<g4v*>(qkf)[i] = reinterpret_cast<const g4v*>(QKS)[i];
@@ -149,10 +172,20 @@ __global__ __launch_bounds__(512, (DecCrossMfmaCfg<KTW, NQ>::MIN_WAVES)) void de
 #pragma unroll
                 for (int i = 0; i < 2; ++i) wn[i] = *reinterpret_cast<const g4v*>(wb + ((g + 1) * 2 + i) * 256 + l4);
             }
+            if (QLDS) {
+                const float* ql = Pt + wave * 32 + g * 2;       // this head's two query values of every slot: LDS broadcasts
 #pragma unroll
-            for (int s = 0; s < NQ; ++s)
+                for (int s = 0; s < NQ; ++s) {
+                    const g2v q2 = *reinterpret_cast<const g2v*>(ql + s * 256);
+                    a[s] += wc[0] * q2[0];
+                    a[s] += wc[1] * q2[1];
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[s] += wc[i] * qb[s * 256 + g * 2 + i];
+                for (int s = 0; s < NQ; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[s] += wc[i] * qb[s * 256 + g * 2 + i];
+            }
         }
         const int c = 4 * lane;
 #pragma unroll
