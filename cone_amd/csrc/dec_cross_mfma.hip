@@ -87,7 +87,10 @@ __global__ __launch_bounds__(512, (DecCrossMfmaCfg<KTW, NQ>::MIN_WAVES)) void de
     // More than 5 slots: the window's query rows go through LDS (stage 0 reads them as wave-uniform broadcasts).  As scalar
     // operands 8 / 10 slots x 32 values are hoisted into more SGPRs than there are: 235 / 281 spilled to VGPR lanes, 448 / 745
     // v_readlane per wave.  Requested FIRST, so that the wait for them does not cover the key rows behind them.
-    constexpr bool QLDS = NQ > 5;
+#ifndef CONE_DCM_QLDS_MIN
+#define CONE_DCM_QLDS_MIN 5
+#endif
+    constexpr bool QLDS = NQ > CONE_DCM_QLDS_MIN;
     constexpr int QREG = QLDS ? (NQ * 64 + 511) / 512 : 1;
     g4v qreg[QREG];
     if (QLDS && !QKS) {
