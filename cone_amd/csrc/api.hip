@@ -955,14 +955,6 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     return 0;
 }
 
-__global__ void iota_rows_kernel(int* a, int n, int stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = i * stride;
-}
-__global__ void fill_int_kernel(int* a, int n, int v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = v;
-}
 __global__ void iota_fill_kernel(int* a, int* b, int n, int stride, int v) {    // a[i] = i * stride, b[i] = v
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = i * stride; b[i] = v; }
