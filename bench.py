@@ -430,10 +430,15 @@ def reference_batch_tensors(model, store, opt, n_batch_queries=None):
     vmask, tmask = (ar_v < vlen[:, None]), (ar_q < tlen[:, None])
     tok = store.tok_raw if store.tok_normalized else ops.l2_normalize(store.tok_raw, 1e-5)
     cls = store.cls_raw if store.cls_normalized else ops.l2_normalize(store.cls_raw, 1e-5)
-    src_vid = store.vid_raw[(vrow0[:, None] + ar_v).clamp_(max=store.vid_raw.shape[0] - 1)] * vmask[..., None]
+    rows = (vrow0[:, None] + ar_v).clamp_(max=store.vid_raw.shape[0] - 1)
+    src_vid = (store.vid_raw[rows] * vmask[..., None]).contiguous()
+    # a store with two visual sources (dataloader :134-158): the model input is cut from the motion arena, the matching's
+    # from the appearance arena; one source: the same tensor serves both, as in the reference's collate
+    src_mot = src_vid if getattr(store, "mot_raw", None) is None else (store.mot_raw[rows] * vmask[..., None]).contiguous()
     src_txt = tok[(trow0[:, None] + ar_q).clamp_(max=tok.shape[0] - 1)] * tmask[..., None]
-    return dict(src_txt=src_txt.contiguous(), src_txt_mask=tmask.float(), src_vid_motion=src_vid.contiguous(),
-                src_vid_motion_mask=vmask.float(), src_cls_txt=cls[wt["cls_row"].long()].contiguous()), wt, sub
+    return dict(src_txt=src_txt.contiguous(), src_txt_mask=tmask.float(), src_vid_motion=src_mot,
+                src_vid_motion_mask=vmask.float(), src_vid_appear=src_vid,
+                src_cls_txt=cls[wt["cls_row"].long()].contiguous()), wt, sub
 
 
 def bench_dropin_forward(model, store, opt, arena_exec_tflops, steps=20, warmup=3):
@@ -453,7 +458,7 @@ def bench_dropin_forward(model, store, opt, arena_exec_tflops, steps=20, warmup=
         # of the masks it saw last (forward_clip_matching gets the very tensor forward just saw, cone/inference.py:45-50)
         vm, tm = inputs["src_vid_motion_mask"].view_as(inputs["src_vid_motion_mask"]), mi["src_txt_mask"].view_as(mi["src_txt_mask"])
         o = model(src_txt=mi["src_txt"], src_txt_mask=tm, src_vid_motion=mi["src_vid_motion"], src_vid_motion_mask=vm)
-        m = model.forward_clip_matching(inputs["src_cls_txt"], inputs["src_vid_motion"], vm, proposal=o["pred_spans"])
+        m = model.forward_clip_matching(inputs["src_cls_txt"], inputs["src_vid_appear"], vm, proposal=o["pred_spans"])
         return o, m
     dt, (o, mt) = _timed(call, steps, warmup)       # the figure: no launch timer (its two event records per launch cost a
     lib.cone_prof_enable(1)                         # 2.5 ms batch ~10 %; a 53 ms step nothing)

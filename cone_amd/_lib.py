@@ -43,7 +43,7 @@ class Weights(C.Structure):
     _fields_ = [
         ("hidden_dim", C.c_int32), ("nheads", C.c_int32), ("dim_ff", C.c_int32), ("enc_layers", C.c_int32),
         ("dec_layers", C.c_int32), ("num_queries", C.c_int32), ("n_input_proj", C.c_int32),
-        ("t_dim", C.c_int32), ("v_dim", C.c_int32), ("has_adapter", C.c_int32),
+        ("t_dim", C.c_int32), ("v_dim", C.c_int32), ("has_adapter", C.c_int32), ("v_motion_dim", C.c_int32),
         ("vid_proj_ln", LNorm * MAX_PROJ), ("vid_proj", Linear * MAX_PROJ),
         ("txt_proj_ln", LNorm * MAX_PROJ), ("txt_proj", Linear * MAX_PROJ),
         ("enc", EncLayer * MAX_LAYERS), ("dec", DecLayer * MAX_LAYERS),
@@ -179,7 +179,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 6:
+    if lib.cone_abi_version() != 7:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

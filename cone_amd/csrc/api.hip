@@ -30,7 +30,7 @@ struct DecLayer { Mha sa, ca; Linear l1, l2; LNorm n1, n2, n3; };
 }  // namespace cone
 
 struct cone_model {
-    int d, heads, ff, n_enc, n_dec, nq, n_proj, dt, dv, has_adapter;
+    int d, heads, ff, n_enc, n_dec, nq, n_proj, dt, dv, dvm, has_adapter;     // dv: appearance clips (pre-filter, matching), dvm: motion clips (window model)
     float* arena = nullptr;  // every weight, one allocation
     cone::LNorm vproj_ln[CONE_MAX_PROJ], tproj_ln[CONE_MAX_PROJ];
     cone::Linear vproj[CONE_MAX_PROJ], tproj[CONE_MAX_PROJ];
@@ -112,11 +112,13 @@ static int build_model(const cone_weights* w, cone_model** out) {
                      w->dec_layers <= CONE_MAX_LAYERS, "model_create: layer counts out of range");
     CONE_REQUIRE(w->num_queries >= 1 && w->num_queries <= 16, "model_create: num_queries=%d not in [1,16]", w->num_queries);
     CONE_REQUIRE(w->n_input_proj >= 1 && w->n_input_proj <= CONE_MAX_PROJ, "model_create: n_input_proj out of range");
-    CONE_REQUIRE(w->t_dim % 32 == 0 && w->v_dim % 32 == 0 && w->t_dim <= 1024 && w->v_dim <= 1024,
-                 "model_create: feature dims must be multiples of 32 and <= 1024 (t=%d v=%d)", w->t_dim, w->v_dim);
+    CONE_REQUIRE(w->t_dim % 32 == 0 && w->v_dim % 32 == 0 && w->v_motion_dim % 32 == 0 && w->t_dim <= 1024 && w->v_dim <= 1024 &&
+                     w->v_motion_dim <= 1024 && w->t_dim > 0 && w->v_dim > 0 && w->v_motion_dim > 0,
+                 "model_create: feature dims must be multiples of 32 and <= 1024 (t=%d v_appear=%d v_motion=%d)", w->t_dim,
+                 w->v_dim, w->v_motion_dim);
     cone_model* m = new cone_model();
     m->d = 256; m->heads = 8; m->ff = w->dim_ff; m->n_enc = w->enc_layers; m->n_dec = w->dec_layers;
-    m->nq = w->num_queries; m->n_proj = w->n_input_proj; m->dt = w->t_dim; m->dv = w->v_dim;
+    m->nq = w->num_queries; m->n_proj = w->n_input_proj; m->dt = w->t_dim; m->dv = w->v_dim; m->dvm = w->v_motion_dim;
     m->has_adapter = w->has_adapter;
     const size_t d = 256, ff = m->ff;
     ArenaBuilder ab;
@@ -131,8 +133,8 @@ static int build_model(const cone_weights* w, cone_model** out) {
         lin(s.out_proj, d, d, dst.out);
     };
     for (int i = 0; i < m->n_proj; ++i) {
-        ln(w->vid_proj_ln[i], i == 0 ? m->dv : d, m->vproj_ln[i]);
-        lin(w->vid_proj[i], d, i == 0 ? m->dv : d, m->vproj[i]);
+        ln(w->vid_proj_ln[i], i == 0 ? m->dvm : d, m->vproj_ln[i]);
+        lin(w->vid_proj[i], d, i == 0 ? m->dvm : d, m->vproj[i]);
         ln(w->txt_proj_ln[i], i == 0 ? m->dt : d, m->tproj_ln[i]);
         lin(w->txt_proj[i], d, i == 0 ? m->dt : d, m->tproj[i]);
     }
@@ -388,7 +390,7 @@ static int layer0_rows(const cone_model* m, const float* rows, int n, const int*
 
 // input_{vid,txt}_proj: LN -> Linear -> ReLU (all but last) with the next LN fused into the GEMM epilogue.
 static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
-    const size_t din = which == 0 ? m->dv : m->dt;
+    const size_t din = which == 0 ? m->dvm : m->dt;
     return align_up(n * din * 4, 256) + 2 * align_up(n * 256 * 4, 256);
 }
 // src_row != null: row i of the projection reads row src_row[i] of x (the valid rows of a zero-padded batch, compacted by the
@@ -396,7 +398,7 @@ static size_t project_ws_bytes(const cone_model* m, int which, int64_t n) {
 static int project_tokens(const cone_model* m, int which, const float* x, int64_t n, float* out, void* ws,
                           size_t ws_bytes, hipStream_t s, const int* src_row = nullptr, const int* n_dev = nullptr) {
     CONE_REQUIRE(n < (1ll << 31), "project: too many rows");
-    const int din = which == 0 ? m->dv : m->dt;
+    const int din = which == 0 ? m->dvm : m->dt;
     const LNorm* lns = which == 0 ? m->vproj_ln : m->tproj_ln;
     const Linear* lin = which == 0 ? m->vproj : m->tproj;
     Carver c(ws, ws_bytes);

@@ -57,8 +57,12 @@ class FeatureStore:
     StartEndDataset of cone/ego4d_mad_dataloader.py for the eval path)."""
 
     def __init__(self, opt, annotations, video_feats, query_feats, device=None, tok_normalized=False,
-                 cls_normalized=False):
+                 cls_normalized=False, motion_feats=None):
         """``video_feats``: clip_id -> RAW (ctx_l, dv) features (hazard H2: the window model sees them un-normalised);
+        ``motion_feats`` (optional): clip_id -> RAW (ctx_l, dv_motion) features of a SECOND visual source -- the reference's
+        ``motion_feat_dir`` when it is not ``appearance_feat_dir`` (cone/ego4d_mad_dataloader.py:63-81, 94-95): the window
+        model (Moment-DETR) reads the motion features, the pre-filter and the proposal matching the appearance features
+        (``video_feats``); the same clips, so the same number of rows per video.  None = one source for both (every shipped script);
         ``query_feats``: query_id -> {token_features, cls_features | eot_features}.  ``tok_normalized`` /
         ``cls_normalized``: the text side already went through the reference's ``l2_normalize_np_array`` on the
         host (features taken from the reference's dataset objects, ``from_datasets``) and must not be normalised
@@ -79,6 +83,13 @@ class FeatureStore:
         self.ctx_l = [int(v.shape[0]) for v in vids]
         self.vid_off = np.concatenate([[0], np.cumsum(self.ctx_l)]).astype(np.int64)
         self.vid_raw = torch.from_numpy(np.concatenate(vids, 0)).to(dev)
+        self.mot_raw = None         # the motion arena (same rows as vid_raw), or None: vid_raw serves both
+        if motion_feats is not None:
+            mots = [np.asarray(motion_feats[c], dtype=np.float32) for c in self.clip_ids]
+            bad = [c for c, m, n in zip(self.clip_ids, mots, self.ctx_l) if int(m.shape[0]) != n]
+            if bad:     # the reference slices both with the appearance length (dataloader :139-151); a shorter motion
+                raise ValueError(f"motion and appearance features disagree on the number of clips of {bad[:3]}")  # video
+            self.mot_raw = torch.from_numpy(np.concatenate(mots, 0)).to(dev)         # would silently shift its windows
         toks, clss = [], []
         for r in self.ann:
             q = query_feats[r["query_id"]]
@@ -110,7 +121,7 @@ class FeatureStore:
         sub.max_tok_len = store.max_tok_len
         sub.ann = store.ann[lo:hi]
         sub.clip_ids, sub.clip2idx, sub.ctx_l, sub.vid_off = store.clip_ids, store.clip2idx, store.ctx_l, store.vid_off
-        sub.vid_raw = store.vid_raw
+        sub.vid_raw, sub.mot_raw = store.vid_raw, store.mot_raw
         t0, t1 = int(store.tok_off[lo]), int(store.tok_off[hi])
         sub.tok_raw = store.tok_raw[t0:t1]
         sub.tok_len = store.tok_len[lo:hi]
@@ -132,7 +143,8 @@ class FeatureStore:
         v = views.get((lo, hi))
         # a view aliases the arenas it was cut from: refilling them IN PLACE (copy_) keeps it valid, assigning NEW tensors to
         # vid_raw / tok_raw / cls_raw does not -- such a view is rebuilt
-        arenas = (self.vid_raw.data_ptr(), self.tok_raw.data_ptr(), self.cls_raw.data_ptr())
+        arenas = (self.vid_raw.data_ptr(), self.tok_raw.data_ptr(), self.cls_raw.data_ptr(),
+                  0 if self.mot_raw is None else self.mot_raw.data_ptr())
         if v is None or v._arenas != arenas:
             if len(views) > 32:
                 views.clear()
@@ -192,8 +204,6 @@ class FeatureStore:
         except ImportError as e:
             raise ImportError("reading the reference LMDB feature stores needs the `lmdb` package "
                               "(or convert once with `python -m cone_amd.pack_features` where it is installed)") from e
-        if opt.motion_feat_dir != opt.appearance_feat_dir:
-            raise NotImplementedError("separate motion/appearance feature dirs are not used by any shipped script")
         with open(opt.eval_path) as f:
             ann = [json.loads(l.strip("\n")) for l in f.readlines()]      # utils/basic_utils.py:51-53
         if opt.data_ratio != 1:
@@ -215,9 +225,13 @@ class FeatureStore:
         vf = {k: v["features"] for k, v in read_all(opt.appearance_feat_dir,
                                                     OrderedDict.fromkeys(r["clip_id"] for r in ann),
                                                     ["features"]).items()}
+        mf = None
+        if opt.motion_feat_dir != opt.appearance_feat_dir:        # dataloader :77-81, 105-111, 294-302
+            mf = {k: v["features"] for k, v in read_all(opt.motion_feat_dir, OrderedDict.fromkeys(r["clip_id"] for r in ann),
+                                                        ["features"]).items()}
         qf = read_all(opt.t_feat_dir, [r["query_id"] for r in ann],
                       ["token_features", "cls_features", "eot_features"])
-        st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device)
+        st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device, motion_feats=mf)
         st.opt = opt
         return st
 
@@ -231,20 +245,21 @@ class FeatureStore:
         store is told not to normalise them again.  The PreFilteringDataset reads the same LMDBs (:409-431) and only
         contributes a consistency check here."""
         intra, inter = eval_intra_window_dataset, eval_inter_window_dataset
-        if not getattr(intra, "same_visual_path", True):
-            raise NotImplementedError("separate motion/appearance feature sources are not used by any shipped script")
         ann = list(intra.data)
         if inter is not None and hasattr(inter, "query_data"):
             if [r["query_id"] for r in inter.query_data] != [r["query_id"] for r in ann]:
                 raise ValueError("the two datasets list different queries")
         to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
         vf = {c: to_np(intra.videofeat[c]) for c in OrderedDict.fromkeys(r["clip_id"] for r in ann)}
+        mf = None
+        if not getattr(intra, "same_visual_path", True):          # dataloader :94-95, 134-137: a second RAM-resident table
+            mf = {c: to_np(intra.motion_videofeat[c]) for c in vf}
         qf = {}
         for r in ann:
             tok, cq = intra._get_query_feat_by_qid(r["query_id"])
             qf[r["query_id"]] = dict(token_features=to_np(tok), cls_features=to_np(cq))
         st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device,
-                 tok_normalized=bool(getattr(intra, "normalize_t", True)), cls_normalized=True)
+                 tok_normalized=bool(getattr(intra, "normalize_t", True)), cls_normalized=True, motion_feats=mf)
         st.opt = opt
         return st
 
@@ -257,6 +272,8 @@ class FeatureStore:
         loading is an mmap + one H2D copy per arena (no decompression, no per-query slicing)."""
         arrs = dict(vid_raw=self.vid_raw.cpu().numpy(), tok_raw=self.tok_raw.cpu().numpy(),
                     cls_raw=self.cls_raw.cpu().numpy())
+        if self.mot_raw is not None:
+            arrs["mot_raw"] = self.mot_raw.cpu().numpy()     # (an optional fourth arena: files without it read as before)
         head = dict(version=1, ann=self.ann, clip_ids=self.clip_ids, ctx_l=self.ctx_l, tok_len=self.tok_len,
                     arrays={})
         off = 0
@@ -306,6 +323,7 @@ class FeatureStore:
                 warnings.simplefilter("ignore", UserWarning)        # "non-writable array": it is only read
                 return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         st.vid_raw = up(mm["vid_raw"])
+        st.mot_raw = up(mm["mot_raw"]) if "mot_raw" in mm else None
         st.tok_raw = up(mm["tok_raw"][:int(st.tok_off[-1])])
         st.cls_raw = up(mm["cls_raw"][:nq])
         st.q_vid = np.array([st.clip2idx[r["clip_id"]] for r in st.ann], dtype=np.int64)
@@ -481,7 +499,7 @@ def project_video(model, store: FeatureStore, row_range=None, ws=None):
     tables.  ``row_range`` = (r0, r1) restricts it to arena rows [r0, r1) (a rank that only runs the windows of
     some videos); ``vid_base`` is what window rows must be rebased by."""
     r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
-    vproj = model.project(0, store.vid_raw[r0:r1], ws=ws)
+    vproj = model.project(0, (store.vid_raw if store.mot_raw is None else store.mot_raw)[r0:r1], ws=ws)   # the MOTION source
     out = dict(vproj=vproj, vid_base=r0)
     if getattr(store.opt, "layer0_cache", True):
         out["l0_vid"] = model.layer0_rows(vproj, ws=ws)      # (the position tables are the model handle's own)

@@ -56,8 +56,9 @@ class CONE:
             raise NotImplementedError("only span_loss_type='l1' (cone/config.py:134)")
         # --pre_norm (cone/config.py:120): normalize_before in every layer + the encoder's final norm; general path as well
         self.pre_norm = bool(getattr(args, "pre_norm", False))
-        if getattr(args, "v_motion_feat_dim", None) != getattr(args, "v_appear_feat_dim", None):
-            raise NotImplementedError("motion and appearance features share one source in every shipped script")
+        # two visual sources (cone/ego4d_mad_dataloader.py:63-71): MOTION features feed the window model (input_vid_proj,
+        # cone/model.py:67), APPEARANCE features the pre-filter and the proposal matching (adapter, cone/model.py:80, 186-208);
+        # every shipped script points both at one LMDB, the dims may differ when they do not
         self.args = args
         self.num_queries = args.num_queries
         self.adapter_module = args.adapter_module
@@ -113,7 +114,7 @@ class CONE:
         w = _lib.Weights()
         w.hidden_dim, w.nheads, w.dim_ff = a.hidden_dim, a.nheads, a.dim_feedforward
         w.enc_layers, w.dec_layers, w.num_queries = a.enc_layers, a.dec_layers, a.num_queries
-        w.n_input_proj, w.t_dim, w.v_dim = a.n_input_proj, a.t_feat_dim, a.v_appear_feat_dim
+        w.n_input_proj, w.t_dim, w.v_dim, w.v_motion_dim = a.n_input_proj, a.t_feat_dim, a.v_appear_feat_dim, a.v_motion_feat_dim
         w.has_adapter = 1 if a.adapter_module == "linear" else 0
         p = lambda k: sd[k].data_ptr()
 
@@ -210,6 +211,8 @@ class CONE:
         vid, txt = self._f32(src_vid_motion), self._f32(src_txt)
         B, Lv, _ = vid.shape
         Lq = txt.shape[1]
+        self._check_dim(vid, self.args.v_motion_feat_dim, "src_vid_motion")
+        self._check_dim(txt, self.args.t_feat_dim, "src_txt")
         vlen, qlen = self._lengths(src_vid_motion_mask), self._lengths(src_txt_mask)
         dev = vid.device
         nq, nd, d = self.num_queries, self.args.dec_layers, self.hidden_dim
@@ -246,6 +249,8 @@ class CONE:
             raise NotImplementedError("ground-truth proposal matching is a training-only branch")
         lib, h = _lib.load(), self._h()
         cls, vid, spans = self._f32(src_cls_txt), self._f32(src_vid_appear), self._f32(proposal)
+        self._check_dim(vid, self.args.v_appear_feat_dim, "src_vid_appear")
+        self._check_dim(cls, self.args.v_appear_feat_dim, "src_cls_txt")
         B, Lv, _ = vid.shape
         vlen = self._lengths(src_vid_appear_mask)
         match = torch.empty(B, self.num_queries, device=vid.device)
@@ -261,6 +266,7 @@ class CONE:
         adapter(x)+x un-normalised (run_on_video/cone_localizator.py:135-138)."""
         lib, h = _lib.load(), self._h()
         x = self._f32(vid_rows)
+        self._check_dim(x, self.args.v_appear_feat_dim, "appearance clip features")
         out = torch.empty_like(x)
         nbytes = lib.cone_adapter_norm_workspace(h, x.shape[0])
         ws = self._ws.get(nbytes, x.device)
@@ -273,12 +279,20 @@ class CONE:
         the model's own)."""
         lib, h = _lib.load(), self._h()
         x = self._f32(rows)
+        self._check_dim(x, self.args.t_feat_dim if which else self.args.v_motion_feat_dim,
+                        "text tokens" if which else "motion clip features")
         out = torch.empty(x.shape[0], self.hidden_dim, device=x.device)
         nbytes = lib.cone_project_workspace(h, which, x.shape[0])
         ws = (ws or self._ws).get(nbytes, x.device)
         _lib.check(lib.cone_project_tokens(h, which, _lib.ptr(x), x.shape[0], _lib.ptr(out), _lib.ptr(ws),
                                            ws.numel(), _lib.stream()))
         return out
+
+    @staticmethod
+    def _check_dim(t, dim, what):
+        """The library takes plain pointers: a feature tensor of another width would be read with the wrong row stride."""
+        if int(t.shape[-1]) != int(dim):
+            raise ValueError(f"{what}: feature dim {int(t.shape[-1])}, the model was built for {int(dim)}")
 
     def set_option(self, name: str, value: int):
         """A/B switch of this model's handle (cone_model_set_option): parity tests and diagnostics only."""
@@ -357,6 +371,8 @@ class CONE:
     def clip_matching_gathered(self, cls, cls_row, vid, vid_row0, vid_len, pad_len, spans):
         lib, h = _lib.load(), self._h()
         B = vid_row0.shape[0]
+        self._check_dim(vid, self.args.v_appear_feat_dim, "appearance clip features")
+        self._check_dim(cls, self.args.v_appear_feat_dim, "query cls vectors")
         match = torch.empty(B, self.num_queries, device=vid.device)
         nbytes = lib.cone_clip_matching_workspace(h, B)
         ws = self._ws.get(nbytes, vid.device)

@@ -105,6 +105,14 @@ def state_dict_checksum(sd) -> str:
     return h.hexdigest()[:16]
 
 
+def make_motion_feats(opt, video_feats, seed: int = 0):
+    """A second visual source for the same clips: clip_id -> (ctx_l, v_motion_feat_dim) fp32 (the reference's
+    ``motion_feat_dir`` when it differs from ``appearance_feat_dir``: cone/ego4d_mad_dataloader.py:63-81)."""
+    rng = np.random.default_rng(seed + 7919)
+    return OrderedDict((c, rng.standard_normal((v.shape[0], opt.v_motion_feat_dim), dtype=np.float32))
+                       for c, v in video_feats.items())
+
+
 def make_dataset(opt, n_queries: int, n_videos: int, seed: int = 0,
                  ctx_range=(850, 950), lq_range=(5, 18)):
     """Synthetic split in the reference's on-disk vocabulary.

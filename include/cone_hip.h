@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 6
+#define CONE_HIP_ABI_VERSION 7
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -61,7 +61,11 @@ typedef struct {
 /* The tensors of CONE.state_dict() (cone/model.py:19-80) that inference reads. */
 typedef struct {
     int32_t hidden_dim, nheads, dim_ff, enc_layers, dec_layers, num_queries;
-    int32_t n_input_proj, t_dim, v_dim, has_adapter;
+    int32_t n_input_proj, t_dim, v_dim, has_adapter;   /* v_dim: APPEARANCE clip features (pre-filter, proposal matching,
+                                                        * adapter: cone/model.py:80, 186-208)                             */
+    int32_t v_motion_dim;                              /* MOTION clip features = the window model's video input
+                                                        * (input_vid_proj: cone/model.py:67); equal to v_dim in every
+                                                        * shipped script (one LMDB serves both: cone/ego4d_mad_dataloader.py:77) */
     cone_ln_w vid_proj_ln[CONE_MAX_PROJ]; cone_linear_w vid_proj[CONE_MAX_PROJ]; /* input_vid_proj.{i} */
     cone_ln_w txt_proj_ln[CONE_MAX_PROJ]; cone_linear_w txt_proj[CONE_MAX_PROJ]; /* input_txt_proj.{i} */
     cone_enc_layer_w enc[CONE_MAX_LAYERS];   /* transformer.encoder.layers.{i} */
@@ -180,7 +184,7 @@ int cone_window_table(const int32_t* win_idx, int nq, int K, const int32_t* row_
 /* --------------------------------------------------------- stage B: intra-window model */
 
 /* A6, cone/model.py:100-101 (input_vid_proj / input_txt_proj): row-wise LN->Linear->ReLU->LN->Linear.
- * which: 0 = video (v_dim in), 1 = text (t_dim in).  x (n_rows,din), out (n_rows,d). */
+ * which: 0 = video (v_motion_dim in), 1 = text (t_dim in).  x (n_rows,din), out (n_rows,d). */
 size_t cone_project_workspace(const cone_model* m, int which, int64_t n_rows);
 int cone_project_tokens(const cone_model* m, int which, const float* x, int64_t n_rows, float* out,
                         void* ws, size_t ws_bytes, void* stream);
@@ -194,7 +198,7 @@ typedef struct {
 } cone_taps;
 
 /* A6-A11, CONE.forward (cone/model.py:82-128) on zero-padded tensors exactly as
- * prepare_batch_inputs delivers them: vid (B,Lv_pad,v_dim), txt (B,Lq_pad,t_dim); masks are prefix
+ * prepare_batch_inputs delivers them: vid (B,Lv_pad,v_motion_dim), txt (B,Lq_pad,t_dim); masks are prefix
  * masks given as valid lengths vid_len[B], txt_len[B] (int32, device).
  * (ABI 6) The batch is compacted first -- the valid clip / token rows are gathered by the first LayerNorm of their input
  * projection, padding is never projected -- the projections and the first encoder layer's q | k | v rows run once per compact

@@ -545,18 +545,21 @@ def prefilter(sd, opt, ann, video_feats, query_feats):
     return ranks, scores
 
 
-def build_batch(opt, ann_rows, video_feats, query_feats, ranks):
+def build_batch(opt, ann_rows, video_feats, query_feats, ranks, motion_feats=None):
     """A5: eval branch of StartEndDataset.__getitem__ + start_end_collate
     (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-358).  Model-side video features
-    are the RAW ones (H2)."""
-    metas, vids, txts, clss = [], [], [], []
+    are the RAW ones (H2).  ``motion_feats``: the second visual source (:134-137, 150-158): the window model's
+    input is sliced from it, the matching's from the appearance features -- both with the appearance length."""
+    metas, vids, mots, txts, clss = [], [], [], [], []
     for row in ann_rows:
         tok, cls = prepare_query_inputs(opt, query_feats[row["query_id"]])
         v = torch.from_numpy(np.asarray(video_feats[row["clip_id"]], dtype=np.float32))
+        mo = v if motion_feats is None else torch.from_numpy(np.asarray(motion_feats[row["clip_id"]], dtype=np.float32))
         ctx_l = v.shape[0]
         for w in ranks[row["query_id"]][:opt.topk_window]:
             s, e = window_bounds(w, ctx_l, opt.max_v_l)
             vids.append(v[s:e])
+            mots.append(mo[s:e])
             txts.append(tok)
             clss.append(cls)
             m = dict(row)
@@ -564,19 +567,20 @@ def build_batch(opt, ann_rows, video_feats, query_feats, ranks):
             m["video_start"] = s
             metas.append(m)
     src_vid, vid_mask = pad_sequences_1d(vids)
+    src_mot, mot_mask = pad_sequences_1d(mots)
     src_txt, txt_mask = pad_sequences_1d(txts)
-    return metas, dict(src_txt=src_txt, src_txt_mask=txt_mask, src_vid_motion=src_vid,
-                       src_vid_motion_mask=vid_mask), dict(
+    return metas, dict(src_txt=src_txt, src_txt_mask=txt_mask, src_vid_motion=src_mot,
+                       src_vid_motion_mask=mot_mask), dict(
         src_cls_txt=torch.stack(clss), src_vid_appear=src_vid.clone(), src_vid_appear_mask=vid_mask.clone())
 
 
-def compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks, capture=None):
+def compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks, capture=None, motion_feats=None):
     """cone/inference.py:30-100 with the DataLoader batching of eval_bsz queries."""
     sd = as_torch_sd(sd)
     mr_res = []
     for b0 in range(0, len(ann), opt.eval_bsz):
         rows = ann[b0:b0 + opt.eval_bsz]
-        metas, mi, ci = build_batch(opt, rows, video_feats, query_feats, ranks)
+        metas, mi, ci = build_batch(opt, rows, video_feats, query_feats, ranks, motion_feats)
         out = cone_forward(sd, opt, **mi)
         match = clip_matching(sd, opt, proposal=out["pred_spans"], **ci)
         if capture is not None:
@@ -591,12 +595,13 @@ def compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks, capture=No
     return mr_res
 
 
-def eval_epoch(sd, opt, ann, video_feats, query_feats):
+def eval_epoch(sd, opt, ann, video_feats, query_feats, motion_feats=None):
     """Stages A->C on an in-memory split; returns the three submission lists
-    (fusion, proposal, matching) and the rank lists."""
+    (fusion, proposal, matching) and the rank lists.  ``video_feats`` = the appearance source (pre-filter, matching),
+    ``motion_feats`` = the window model's source when it is another one (cone/ego4d_mad_dataloader.py:63-71)."""
     with torch.no_grad():
         ranks, _ = prefilter(sd, opt, ann, video_feats, query_feats)
-        mr = compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks)
+        mr = compute_mr_results(sd, opt, ann, video_feats, query_feats, ranks, motion_feats=motion_feats)
     return postprocess(mr, opt), ranks, mr
 
 

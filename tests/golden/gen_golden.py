@@ -105,7 +105,7 @@ class MemPre(PreFilteringDataset):
 class MemSE(StartEndDataset):
     """StartEndDataset (eval branch) with the LMDB readers replaced by dict lookups."""
 
-    def __init__(self, opt, ann, video_feats, query_feats):
+    def __init__(self, opt, ann, video_feats, query_feats, motion_feats=None):
         self.max_q_l, self.max_v_l = opt.max_q_l, opt.max_v_l
         self.use_video, self.clip_len = True, opt.clip_length
         self.topk_window = opt.topk_window
@@ -116,6 +116,9 @@ class MemSE(StartEndDataset):
         self.query_id2windowidx = None
         self._q = query_feats
         self.videofeat = {k: torch.from_numpy(v) for k, v in video_feats.items()}  # RAW (H2)
+        if motion_feats is not None:        # a second visual source (the reference's motion_feat_dir != appearance_feat_dir)
+            self.same_visual_path = False
+            self.motion_videofeat = {k: torch.from_numpy(v) for k, v in motion_feats.items()}
 
     def _get_query_feat_by_qid(self, qid):
         q = self._q[qid]
@@ -204,10 +207,12 @@ def gen_stage_a(name, preset, seed, ctx_ls):
 
 
 def gen_e2e(name, preset, seed, n_queries, n_videos, ctx_range, **optkw):
-    """The unmodified reference eval_epoch on an in-memory split -> submission files."""
+    """The unmodified reference eval_epoch on an in-memory split -> submission files.  ``v_motion_feat_dim`` in optkw:
+    the window model reads a SECOND visual source of that width (synth.make_motion_feats, seed = the data seed)."""
     opt = ref_opt(preset, nms_thd=0.5, eval_split_name="test", save_all=True, **optkw)
     model, cks = ref_model(opt, seed)
     ann, vf, qf = synth.make_dataset(opt, n_queries, n_videos, seed=3000 + seed, ctx_range=ctx_range)
+    mf = synth.make_motion_feats(opt, vf, seed=3000 + seed) if "v_motion_feat_dim" in optkw else None
     captured = {}
     orig = ref_inf.get_eval_res
 
@@ -217,7 +222,7 @@ def gen_e2e(name, preset, seed, n_queries, n_videos, ctx_range, **optkw):
         return res
 
     ref_inf.get_eval_res = spy
-    se = MemSE(opt, ann, vf, qf)
+    se = MemSE(opt, ann, vf, qf, mf)
     with tempfile.TemporaryDirectory() as td:
         opt.results_dir = td
         opt.eval_path = os.path.join(td, "ann.jsonl")
@@ -503,6 +508,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "prenorm":
         gen_stage_b("stageB_ego4d_prenorm", "ego4d", 4, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], pre_norm=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "two_sources":
+        gen_e2e("e2e_ego4d_two_sources", "ego4d", 5, 10, 3, (100, 330), v_motion_feat_dim=128, eval_bsz=4, topk_window=4)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "txtpos":
         gen_stage_b("stageB_ego4d_txtpos", "ego4d", 3, [90, 45, 90, 17, 1, 63], [12, 5, 20, 9, 7, 17], use_txt_pos=True)
         return
@@ -517,6 +525,9 @@ def main():
     gen_e2e("e2e_ego4d", "ego4d", 0, 12, 3, (300, 420))
     gen_e2e("e2e_ego4d_small_bsz", "ego4d", 2, 9, 2, (80, 200), eval_bsz=4, topk_window=3)
     gen_e2e("e2e_mad", "mad", 1, 6, 2, (500, 800), topk_window=5)
+    # two visual sources (cone/ego4d_mad_dataloader.py:63-81): motion features (128-d) into the window model, appearance
+    # features (256-d) into the pre-filter and the proposal matching
+    gen_e2e("e2e_ego4d_two_sources", "ego4d", 5, 10, 3, (100, 330), v_motion_feat_dim=128, eval_bsz=4, topk_window=4)
     gen_stage_c("stageC", 0)
     gen_matcher("matcher", 0)
     gen_criterion("criterion", 0)

@@ -875,19 +875,24 @@ def test_matcher_cost_matches_reference_golden(golden_dir):
 
 # ------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("name,split_bf16", [("e2e_ego4d", 0), ("e2e_ego4d_small_bsz", 0), ("e2e_mad", 0), ("e2e_ego4d", 1),
-                                             ("e2e_mad", 1)], indirect=["split_bf16"])
+                                             ("e2e_mad", 1), ("e2e_ego4d_two_sources", 0), ("e2e_ego4d_two_sources", 1)],
+                         indirect=["split_bf16"])
 def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path, split_bf16):
     from cone_amd import inference as inf
     with open(os.path.join(golden_dir, name + ".json")) as f:
         fx = json.load(f)
     preset = fx["preset"]
-    model, _, _ = get_model(preset, fx["weight_seed"])
+    # e2e_ego4d_two_sources: the reference ran with motion_feat_dir != appearance_feat_dir (cone/ego4d_mad_dataloader.py:63-81):
+    # 128-d motion features into the window model, 256-d appearance features into the pre-filter and the matching
+    model_kw = {k: v for k, v in fx["opt"].items() if k == "v_motion_feat_dim"}
+    model, _, _ = get_model(preset, fx["weight_seed"], **model_kw)
     model.set_option("split_bf16", split_bf16)
     opt = make_opt(preset, nms_thd=0.5, eval_split_name="test", save_all=True, results_dir=str(tmp_path),
                    **fx["opt"])
     ann, vf, qf = synth.make_dataset(opt, fx["n_queries"], fx["n_videos"], seed=fx["data_seed"],
                                      ctx_range=tuple(fx["ctx_range"]))
-    store = inf.FeatureStore(opt, ann, vf, qf)
+    mf = synth.make_motion_feats(opt, vf, seed=fx["data_seed"]) if model_kw else None
+    store = inf.FeatureStore(opt, ann, vf, qf, motion_feats=mf)
     win_idx = inf.prefilter(model, store, opt)
     # window rank lists: exact
     for qi, row in enumerate(ann):
@@ -930,7 +935,7 @@ def test_end_to_end_matches_reference_golden(golden_dir, name, tmp_path, split_b
             n_cmp += int(ok.sum())
     # ... and the proposals next to a clip boundary are not skipped: every (window, slot) matching score must equal the
     # oracle's pooling of OUR span on the same padded window, either neighbouring pooling being admissible at a boundary
-    _, _, sd_t = get_model(preset, fx["weight_seed"])
+    _, _, sd_t = get_model(preset, fx["weight_seed"], **model_kw)
     n_chk, n_bnd, worst_alt = check_matching_vs_own_spans(sd_t, opt, store, wt, raw)
     assert n_chk == safe.size and worst_alt <= 1e-4, (n_chk, safe.size, worst_alt)
     record_measured(f"e2e[{name},split={split_bf16}]", rows=int(safe.size), safe_share=float(safe.mean()),
@@ -1119,6 +1124,56 @@ def test_pre_norm_pipeline_matches_oracle():
             agree += 1
     record_measured("pre_norm_pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, share=agree / len(f1))
     assert agree >= PIPELINE_FLOOR * len(f1), agree
+
+
+def test_two_visual_sources_pipeline_matches_oracle():
+    """motion_feat_dir != appearance_feat_dir (cone/ego4d_mad_dataloader.py:63-81, 134-158): the window model reads the MOTION
+    features (here 256-d against MAD's 512-d appearance features), the pre-filter and the proposal matching the APPEARANCE
+    features.  The reference's own run of that case is the fixture e2e_ego4d_two_sources (test_end_to_end_matches_reference_golden);
+    here the other preset against the oracle: rank lists exact, kept moments, chunk invariance, the padded entry on the
+    reference's collated batch (motion tensor into forward, appearance tensor into forward_clip_matching) = the arena entry bit
+    for bit, and the motion source is really the one the window model reads."""
+    import bench as B_
+    from cone_amd import inference as inf
+    kw = dict(v_motion_feat_dim=256)
+    model, _, sd = get_model("mad", 8, **kw)
+    opt = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=4, eval_bsz=4, **kw)
+    ann, vf, qf = synth.make_dataset(opt, 11, 2, seed=31, ctx_range=(200, 600))
+    mf = synth.make_motion_feats(opt, vf, seed=31)
+    store = inf.FeatureStore(opt, ann, vf, qf, motion_feats=mf)
+    (f1, p1, m1), info = inf.predict_split(model, store, opt)
+    opt2 = make_opt("mad", nms_thd=0.5, eval_split_name="test", topk_window=4, eval_bsz=4, window_batch=17, pipeline_chunks=2, **kw)
+    (f2, p2, m2), _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf, motion_feats=mf), opt2)
+    assert f1 == f2 and p1 == p2 and m1 == m2
+    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf, motion_feats=mf)
+    for qi, row in enumerate(ann):
+        assert [w for w in info["win_idx"][qi].cpu().tolist() if w >= 0] == ranks[row["query_id"]][:4]
+    mine, _ = inf.compute_mr_results(model, store, opt, info["win_idx"])
+    worst = max(np.abs(np.array(a["pred_relevant_windows"])[:, 2] - np.array(b["pred_relevant_windows"])[:, 2]).max()
+                for a, b in zip(mine, mr))
+    agree = 0
+    for a, b in zip(f1, fo):
+        ra, rb = np.array(a["predicted_times"]), np.array(b["predicted_times"])
+        if ra.shape == rb.shape and np.abs(ra - rb).max() <= 1e-4 * opt.max_v_l * opt.clip_length + 2e-4:
+            agree += 1
+    record_measured("two_sources_pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, worst_proposal_score=float(worst))
+    assert worst <= 2e-4 and agree >= PIPELINE_FLOOR * len(f1), (worst, agree)
+    inputs, wt1, sub1 = B_.reference_batch_tensors(model, store, opt)
+    assert inputs["src_vid_motion"].shape[2] == 256 and inputs["src_vid_appear"].shape[2] == 512
+    o1 = model(**{k: inputs[k] for k in ("src_txt", "src_txt_mask", "src_vid_motion", "src_vid_motion_mask")})
+    mt1 = model.forward_clip_matching(inputs["src_cls_txt"], inputs["src_vid_appear"], inputs["src_vid_motion_mask"],
+                                      proposal=o1["pred_spans"])
+    wt_all = inf.window_table(sub1, opt, inf.prefilter(model, sub1, opt))
+    raw = inf.run_windows(model, sub1, opt, wt_all)
+    for k in ("pred_logits", "pred_spans"):
+        assert torch.equal(o1[k], raw[k]), k
+    assert torch.equal(mt1, raw["matching"])
+    with pytest.raises(ValueError):         # the appearance tensor is not a model input here: refused by width, not read with
+        model(src_txt=inputs["src_txt"], src_txt_mask=inputs["src_txt_mask"], src_vid_motion=inputs["src_vid_appear"],
+              src_vid_motion_mask=inputs["src_vid_motion_mask"])                                  # the wrong row stride
+    # the same store without the motion arena cannot even be projected by this model (256-d input projection, 512-d clips)
+    with pytest.raises(ValueError):
+        inf.predict_split(model, inf.FeatureStore(opt, ann, vf, qf), opt)
 
 
 def test_use_txt_pos_pipeline_matches_oracle():

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cone_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-    assert lib.cone_abi_version() == 6
+    assert lib.cone_abi_version() == 7
     assert lib.cone_num_windows(901, 90) == 22 and lib.cone_num_windows(1250, 125) == 22
 
 
@@ -228,6 +228,49 @@ def test_feature_store_from_reference_dataset_objects():
     raw = FeatureStore.from_datasets(opt, ds, RefLikeDatasets(opt, ann, vf, qf, normalize_t=False),
                                      device=torch.device("cpu"))
     assert not raw.tok_normalized and torch.equal(raw.tok_raw, plain.tok_raw)
+
+
+def test_feature_store_with_two_visual_sources(tmp_path, monkeypatch):
+    """motion_feat_dir != appearance_feat_dir (cone/ego4d_mad_dataloader.py:63-81, 94-95, 134-151): the store carries a second
+    arena with the same rows; every constructor fills it (arrays, the reference's LMDBs, its dataset objects, the packed
+    file), views alias it, and a motion source of another length is refused (the reference would slice it with the
+    appearance length and silently shift the windows)."""
+    import sys
+    import fake_lmdb
+    from cone_amd.inference import FeatureStore
+    monkeypatch.setitem(sys.modules, "lmdb", fake_lmdb)
+    cpu = torch.device("cpu")
+    base = make_opt("ego4d", v_motion_feat_dim=128)
+    ann, vf, qf = synth.make_dataset(base, 9, 3, seed=6, ctx_range=(30, 90))
+    mf = synth.make_motion_feats(base, vf, seed=6)
+    a = FeatureStore(base, ann, vf, qf, device=cpu, motion_feats=mf)
+    assert a.mot_raw.shape == (a.vid_raw.shape[0], 128) and a.vid_raw.shape[1] == 256
+    assert torch.equal(a.mot_raw, torch.from_numpy(np.concatenate([mf[c] for c in a.clip_ids])))
+    assert FeatureStore(base, ann, vf, qf, device=cpu).mot_raw is None
+    v = a.view(2, 6)
+    assert v.mot_raw.data_ptr() == a.mot_raw.data_ptr() and v.vid_raw.data_ptr() == a.vid_raw.data_ptr()
+    # the reference's stores: two video LMDBs
+    vdir, tdir, eval_path = _write_reference_stores(tmp_path, base, ann, vf, qf)
+    mdir = fake_lmdb.write_env(str(tmp_path / "motion_lmdb"), {c: {"features": m} for c, m in mf.items()})
+    opt = make_opt("ego4d", v_motion_feat_dim=128, eval_path=eval_path, motion_feat_dir=mdir, appearance_feat_dir=vdir,
+                   t_feat_dir=tdir)
+    b = FeatureStore.from_lmdb(opt, device=cpu)
+    for k in ("vid_raw", "mot_raw", "tok_raw", "cls_raw"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    # the reference's dataset objects (eval_epoch(model, inter_ds, intra_ds, ...))
+    ds = RefLikeDatasets(base, ann, vf, qf)
+    ds.same_visual_path, ds.motion_videofeat = False, {c: torch.from_numpy(m) for c, m in mf.items()}
+    c = FeatureStore.from_datasets(base, ds, ds, device=cpu)
+    assert torch.equal(c.mot_raw, a.mot_raw) and torch.equal(c.vid_raw, a.vid_raw)
+    # the packed arena file carries the fourth arena; files without it load as before
+    d = FeatureStore.from_packed(base, a.save_packed(str(tmp_path / "two.conefs")), device=cpu)
+    assert torch.equal(d.mot_raw, a.mot_raw) and torch.equal(d.vid_raw, a.vid_raw)
+    one = FeatureStore(base, ann, vf, qf, device=cpu)
+    assert FeatureStore.from_packed(base, one.save_packed(str(tmp_path / "one.conefs")), device=cpu).mot_raw is None
+    short = dict(mf)
+    short[a.clip_ids[1]] = short[a.clip_ids[1]][:-1]
+    with pytest.raises(ValueError):
+        FeatureStore(base, ann, vf, qf, device=cpu, motion_feats=short)
 
 
 def test_debug_and_results_dir_options(tmp_path):

@@ -93,7 +93,7 @@ def test_stage_c_matches_reference(golden_dir):
         assert got == case["out"]
 
 
-@pytest.mark.parametrize("name", ["e2e_ego4d", "e2e_ego4d_small_bsz", "e2e_mad"])
+@pytest.mark.parametrize("name", ["e2e_ego4d", "e2e_ego4d_small_bsz", "e2e_mad", "e2e_ego4d_two_sources"])
 def test_end_to_end_matches_reference(golden_dir, name):
     with open(os.path.join(golden_dir, name + ".json")) as f:
         fx = json.load(f)
@@ -102,7 +102,10 @@ def test_end_to_end_matches_reference(golden_dir, name):
     assert synth.state_dict_checksum(sd) == fx["weight_checksum"]
     ann, vf, qf = synth.make_dataset(opt, fx["n_queries"], fx["n_videos"], seed=fx["data_seed"],
                                      ctx_range=tuple(fx["ctx_range"]))
-    (fusion, proposal, matching), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    # e2e_ego4d_two_sources: the reference read a second, 128-d visual source for the window model (motion_feat_dir !=
+    # appearance_feat_dir, cone/ego4d_mad_dataloader.py:63-81, 134-151)
+    mf = synth.make_motion_feats(opt, vf, seed=fx["data_seed"]) if "v_motion_feat_dim" in fx["opt"] else None
+    (fusion, proposal, matching), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf, motion_feats=mf)
     assert {k: v for k, v in ranks.items()} == fx["ranks"]
     # window-level rows: identical up to fp noise before the 4-decimal rounding
     assert len(mr) == len(fx["mr_res"])
