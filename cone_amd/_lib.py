@@ -57,7 +57,8 @@ class Weights(C.Structure):
 
 class Layer0(C.Structure):
     _fields_ = [("qkv_vid", C.c_void_p), ("qkv_txt", C.c_void_p), ("pos_qk", C.c_void_p), ("pos_rows", C.c_void_p),
-                ("max_v_l", C.c_int32)]
+                ("max_v_l", C.c_int32),
+                ("txt_pos", C.c_void_p), ("txt_pos_qk", C.c_void_p), ("n_txt", C.c_int64)]   # ABI 7: --use_txt_pos rows
 
 
 class Taps(C.Structure):
@@ -105,6 +106,7 @@ _SIGNATURES = {
     "cone_pos_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_layer0_project_workspace": (C.c_size_t, [C.c_void_p, C.c_int64]),
     "cone_layer0_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cone_layer0_text_positions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cone_clip_matching_workspace": (C.c_size_t, [C.c_void_p, C.c_int]),
     "cone_clip_matching_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -434,13 +434,17 @@ struct FwdBuffers {
     float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
     float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS;
 };
-struct FwdPlan { bool tables, fold; };
+struct FwdPlan { bool tables, fold, dec_xp = false; };
 // What a call runs on: the caller's cone_layer0 with the handle's position tables filled in where it brings none (ABI 6: a
 // NULL cone_layer0, or one with the row caches only, still takes the table path), or nothing for --use_txt_pos (the general
 // path: the caches / tables assume a zero text position term) and for windows longer than the handle's tables cover.
-static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff) {
-    if (m->txt_pos_emb) return nullptr;
+static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff,
+                                       bool own_txt = false) {
+    // --use_txt_pos: the table path needs the tokens' own position rows (cone_layer0_text_positions) -- handed over in l0, or
+    // (own_txt: the padded entry) built by the caller itself; without them, and for --pre_norm with it, the general path
+    if (m->txt_pos_emb && (m->pre_norm || !(own_txt || (l0 && l0->txt_pos && l0->txt_pos_qk)))) return nullptr;
     *eff = l0 ? *l0 : cone_layer0{};
+    if (!m->txt_pos_emb) eff->txt_pos = eff->txt_pos_qk = nullptr;
     if (!eff->qkv_vid || !eff->qkv_txt) eff->qkv_vid = eff->qkv_txt = nullptr;
     if (!eff->pos_rows || !eff->pos_qk) {                   // no (complete) tables of the caller's: the handle's
         if (Lv_max > m->tab_max_v_l) return nullptr;
@@ -452,7 +456,10 @@ static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l
 static FwdPlan plan_for(const cone_model* m, bool have_tables, bool caches, int Lmax) {
     FwdPlan p;
     p.tables = have_tables && m->opt_pos_tables && (!caches || m->opt_l0_gather);
-    p.fold = m->opt_dec_fold >= 2 ? dec_cross_mfma_supported(m->nq, Lmax, p.tables)
+    // --use_txt_pos on the table path: the decoder's keys memory + pos are written once behind the encoder (clip rows from the
+    // table, text rows from the tokens' own position rows) and the cross-attention runs its x + pos form on them
+    p.dec_xp = p.tables && m->txt_pos_emb != nullptr;
+    p.fold = m->opt_dec_fold >= 2 ? dec_cross_mfma_supported(m->nq, Lmax, p.tables && !p.dec_xp)
                                   : (m->opt_dec_fold == 1 && dec_cross_supported(m->nq, Lmax));
     if (m->pre_norm) {  // the fused pre-norm path needs all of: tables, the fused layer tail, the matrix-core fold; else the
                         // general pre-norm path (plain LayerNorm / GEMM / attention launches)
@@ -464,10 +471,20 @@ static FwdPlan plan_for(const cone_model* m, bool have_tables, bool caches, int 
     // encoder (launch_add_pos_rows) -- slot counts other than 5 keep the encoder's fast path.  The fold switched off BY OPTION
     // (parity tests) keeps meaning the whole general path
     if (!p.fold && !(m->opt_dec_fold && m->nq != 5)) p.tables = false;
+    if (!p.tables) p.dec_xp = false;
     return p;
 }
 static FwdPlan plan_of(const cone_model* m, const cone_layer0* l0 /* effective_l0 */, int Lmax) {
     return plan_for(m, l0 && l0->pos_rows && l0->pos_qk, l0 && l0->qkv_vid, Lmax);
+}
+// effective_l0 + plan_of; a --use_txt_pos model that cannot take the table path (an A/B switch, a window too long for the
+// x + pos form of the fold) drops to the WHOLE general path: its row caches do not carry the text position term
+static const cone_layer0* resolve_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, int Lmax, cone_layer0* eff,
+                                     FwdPlan* plan) {
+    const cone_layer0* e = effective_l0(m, l0, Lv_max, eff);
+    *plan = plan_of(m, e, Lmax);
+    if (m->txt_pos_emb && e && !plan->tables) { e = nullptr; *plan = plan_of(m, nullptr, Lmax); }
+    return e;
 }
 static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const FwdPlan& p, FwdBuffers& f) {
     const size_t M = (size_t)B * Lmax, T = (size_t)B * m->nq, nd = m->n_dec;
@@ -483,7 +500,8 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
         f.QKV = c.take<float>(M * 768); f.ATT = c.take<float>(M * 256);
     }
     if (!p.fold) { f.KD = c.take<float>(M * 256 * nd); f.VD = c.take<float>(M * 256 * nd); }
-    if (!p.fold && p.tables) f.XP = c.take<float>(M * 256);      // memory + pos for the unfolded decoder (launch_add_pos_rows)
+    if ((!p.fold || p.dec_xp) && p.tables) f.XP = c.take<float>(M * 256);   // memory + pos for the unfolded decoder / the
+                                                                            // x + pos form of the fold (launch_add_pos_rows)
     f.TGT = c.take<float>(T * 256); f.TGT1 = c.take<float>(T * 256); f.TGT2 = c.take<float>(T * 256);
     f.DQK = c.take<float>(T * 768); f.DV = nullptr; f.DATT = c.take<float>(T * 256);      // DQK: the slots' q | k | v
     f.DQ = c.take<float>(T * 256); f.DH = c.take<float>(T * m->ff);
@@ -694,12 +712,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         CONE_REQUIRE(Lq_max <= m->txt_pos_rows, "forward: %d text tokens but txt_position_embed has %d rows (max_q_l)", Lq_max,
                      m->txt_pos_rows);
     cone_layer0 eff;
-    l0 = effective_l0(m, l0, Lv_max, &eff);
+    FwdPlan plan;
+    l0 = resolve_l0(m, l0, Lv_max, Lmax, &eff, &plan);
     const bool caches = l0 && l0->qkv_vid;
     if (l0)     // (the handle's own tables or the caller's: either must cover the longest window of the call)
         CONE_REQUIRE(l0->pos_qk && l0->max_v_l >= Lv_max,
                      "forward: position tables / layer-0 cache built for a shorter window (%d < %d clips)", l0->max_v_l, Lv_max);
-    const FwdPlan plan = plan_of(m, l0, Lmax);
     Carver c(ws, ws_bytes);
     FwdBuffers f;
     carve_fwd(m, c, B, Lmax, plan, f);
@@ -749,6 +767,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             mode = ATTN_GATHER;
             src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.pos_qk = l0->pos_qk;
             src.vrow0 = vrow0; src.vlen = vlen; src.trow0 = trow0; src.pos_zero_row = (int)pos_rows_n - 1;
+            src.txt_pos_qk = l0->txt_pos_qk;                                   // (--use_txt_pos: this layer's = the first image)
         } else if (l == 0 && caches) {                     // packed by pack_l0: (M, 512) q|k then (M, 256) v
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + (size_t)Mmax * 512;
             src.ldq = src.ldk = 512; src.ldv = 256;
@@ -765,6 +784,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
             mode = ATTN_POSADD;
             src.Q = f.QKV; src.K = f.QKV + 256; src.V = f.QKV + 512; src.ldq = src.ldk = src.ldv = 768;
             src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512; src.vlen = vlen; src.pos_zero_row = (int)pos_rows_n - 1;
+            if (l0->txt_pos_qk) { src.txt_pos_qk = l0->txt_pos_qk + (size_t)l * l0->n_txt * 512; src.trow0 = trow0; }
         } else {
             float* QK = f.QKV; float* V = f.QKV + (size_t)Mmax * 512;
             RUN(launch_gemm(G(m, f.XP, 256, e.sa.in_w, 256, e.sa.in_b, QK, 512, Mmax, Mdev, 512, 256), s));  // q | k = (x+pos) W^T
@@ -830,8 +850,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     // (the chain only where launch_gemm itself would run its 16-row form, and only on the automatic tile family: the A/B
     // families walk k in other orders)
     const bool heads_chain = m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T);
+    // the position rows come from the tables inside the cross-attention kernels -- unless text tokens carry their own
+    // (--use_txt_pos): then memory + pos is written once (dec_xp) and the kernels run their x + pos form
+    const bool dec_tab = plan.tables && !plan.dec_xp;
+    if (plan.dec_xp) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s, l0->txt_pos, trow0));
     if (!fold) {
-        if (plan.tables) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s));
+        if (dec_tab) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s));
         GemmArgs g = G(m, f.XP, 256, m->dec_k.w, 256, m->dec_k.b, f.KD, 256 * nd, Mmax, Mdev, 256 * nd, 256);
         RUN(launch_gemm(g, s));                                                             // k = (memory+pos) W_k^T
         RUN(launch_gemm(G(m, MEM, 256, m->dec_v.w, 256, m->dec_v.b, f.VD, 256 * nd, Mmax, Mdev, 256 * nd, 256), s));
@@ -866,12 +890,12 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (fold && m->opt_dec_fold >= 2) {
             // the first layer's launch holds every memory row of the batch in registers anyway: the saliency head rides along
             // (table form of the default kernel; other forms: the separate pass at the end)
-            const bool ride = l == 0 && saliency && plan.tables && (m->opt_dec_fold == 2 || m->opt_dec_fold == 3 || m->opt_dec_fold == 5);
+            const bool ride = l == 0 && saliency && dec_tab && (m->opt_dec_fold == 2 || m->opt_dec_fold == 3 || m->opt_dec_fold == 5);
             if (ride) {
                 CONE_CHECK_HIP(hipMemsetAsync(saliency, 0, (size_t)B * Lv_max * sizeof(float), s));     // padded clips: 0
                 sal_done = true;
             }
-            RUN(launch_dec_cross_mfma(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
+            RUN(launch_dec_cross_mfma(f.DQ, dec_tab ? nullptr : f.XP, MEM, dec_tab ? l0->pos_rows : nullptr, vlen,
                                       f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax,
                                       Tq != T ? f.QKS : nullptr, s,       // layer 0: the same queries for every window
                                       // the kernel form.  Default: rows-once for the first layer, two-read behind it -- by
@@ -882,7 +906,7 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                                       ride ? Lv_max : 0));
         }
         else if (fold)
-            RUN(launch_dec_cross(f.DQ, plan.tables ? nullptr : f.XP, MEM, plan.tables ? l0->pos_rows : nullptr, vlen,
+            RUN(launch_dec_cross(f.DQ, dec_tab ? nullptr : f.XP, MEM, dec_tab ? l0->pos_rows : nullptr, vlen,
                                  f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, s));
         else
             RUN(launch_small_attn(f.DQ, 256, f.KD + l * 256, 256 * nd, f.VD + l * 256, 256 * nd, f.DATT, 256, f.off, B,
@@ -1022,7 +1046,9 @@ extern "C" int cone_project_tokens(const cone_model* m, int which, const float* 
 extern "C" size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
                                                 const cone_layer0* l0) {
     cone_layer0 eff;
-    return fwd_ws_bytes(m, B, Lv_max + Lq_max, plan_of(m, effective_l0(m, l0, Lv_max, &eff), Lv_max + Lq_max));
+    FwdPlan plan;
+    resolve_l0(m, l0, Lv_max, Lv_max + Lq_max, &eff, &plan);
+    return fwd_ws_bytes(m, B, Lv_max + Lq_max, plan);
 }
 extern "C" int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
                                    const int32_t* vid_len, const float* tproj, const int32_t* txt_row0,
@@ -1040,6 +1066,25 @@ extern "C" int64_t cone_pos_table_rows(int max_v_l) { return pos_table_rows(max_
 extern "C" int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream) {
     CONE_REQUIRE(m && pos_rows && pos_qk && max_v_l >= 1 && max_v_l <= CONE_TABLE_MAX_V_L, "pos_tables: bad argument");
     return build_pos_tables(m, max_v_l, pos_rows, pos_qk, (hipStream_t)stream);
+}
+
+// --use_txt_pos on the table path: the tokens' own position rows and their images under every encoder layer's [W_q | W_k]
+// (rows of a GEMM are independent: an arena row and the same token as a compact row of the padded entry get the same bits)
+static int text_positions(const cone_model* m, const float* tproj, const int* tok_index, const int* src_row, int mod, int n,
+                          const int* n_dev, float* txt_pos, float* txt_pos_qk, hipStream_t s) {
+    RUN(launch_txt_pos_rows(tproj, tok_index, src_row, mod, m->txt_pos_rows, m->txt_pos_emb, m->txt_pos_ln.g, m->txt_pos_ln.b, n,
+                            n_dev, txt_pos, s));
+    for (int l = 0; l < m->n_enc; ++l)
+        RUN(launch_gemm(G(m, txt_pos, 256, m->enc[l].sa.in_w, 256, nullptr, txt_pos_qk + (size_t)l * n * 512, 512, n, n_dev, 512,
+                          256), s));
+    return 0;
+}
+extern "C" int cone_layer0_text_positions(const cone_model* m, const float* txt_proj_rows, const int32_t* tok_index,
+                                          int64_t n_rows, float* txt_pos, float* txt_pos_qk, void* stream) {
+    CONE_REQUIRE(m && txt_proj_rows && tok_index && txt_pos && txt_pos_qk && n_rows < (1ll << 31), "layer0_text_positions: bad argument");
+    CONE_REQUIRE(m->txt_pos_emb, "layer0_text_positions: the model has no txt_position_embed (--use_txt_pos)");
+    if (n_rows <= 0) return 0;
+    return text_positions(m, txt_proj_rows, tok_index, nullptr, 1, (int)n_rows, nullptr, txt_pos, txt_pos_qk, (hipStream_t)stream);
 }
 
 extern "C" size_t cone_layer0_project_workspace(const cone_model* m, int64_t n_rows) {
@@ -1060,34 +1105,41 @@ extern "C" int cone_layer0_project(const cone_model* m, const float* proj_rows, 
 // layer, position tables, fused layer tails, folded decoder), bit for bit.
 struct PaddedCarve {
     int *voff, *toff, *vidx, *tidx;
-    float *vp, *tp, *qv, *qt;
+    float *vp, *tp, *qv, *qt, *pt, *ptqk;
     char* pws; size_t pw;
 };
-static void carve_padded(const cone_model* m, Carver& c, int B, int Lv_pad, int Lq_pad, bool caches, PaddedCarve& p) {
+static void carve_padded(const cone_model* m, Carver& c, int B, int Lv_pad, int Lq_pad, bool caches, bool txt_tables,
+                         PaddedCarve& p) {
     const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
     p.voff = c.take<int>(B + 1); p.toff = c.take<int>(B + 1);
     p.vidx = c.take<int>(nv); p.tidx = c.take<int>(nt);
     p.vp = c.take<float>(nv * 256); p.tp = c.take<float>(nt * 256);
-    p.qv = p.qt = nullptr;
+    p.qv = p.qt = p.pt = p.ptqk = nullptr;
     if (caches) { p.qv = c.take<float>(nv * 768); p.qt = c.take<float>(nt * 768); }
+    if (txt_tables) { p.pt = c.take<float>(nt * 256); p.ptqk = c.take<float>((size_t)m->n_enc * nt * 512); }   // --use_txt_pos
     p.pw = project_ws_bytes(m, 0, nv);
     const size_t pt = project_ws_bytes(m, 1, nt);
     if (pt > p.pw) p.pw = pt;
     p.pws = c.take<char>(p.pw);
 }
-static bool padded_uses_caches(const cone_model* m, int Lv_pad) {
+// What the padded entry runs on: the handle's tables, first-layer row caches it builds itself, and for a --use_txt_pos model
+// the text position rows it builds itself (such a model off the table path: nothing of it -- the general path)
+static FwdPlan padded_plan(const cone_model* m, int Lv_pad, int Lmax, bool* caches, bool* txt_tables) {
     cone_layer0 eff;
-    const cone_layer0* l0 = effective_l0(m, nullptr, Lv_pad, &eff);
-    return l0 && m->opt_pos_tables && m->opt_l0_gather;
+    const cone_layer0* l0 = effective_l0(m, nullptr, Lv_pad, &eff, true);
+    *caches = l0 && m->opt_pos_tables && m->opt_l0_gather;
+    FwdPlan p = plan_for(m, l0 != nullptr, *caches, Lmax);
+    if (m->txt_pos_emb && !p.tables) { *caches = false; p = plan_for(m, false, false, Lmax); }
+    *txt_tables = m->txt_pos_emb && p.tables;
+    return p;
 }
 extern "C" size_t cone_forward_workspace(const cone_model* m, int B, int Lv_pad, int Lq_pad) {
-    const bool caches = padded_uses_caches(m, Lv_pad);
+    bool caches, txt_tables;
+    const FwdPlan plan = padded_plan(m, Lv_pad, Lv_pad + Lq_pad, &caches, &txt_tables);
     Carver c(nullptr, ~(size_t)0);
     PaddedCarve p;
-    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, p);
-    cone_layer0 eff;
-    const bool have_tables = effective_l0(m, nullptr, Lv_pad, &eff) != nullptr;
-    return c.cur + fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan_for(m, have_tables, caches, Lv_pad + Lq_pad));
+    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, txt_tables, p);
+    return c.cur + fwd_ws_bytes(m, B, Lv_pad + Lq_pad, plan);
 }
 extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const int32_t* vid_len, const float* txt,
                                     const int32_t* txt_len, int B, int Lv_pad, int Lq_pad, float* logits,
@@ -1098,10 +1150,11 @@ extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const
     CONE_REQUIRE((int64_t)B * Lv_pad < (1ll << 31) && (int64_t)B * Lq_pad < (1ll << 31), "forward_windows: batch too large");
     hipStream_t s = (hipStream_t)stream;
     const size_t nv = (size_t)B * Lv_pad, nt = (size_t)B * Lq_pad;
-    const bool caches = padded_uses_caches(m, Lv_pad);
+    bool caches, txt_tables;
+    padded_plan(m, Lv_pad, Lv_pad + Lq_pad, &caches, &txt_tables);
     Carver c(ws, ws_bytes);
     PaddedCarve p;
-    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, p);
+    carve_padded(m, c, B, Lv_pad, Lq_pad, caches, txt_tables, p);
     if (!c.ok) { set_error("forward_windows: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     // compact row lists of the valid clips / tokens: offsets (= the windows' first rows), source-row indices, device counts
     RUN(launch_scan_lengths(vid_len, nullptr, B, p.voff, s));
@@ -1115,8 +1168,12 @@ extern "C" int cone_forward_windows(const cone_model* m, const float* vid, const
         RUN(layer0_rows(m, p.tp, (int)nt, p.toff + B, p.qt, (float*)p.pws, s));
         l0.qkv_vid = p.qv; l0.qkv_txt = p.qt;
     }
+    if (txt_tables) {   // a compact token row's index in its query = its column in the padded batch (masks are prefixes)
+        RUN(text_positions(m, p.tp, nullptr, p.tidx, Lq_pad, (int)nt, p.toff + B, p.pt, p.ptqk, s));
+        l0.txt_pos = p.pt; l0.txt_pos_qk = p.ptqk; l0.n_txt = (int64_t)nt;
+    }
     return forward_packed(m, p.vp, p.voff, vid_len, p.tp, p.toff, txt_len, B, Lv_pad, Lq_pad, logits, spans, saliency,
-                          taps, (char*)ws + c.cur, ws_bytes - c.cur, s, caches ? &l0 : nullptr);
+                          taps, (char*)ws + c.cur, ws_bytes - c.cur, s, caches || txt_tables ? &l0 : nullptr);
 }
 
 extern "C" size_t cone_clip_matching_workspace(const cone_model* m, int B) {

@@ -110,9 +110,14 @@ __device__ __forceinline__ void attn_normalise(f32x4m& o0, f32x4m& o1, float inv
 // Windows of 193 .. 256 tokens (NKT 13 .. 16: WINDOW_LENGTH is a user argument of the reference's scripts, README.md:94-98) need
 // 57 .. 70 KiB for the two images: dynamic LDS (opt-in above 64 KiB), one workgroup of up to 1 024 threads; the shipped
 // window lengths (NKT <= 12) keep their static images and their instruction sequence.
-template <int NKT, int MODE>
+// MODE_ = MODE | 4 (--use_txt_pos on the table path): a text token adds ITS position row txt_pos_qk[trow0[b] + j] (this layer's
+// image of LayerNorm(src_txt + position_embeddings), cone/model.py:106) instead of the zero row -- the same unconditional add
+// from another uniform base; the instantiations without the bit are untouched.
+template <int NKT, int MODE_>
 __global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kernel(AttnSrc a, float* __restrict__ OUT,
                                                                  const int* __restrict__ off) {
+    constexpr int MODE = MODE_ & 3;
+    constexpr bool TXT = (MODE_ & 4) != 0;
     constexpr int KP = 16 * NKT, LDK = KP + 2, LDV = 36, NT = 64 * NKT;
     constexpr bool DYN = NKT > 12;
     __shared__ float KsT_s[DYN ? 4 : 32 * LDK];
@@ -147,6 +152,12 @@ __global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kerne
         qb = a.Q + (size_t)t0 * sq + hc; kb = a.K + (size_t)t0 * sk + hc; vb = a.V + (size_t)t0 * sv + hc;
     }
     const int zrow = a.pos_zero_row;
+    const float* tpb = nullptr;             // TXT: text token `tok` (>= lv) adds row tok of tpb (biased by -lv rows, like tb)
+    if (TXT) tpb = a.txt_pos_qk + ((ptrdiff_t)a.trow0[b] - lv) * 512 + hc;
+    auto prow = [&](int row) -> const float* {
+        if (TXT && row >= lv) return tpb + (unsigned)row * 512u;
+        return pb + (unsigned)(row < lv ? pbase + row : zrow) * 512u;
+    };
 
     // ONE memory round trip per workgroup: the query values, both staging passes (key rows kr and kr + NT/8: KP = 2 NT/8
     // exactly) and their position rows are all requested before anything is waited for.  Rows past the window re-read its
@@ -164,9 +175,9 @@ __global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kerne
         qx[0] = *reinterpret_cast<const f32x4m*>(qp);
         qx[1] = *reinterpret_cast<const f32x4m*>(qp + 4);
         if (MODE != ATTN_PACKED) {
-            const unsigned pr = (unsigned)(qrow < lv ? pbase + qrow : zrow) * 512u + 8u * lg;
-            qt[0] = *reinterpret_cast<const f32x4m*>(pb + pr);
-            qt[1] = *reinterpret_cast<const f32x4m*>(pb + pr + 4);
+            const float* pr = prow(qrow) + 8u * lg;
+            qt[0] = *reinterpret_cast<const f32x4m*>(pr);
+            qt[1] = *reinterpret_cast<const f32x4m*>(pr + 4);
         }
     }
 #pragma unroll
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kerne
             vv[it] = *reinterpret_cast<const f32x4m*>(vb + (unsigned)row * sv + c4);
         }
         if (MODE != ATTN_PACKED)
-            kt_[it] = *reinterpret_cast<const f32x4m*>(pb + (unsigned)(row < lv ? pbase + row : zrow) * 512u + 256u + c4);
+            kt_[it] = *reinterpret_cast<const f32x4m*>(prow(row) + 256u + c4);
     }
     float qv[8];
     {
@@ -374,9 +385,9 @@ __global__ __launch_bounds__(256, 2) void enc_attn_wave_kernel(AttnSrc a, float*
 template <int MODE>
 static int launch_enc_attn_t(const AttnSrc& a, float* OUT, const int* off, int B, int Lmax, hipStream_t s) {
     const int nkt = max(6, (Lmax + 15) / 16);     // short batches ride on the 6-wave build (spare waves exit early)
-    if (a.form == 2 && nkt <= 9) {                // the register-resident cross-check form (same bits), on request
+    if (a.form == 2 && nkt <= 9 && !(MODE & 4)) { // the register-resident cross-check form (same bits), on request
         dim3 wgrid(2, B);
-#define CONE_ATTNW(N) case N: hipLaunchKernelGGL((enc_attn_wave_kernel<N, MODE>), wgrid, dim3(256), 0, s, a, OUT, off); break;
+#define CONE_ATTNW(N) case N: hipLaunchKernelGGL((enc_attn_wave_kernel<N, (MODE & 3)>), wgrid, dim3(256), 0, s, a, OUT, off); break;
         switch (nkt) { CONE_ATTNW(6) CONE_ATTNW(7) CONE_ATTNW(8) CONE_ATTNW(9) }
 #undef CONE_ATTNW
         CONE_LAUNCH_CHECK();
@@ -417,10 +428,15 @@ int launch_enc_attn(int mode, const AttnSrc& a, float* OUT, const int* off, int 
         case ATTN_GATHER:
             CONE_REQUIRE(a.qkv_vid && a.qkv_txt && a.pos_qk && a.vrow0 && a.vlen && a.trow0 && a.pos_zero_row >= 0,
                          "enc attention: gather mode needs the layer-0 caches");
+            if (a.txt_pos_qk) return launch_enc_attn_t<ATTN_GATHER | 4>(a, OUT, off, B, Lmax, s);
             return launch_enc_attn_t<ATTN_GATHER>(a, OUT, off, B, Lmax, s);
         case ATTN_POSADD:
             CONE_REQUIRE(a.Q && a.K && a.V && a.pos_qk && a.vlen && a.pos_zero_row >= 0,
                          "enc attention: pos-add mode needs Q, K, V, pos_qk, vlen");
+            if (a.txt_pos_qk) {
+                CONE_REQUIRE(a.trow0, "enc attention: text position rows need trow0");
+                return launch_enc_attn_t<ATTN_POSADD | 4>(a, OUT, off, B, Lmax, s);
+            }
             return launch_enc_attn_t<ATTN_POSADD>(a, OUT, off, B, Lmax, s);
     }
     set_error("enc attention: unknown mode %d", mode);

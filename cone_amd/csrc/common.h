@@ -217,6 +217,7 @@ struct AttnSrc {
     const float* qkv_vid; const float* qkv_txt; const float* pos_qk;    // pos_qk (R, 512), row lv (lv - 1) / 2 + p
     int pos_zero_row;                             // a row of pos_qk that is all zeros (cone_pos_tables: its last row): what a text token adds
     const int* vrow0; const int* vlen; const int* trow0;
+    const float* txt_pos_qk;                      // --use_txt_pos on the table path: (n_txt, 512) rows of THIS layer, token row trow0[b] + j (needs trow0); NULL: the zero row
     int form;                                     // 0: the workgroup-per-(window, head) kernel; 2: one wave per (window, head), K / V in registers (same bits; <= 144 tokens)
 };
 int launch_enc_attn(int mode, const AttnSrc& src, float* OUT, const int* off, int B, int Lmax, hipStream_t s);
@@ -258,7 +259,9 @@ int launch_pack_pos(const float* vproj, const int* vrow0, const int* vlen, const
                     const float* tpb = nullptr);        // tpe != null: --use_txt_pos (embedding rows + its LayerNorm)
 int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s);
 int launch_add_pos_rows(const float* MEM, const int* off, const int* vlen, const float* pos_rows, float* XP, int B, int Lmax,
-                        hipStream_t s);     // XP = MEM + table row of (vlen[b], p) for clip tokens (the unfolded decoder's keys)
+                        hipStream_t s, const float* txt_pos = nullptr, const int* trow0 = nullptr);
+int launch_txt_pos_rows(const float* tproj, const int* tok_index, const int* src_row, int mod, int n_emb, const float* tpe,
+                        const float* tpg, const float* tpb, int n, const int* n_dev, float* out, hipStream_t s);     // XP = MEM + table row of (vlen[b], p) for clip tokens (the unfolded decoder's keys)
 // X always; POS (sine rows) and QK / V (layer-0 q|k|v gathered from the caches) only when non-null
 int launch_row_index(const int* vrow0, const int* vlen, const int* trow0, const int* qlen, const int* off, int* ridx,
                      int B, int Lmax, hipStream_t s);

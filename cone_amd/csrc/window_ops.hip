@@ -158,7 +158,8 @@ int launch_pos_rows(const float* dim_t, int max_v_l, float* out, hipStream_t s) 
 // specialised): clip token p of window b gets the table row (vlen[b], p), a text token nothing.  One wavefront per token.
 __global__ __launch_bounds__(256) void add_pos_rows_kernel(const float* __restrict__ MEM, const int* __restrict__ off,
                                                            const int* __restrict__ vlen, const float* __restrict__ pos_rows,
-                                                           float* __restrict__ XP) {
+                                                           float* __restrict__ XP, const float* __restrict__ txt_pos,
+                                                           const int* __restrict__ trow0) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -168,14 +169,52 @@ __global__ __launch_bounds__(256) void add_pos_rows_kernel(const float* __restri
     if (p < lv) {
         const float4 q = reinterpret_cast<const float4*>(pos_rows + ((size_t)(lv * (lv - 1) / 2 + p)) * 256)[lane];
         x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+    } else if (txt_pos) {       // --use_txt_pos: the token's own position row (cone_layer0_text_positions)
+        const float4 q = reinterpret_cast<const float4*>(txt_pos + (size_t)(trow0[b] + p - lv) * 256)[lane];
+        x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
     }
     reinterpret_cast<float4*>(XP + (size_t)(t0 + p) * 256)[lane] = x;
 }
 
 int launch_add_pos_rows(const float* MEM, const int* off, const int* vlen, const float* pos_rows, float* XP, int B, int Lmax,
-                        hipStream_t s) {
+                        hipStream_t s, const float* txt_pos, const int* trow0) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(add_pos_rows_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, MEM, off, vlen, pos_rows, XP);
+    hipLaunchKernelGGL(add_pos_rows_kernel, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, MEM, off, vlen, pos_rows, XP, txt_pos,
+                       trow0);
+    CONE_LAUNCH_CHECK();
+    return 0;
+}
+
+// --use_txt_pos on the table path: out[i] = LayerNorm(tproj[i] + E[index of token row i in its query]) (cone/model.py:106,
+// cone/position_encoding.py:21-31), one wave per token row -- the arithmetic of pack_pos_kernel's text branch.  The index
+// comes from tok_index[i], or (the padded entry's compact rows) from the row's place in the padded batch: src_row[i] % mod.
+__global__ __launch_bounds__(256) void txt_pos_rows_kernel(const float* __restrict__ tproj, const int* __restrict__ tok_index,
+                                                           const int* __restrict__ src_row, int mod, int n_emb,
+                                                           const float* __restrict__ tpe, const float* __restrict__ tpg,
+                                                           const float* __restrict__ tpb, int n, const int* __restrict__ n_dev,
+                                                           float* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= (n_dev ? min(*n_dev, n) : n)) return;
+    int j = tok_index ? tok_index[i] : src_row[i] % mod;
+    j = min(max(j, 0), n_emb - 1);      // (callers check the query length against the table: cone_forward_packed)
+    const float4 x = reinterpret_cast<const float4*>(tproj + (size_t)i * 256)[lane];
+    const float4 e = reinterpret_cast<const float4*>(tpe + (size_t)j * 256)[lane];
+    float4 v = make_float4(x.x + e.x, x.y + e.y, x.z + e.z, x.w + e.w);
+    const float mean = pack_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+    const float var = pack_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 256.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4 g = reinterpret_cast<const float4*>(tpg)[lane], bb = reinterpret_cast<const float4*>(tpb)[lane];
+    reinterpret_cast<float4*>(out + (size_t)i * 256)[lane] =
+        make_float4(v.x * rstd * g.x + bb.x, v.y * rstd * g.y + bb.y, v.z * rstd * g.z + bb.z, v.w * rstd * g.w + bb.w);
+}
+
+int launch_txt_pos_rows(const float* tproj, const int* tok_index, const int* src_row, int mod, int n_emb, const float* tpe,
+                        const float* tpg, const float* tpb, int n, const int* n_dev, float* out, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(txt_pos_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, tproj, tok_index, src_row, mod, n_emb, tpe, tpg,
+                       tpb, n, n_dev, out);
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -134,6 +134,8 @@ class FeatureStore:
             ix = store._index                               # (a pageable copy would wait for the stream to drain)
             sub._index = dict(q_ctx_l=ix["q_ctx_l"][lo:hi], q_vid_off=ix["q_vid_off"][lo:hi],
                               tok_off=ix["tok_off"][lo:hi + 1] - t0, tok_len=ix["tok_len"][lo:hi])
+            if "tok_idx" in ix:
+                sub._index["tok_idx"] = ix["tok_idx"][t0:t1]
         return sub
 
     def view(self, lo: int, hi: int):
@@ -161,6 +163,9 @@ class FeatureStore:
                                q_vid_off=torch.from_numpy(self.vid_off).to(dev)[qv],
                                tok_off=torch.from_numpy(np.ascontiguousarray(self.tok_off)).to(dev),
                                tok_len=torch.tensor(self.tok_len, device=dev))
+        if "tok_idx" not in self._index:    # index of every token row inside its query (--use_txt_pos: cone/model.py:106)
+            self._index["tok_idx"] = torch.from_numpy(np.concatenate(
+                [np.arange(n, dtype=np.int32) for n in self.tok_len] or [np.zeros(0, np.int32)])).to(self.device)
         return self._index
 
     def prefilter_plan(self):
@@ -517,6 +522,8 @@ def project_text(model, store: FeatureStore, ws=None):
     out = dict(tproj=tproj)
     if getattr(store.opt, "layer0_cache", True):
         out["l0_txt"] = model.layer0_rows(tproj, ws=ws)
+        if getattr(model, "txt_pos_tables", False):     # --use_txt_pos: the tokens' own position rows, once per token as well
+            out["txt_pos"], out["txt_pos_qk"] = model.text_positions(tproj, store.index_tensors()["tok_idx"])
     return out
 
 
@@ -535,6 +542,8 @@ def project_features(model, store: FeatureStore, video=None, cls_norm=None, text
     if "l0_vid" in video:
         feats["l0"] = dict(qkv_vid=video["l0_vid"], qkv_txt=text["l0_txt"] if "l0_txt" in text else model.layer0_rows(tproj),
                            max_v_l=store.opt.max_v_l)
+        if "txt_pos" in text:
+            feats["l0"]["txt_pos"], feats["l0"]["txt_pos_qk"] = text["txt_pos"], text["txt_pos_qk"]
     return feats
 
 

@@ -60,6 +60,7 @@ class CONELocalizator:
             c = cache[(ctx_l, n_tok)] = dict(
                 K=K, q_ctx_l=t([ctx_l]), q_vid_off=t([0]), tok_off=t([0, n_tok]), tok_len=t([n_tok]),
                 batch_pad=t([a.max_v_l]), full_w=torch.full((K,), a.max_v_l, dtype=torch.int32, device=dev),
+                tok_idx=torch.arange(n_tok, dtype=torch.int32, device=dev),
                 n_valid=t([K * self.localizator.num_queries]))
         return c
 
@@ -85,7 +86,7 @@ class CONELocalizator:
                                    batch_pad=c["batch_pad"], n_batches=1)
         vproj, tproj = m.project(0, vid), m.project(1, tok)
         out = m.forward_packed(vproj, wt["vid_row0"], wt["vid_len"], tproj, wt["txt_row0"], wt["txt_len"], W, a.max_q_l,
-                               l0=m.layer0_cache(vproj, tproj, W), saliency=False)
+                               l0=m.layer0_cache(vproj, tproj, W, tok_index=c["tok_idx"]), saliency=False)
         match = m.clip_matching_gathered(cls, wt["cls_row"], vid, wt["vid_row0"], wt["vid_len"], wt["pad_len"],
                                          out["pred_spans"])
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, c["full_w"], wt["video_start"], a.clip_length,

@@ -323,10 +323,35 @@ class CONE:
             self._pos_tabs = (max_v_l, dict(pos_rows=pos_rows, pos_qk=pos_qk))
         return self._pos_tabs[1]
 
-    def layer0_cache(self, vproj, tproj, max_v_l: int):
+    @property
+    def txt_pos_tables(self) -> bool:
+        """--use_txt_pos checkpoints take the table path when the caller hands over the tokens' own position rows
+        (``text_positions``); with --pre_norm as well they stay on the general path."""
+        return self.use_txt_pos and not self.pre_norm
+
+    def text_positions(self, tproj, tok_index):
+        """--use_txt_pos (cone/model.py:106): the position term of a text token is LayerNorm(src_txt[t] + position_embeddings[t])
+        -- a per-TOKEN row, shared by all windows of its query like the row caches.  ``tok_index`` (n,) int32 = index of each
+        projected token row inside its query.  Returns ``txt_pos`` (n, d) and ``txt_pos_qk`` (enc_layers, n, 2d), its images
+        under every encoder layer's [W_q | W_k] (cone_layer0_text_positions)."""
+        lib, h = _lib.load(), self._h()
+        n = int(tproj.shape[0])
+        if int(tok_index.shape[0]) != n:
+            raise ValueError(f"text_positions: {n} token rows, {int(tok_index.shape[0])} indices")
+        txt_pos = torch.empty(n, self.hidden_dim, device=tproj.device)
+        txt_pos_qk = torch.empty(self.args.enc_layers, n, 2 * self.hidden_dim, device=tproj.device)
+        _lib.check(lib.cone_layer0_text_positions(h, _lib.ptr(tproj), _lib.ptr(tok_index, torch.int32), n, _lib.ptr(txt_pos),
+                                                  _lib.ptr(txt_pos_qk), _lib.stream()))
+        return txt_pos, txt_pos_qk
+
+    def layer0_cache(self, vproj, tproj, max_v_l: int, tok_index=None):
         """cone_layer0 for forward_packed: the per-row q|k|v caches.  The static position tables are the handle's own
-        (built at cone_model_create, ABI 6); ``pos_tables()`` builds caller-owned ones (parity tests)."""
-        return dict(qkv_vid=self.layer0_rows(vproj), qkv_txt=self.layer0_rows(tproj), max_v_l=max_v_l)
+        (built at cone_model_create, ABI 6); ``pos_tables()`` builds caller-owned ones (parity tests).  ``tok_index``: see
+        ``text_positions`` -- a --use_txt_pos model needs it to take the table path."""
+        l0 = dict(qkv_vid=self.layer0_rows(vproj), qkv_txt=self.layer0_rows(tproj), max_v_l=max_v_l)
+        if self.txt_pos_tables and tok_index is not None:
+            l0["txt_pos"], l0["txt_pos_qk"] = self.text_positions(tproj, tok_index)
+        return l0
 
     def forward_packed(self, vproj, vid_row0, vid_len, tproj, txt_row0, txt_len, Lv_max, Lq_max, l0=None,
                        saliency: bool = True, aux: bool = False):
@@ -338,7 +363,8 @@ class CONE:
         l0s = l0p = None
         if l0 is not None:
             dp = lambda k: l0[k].data_ptr() if l0.get(k) is not None else None
-            l0s = _lib.Layer0(dp("qkv_vid"), dp("qkv_txt"), dp("pos_qk"), dp("pos_rows"), l0["max_v_l"])
+            l0s = _lib.Layer0(dp("qkv_vid"), dp("qkv_txt"), dp("pos_qk"), dp("pos_rows"), l0["max_v_l"], dp("txt_pos"),
+                              dp("txt_pos_qk"), int(l0["txt_pos"].shape[0]) if l0.get("txt_pos") is not None else 0)
             l0p = C.byref(l0s)
         B = vid_row0.shape[0]
         dev = vproj.device

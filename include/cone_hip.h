@@ -246,6 +246,13 @@ typedef struct {
     const float* qkv_vid; const float* qkv_txt;
     const float* pos_qk; const float* pos_rows;
     int32_t max_v_l;
+    /* (ABI 7) --use_txt_pos checkpoints (cone/config.py:115) on the table path: the position term of a text token is a
+     * per-TOKEN row (cone/model.py:106) -- txt_pos (n_txt, d) and its images under every encoder layer's [W_q | W_k],
+     * txt_pos_qk (enc_layers, n_txt, 2d), both from cone_layer0_text_positions on the projected token arena (row i of
+     * either belongs to token row i of txt_proj).  NULL for such a model: the general path (x + pos materialised).
+     * Ignored by models without the option. */
+    const float* txt_pos; const float* txt_pos_qk;
+    int64_t n_txt;
 } cone_layer0;
 int64_t cone_pos_table_rows(int max_v_l);
 int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* pos_qk, void* stream);
@@ -254,6 +261,13 @@ int cone_pos_tables(const cone_model* m, int max_v_l, float* pos_rows, float* po
 size_t cone_layer0_project_workspace(const cone_model* m, int64_t n_rows);
 int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_rows, float* qkv, void* ws, size_t ws_bytes,
                         void* stream);
+/* (ABI 7) --use_txt_pos: the text-side position rows of the table path, once per token of the projected text arena (they
+ * are shared by all windows of a query, like the row caches).  tok_index[i] = index of token row i inside its query (0-based);
+ * txt_pos[i] = LayerNorm(txt_proj_rows[i] + position_embeddings[tok_index[i]]) (cone/position_encoding.py:21-31, eval: no
+ * dropout), txt_pos_qk[l][i] = txt_pos[i] [W_q | W_k]_l^T (no bias) for every encoder layer l.  Error for a model without
+ * txt_pos_embed. */
+int cone_layer0_text_positions(const cone_model* m, const float* txt_proj_rows, const int32_t* tok_index, int64_t n_rows,
+                               float* txt_pos, float* txt_pos_qk, void* stream);
 
 /* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows); 13 KiB on the general path (--use_txt_pos, A/B switches). */
 size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,

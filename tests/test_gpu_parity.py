@@ -307,8 +307,9 @@ def arena_forward(model, opt, inp, lens_v, lens_q, dev, share_text=False):
     vproj = model.project(0, torch.from_numpy(vid).to(dev))
     tproj = model.project(1, torch.from_numpy(txt).to(dev))
     Lv, Lq = inp["src_vid"].shape[1], inp["src_txt"].shape[1]
+    tok_index = i32(np.concatenate([np.arange(n) for n in lens_q]))     # (--use_txt_pos: a token's index inside its query)
     return model.forward_packed(vproj, vrow0, i32(lens_v), tproj, trow0, i32(lens_q), Lv, Lq,
-                                l0=model.layer0_cache(vproj, tproj, Lv), saliency=True, aux=True)
+                                l0=model.layer0_cache(vproj, tproj, Lv, tok_index=tok_index), saliency=True, aux=True)
 
 
 def stage_b_forward(entry, model, opt, inp, lens_v, lens_q, dev, taps=False):
@@ -394,6 +395,57 @@ def test_padded_and_arena_entries_are_one_path(preset, split_bf16):
         assert torch.equal(a[k], b[k]), k
     for k in ("pred_logits", "pred_spans"):
         assert torch.equal(a["aux_outputs"][0][k], b["aux_outputs"][0][k]), ("aux", k)
+
+
+def test_use_txt_pos_runs_the_table_path():
+    """--use_txt_pos (cone/config.py:115; cone/model.py:106): the position term of a text token is a per-TOKEN row, so it joins
+    the row caches (cone_layer0_text_positions: the row and its images under every encoder layer's [W_q | W_k]) and such a model
+    runs the table path too -- first-layer caches, fused layer tails, one N = 768 GEMM per later layer, the decoder's keys written
+    once behind the encoder.  Both entries bit for bit the same; against the general path (x + pos materialised per token: the
+    tables switched off) within the re-association tolerance of the other A/B tests; against the oracle at 1e-4; and the position
+    term is really applied (the same weights without the option give other outputs)."""
+    model, opt, sd = get_model("ego4d", 3, use_txt_pos=True)
+    rng = np.random.default_rng(19)
+    B = 29
+    lens_v = [opt.max_v_l] + [int(x) for x in rng.integers(1, opt.max_v_l + 1, B - 1)]
+    lens_q = [opt.max_q_l] + [int(x) for x in rng.integers(1, opt.max_q_l + 1, B - 1)]
+    inp = gi.stage_b_inputs(opt, 53, lens_v, lens_q)
+    dev = _gpu()
+    a = stage_b_forward("padded", model, opt, inp, lens_v, lens_q, dev)
+    b = stage_b_forward("arena", model, opt, inp, lens_v, lens_q, dev)
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("pred_logits", "pred_spans"):
+        assert torch.equal(a["aux_outputs"][0][k], b["aux_outputs"][0][k]), ("aux", k)
+    try:
+        model.set_option("pos_tables", 0)
+        g = stage_b_forward("padded", model, opt, inp, lens_v, lens_q, dev)
+    finally:
+        model.set_option("pos_tables", 1)
+    t = torch.from_numpy
+    with torch.no_grad():
+        ref = O.cone_forward(sd, opt, t(inp["src_txt"]), t(inp["txt_mask"]), t(inp["src_vid"]), t(inp["vid_mask"]))
+    worst = {}
+    Lv = inp["src_vid"].shape[1]
+    vm = torch.from_numpy(_valid_token_mask(lens_v, lens_q, Lv, inp["src_txt"].shape[1])[:, :Lv])
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        r = ref[k] * vm if k == "saliency_scores" else ref[k]       # (padded clips: 0 here, the masked head's value there)
+        worst[k] = (maxdiff(a[k], g[k].cpu()), maxdiff(a[k], r))
+        assert worst[k][0] < 5e-5 and worst[k][1] < TOL, (k, worst[k])
+    record_measured("txt_pos_table_path", **{k: list(v) for k, v in worst.items()})
+    plain, _, _ = get_model("ego4d", 3)
+    p = stage_b_forward("padded", plain, opt, inp, lens_v, lens_q, dev)
+    assert maxdiff(a["pred_logits"], p["pred_logits"].cpu()) > 1e-3
+    # a caller that hands over row caches WITHOUT the text position rows gets the general path, not wrong numbers
+    vid = np.concatenate([inp["src_vid"][i, :lens_v[i]] for i in range(B)], 0)
+    txt = np.concatenate([inp["src_txt"][i, :lens_q[i]] for i in range(B)], 0)
+    i32 = lambda x: torch.tensor(np.asarray(x), dtype=torch.int32, device=dev)
+    vproj, tproj = model.project(0, torch.from_numpy(vid).to(dev)), model.project(1, torch.from_numpy(txt).to(dev))
+    o = model.forward_packed(vproj, i32(np.concatenate([[0], np.cumsum(lens_v)[:-1]])), i32(lens_v), tproj,
+                             i32(np.concatenate([[0], np.cumsum(lens_q)[:-1]])), i32(lens_q), inp["src_vid"].shape[1],
+                             inp["src_txt"].shape[1], l0=model.layer0_cache(vproj, tproj, inp["src_vid"].shape[1]), saliency=True)
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert torch.equal(o[k], g[k]), k
 
 
 @pytest.mark.parametrize("entry", ["padded", "arena"])
