@@ -80,9 +80,10 @@ typedef struct {
     /* (ABI 5) --use_txt_pos (cone/config.py:115, cone/model.py:106): the position term of text token t of a query is
      * TrainablePositionalEncoding(src_txt) = LayerNorm(src_txt[t] + position_embeddings[t]) (cone/position_encoding.py:10-32).
      * txt_pos_embed = txt_position_embed.position_embeddings.weight [txt_pos_rows = max_q_l][d], txt_pos_ln its LayerNorm;
-     * NULL = the option is off (every shipped configuration): text tokens carry a zero position term.  With it set the forward
-     * runs on the general path (x + pos materialised per token; the layer-0 caches / position tables, which assume the
-     * zero term, are not used). */
+     * NULL = the option is off (every shipped configuration): text tokens carry a zero position term.  (ABI 7) With it set the
+     * forward runs the table path when it gets the tokens' own position rows (cone_layer0.txt_pos / txt_pos_qk from
+     * cone_layer0_text_positions; cone_forward_windows builds them itself), otherwise the general path (x + pos materialised
+     * per token). */
     const float* txt_pos_embed; int32_t txt_pos_rows; cone_ln_w txt_pos_ln;
     /* (ABI 5) --pre_norm (cone/config.py:120 -> normalize_before, cone/transformer.py:19-36): pre_norm != 0 = every layer
      * normalises its input (forward_pre) and the encoder ends with enc_norm = transformer.encoder.norm, which exists only
@@ -269,7 +270,7 @@ int cone_layer0_project(const cone_model* m, const float* proj_rows, int64_t n_r
 int cone_layer0_text_positions(const cone_model* m, const float* txt_proj_rows, const int32_t* tok_index, int64_t n_rows,
                                float* txt_pos, float* txt_pos_qk, void* stream);
 
-/* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows); 13 KiB on the general path (--use_txt_pos, A/B switches). */
+/* Workspace: 6 KiB per token row (B * (Lv_max + Lq_max) rows); 13 KiB on the general path (--use_txt_pos without its position rows, A/B switches). */
 size_t cone_forward_packed_workspace(const cone_model* m, int B, int Lv_max, int Lq_max,
                                      const cone_layer0* l0 /* as passed to cone_forward_packed */);
 int cone_forward_packed(const cone_model* m, const float* vproj, const int32_t* vid_row0,
