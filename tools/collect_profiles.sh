@@ -75,9 +75,10 @@ rm -rf $out/proxy8
 rocprofv3 --kernel-trace -d $out/proxy8 -o t -- python3 tools/proxy_bench.py 8 0 10 > $out/${tag}_proxy8.json 2> $out/proxy8.log
 python3 tools/step_trace.py $out/proxy8/t_results.db > $out/${tag}_proxy8_trace.txt 2>&1
 python3 tools/rocpd_summary.py $out/proxy8/t_results.db 60 > $out/${tag}_proxy8_kernel_stats.csv 2>> $out/proxy8.log
-# (12) other slot counts / pre-norm: ms per step
+# (12) other slot counts / pre-norm / --use_txt_pos: ms per step
 python3 tools/slots_step.py 5 10 8 3 16 > $out/${tag}_slots_step.txt 2>&1
 python3 tools/prenorm_step.py > $out/${tag}_prenorm_step.txt 2>&1
+python3 tools/txtpos_step.py > $out/${tag}_txtpos_step.txt 2>&1
 # the bench line last: roofline.traffic is read from profiles/<tag>_pmc_*.json of THIS collection
 cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_counters.csv $out/${tag}_pmc_prefilter.json $out/${tag}_pmc_prefilter_counters.csv profiles/
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
