@@ -441,8 +441,8 @@ struct FwdPlan { bool tables, fold, dec_xp = false; };
 static const cone_layer0* effective_l0(const cone_model* m, const cone_layer0* l0, int Lv_max, cone_layer0* eff,
                                        bool own_txt = false) {
     // --use_txt_pos: the table path needs the tokens' own position rows (cone_layer0_text_positions) -- handed over in l0, or
-    // (own_txt: the padded entry) built by the caller itself; without them, and for --pre_norm with it, the general path
-    if (m->txt_pos_emb && (m->pre_norm || !(own_txt || (l0 && l0->txt_pos && l0->txt_pos_qk)))) return nullptr;
+    // (own_txt: the padded entry) built by the caller itself; without them the general path
+    if (m->txt_pos_emb && !(own_txt || (l0 && l0->txt_pos && l0->txt_pos_qk))) return nullptr;
     *eff = l0 ? *l0 : cone_layer0{};
     if (!m->txt_pos_emb) eff->txt_pos = eff->txt_pos_qk = nullptr;
     if (!eff->qkv_vid || !eff->qkv_txt) eff->qkv_vid = eff->qkv_txt = nullptr;
@@ -465,6 +465,7 @@ static FwdPlan plan_for(const cone_model* m, bool have_tables, bool caches, int 
                         // general pre-norm path (plain LayerNorm / GEMM / attention launches)
         const bool fused = p.tables && p.fold && m->opt_dec_fold >= 2 && m->opt_ffn_fused >= 2 && ffn_fused_supported(m->ff);
         p.tables = p.fold = fused;
+        if (!fused) p.dec_xp = false;
         return p;
     }
     // the unfolded decoder projects its keys from memory + pos rows: on the table path that matrix is written once behind the
@@ -637,6 +638,7 @@ static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj,
         AttnSrc src{};
         src.vlen = vlen; src.pos_zero_row = (int)pos_rows_n - 1;
         src.pos_qk = l0->pos_qk + (size_t)l * pos_rows_n * 512;
+        if (l0->txt_pos_qk) { src.txt_pos_qk = l0->txt_pos_qk + (size_t)l * l0->n_txt * 512; src.trow0 = trow0; }   // --use_txt_pos
         if (g0) {
             src.qkv_vid = l0->qkv_vid; src.qkv_txt = l0->qkv_txt; src.vrow0 = vrow0; src.trow0 = trow0;
         } else {
@@ -650,6 +652,9 @@ static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj,
                                     g0 ? f.RIDX : nullptr, g0 ? tproj : nullptr));
     }
     const float* MEM = Z;                                                                            // encoder.norm(src)
+    // --use_txt_pos: the keys memory + pos written once (text rows from the tokens' own position rows), x + pos form of the fold
+    const bool xp = l0->txt_pos != nullptr;
+    if (xp) RUN(launch_add_pos_rows(MEM, f.off, vlen, l0->pos_rows, f.XP, B, Lmax, s, l0->txt_pos, trow0));
     CONE_CHECK_HIP(hipMemsetAsync(f.TGT, 0, (size_t)T * 256 * sizeof(float), s));                    // tgt = 0 (:66)
     GemmArgs g;
     for (int l = 0; l < nd; ++l) {          // cone/transformer.py:319-342
@@ -666,8 +671,8 @@ static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj,
         g = G(m, f.TGT1, 256, dl.ca.in_w, 256, nullptr, f.DQ, 256, T, nullptr, 256, 256, EPI_RESIDUAL);
         g.R = m->dec_ca_tab[l]; g.ldr = 256; g.r_mod = m->nq;
         RUN(launch_gemm(g, s));
-        RUN(launch_dec_cross_mfma(f.DQ, nullptr, MEM, l0->pos_rows, vlen, f.off, dl.ca.in_w + 256 * 256, m->dec_vT[l],
-                                  dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, nullptr, s, 3));
+        RUN(launch_dec_cross_mfma(f.DQ, xp ? f.XP : nullptr, MEM, xp ? nullptr : l0->pos_rows, vlen, f.off, dl.ca.in_w + 256 * 256,
+                                  m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, nullptr, s, 3));
         RUN(launch_proj_ffn_prenorm(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT, 256, dl.n3.g, dl.n3.b, dl.l1.w, dl.l1.b, dl.l2.w,
                                     dl.l2.b, f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
                                     ff, s));

@@ -326,8 +326,8 @@ class CONE:
     @property
     def txt_pos_tables(self) -> bool:
         """--use_txt_pos checkpoints take the table path when the caller hands over the tokens' own position rows
-        (``text_positions``); with --pre_norm as well they stay on the general path."""
-        return self.use_txt_pos and not self.pre_norm
+        (``text_positions``)."""
+        return self.use_txt_pos
 
     def text_positions(self, tproj, tok_index):
         """--use_txt_pos (cone/model.py:106): the position term of a text token is LayerNorm(src_txt[t] + position_embeddings[t])

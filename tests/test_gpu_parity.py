@@ -397,14 +397,16 @@ def test_padded_and_arena_entries_are_one_path(preset, split_bf16):
         assert torch.equal(a["aux_outputs"][0][k], b["aux_outputs"][0][k]), ("aux", k)
 
 
-def test_use_txt_pos_runs_the_table_path():
+@pytest.mark.parametrize("pre_norm", [False, True])
+def test_use_txt_pos_runs_the_table_path(pre_norm):
     """--use_txt_pos (cone/config.py:115; cone/model.py:106): the position term of a text token is a per-TOKEN row, so it joins
     the row caches (cone_layer0_text_positions: the row and its images under every encoder layer's [W_q | W_k]) and such a model
     runs the table path too -- first-layer caches, fused layer tails, one N = 768 GEMM per later layer, the decoder's keys written
     once behind the encoder.  Both entries bit for bit the same; against the general path (x + pos materialised per token: the
     tables switched off) within the re-association tolerance of the other A/B tests; against the oracle at 1e-4; and the position
     term is really applied (the same weights without the option give other outputs)."""
-    model, opt, sd = get_model("ego4d", 3, use_txt_pos=True)
+    kw = dict(pre_norm=True) if pre_norm else {}     # (with --pre_norm too: the fused pre-norm form of the same path)
+    model, opt, sd = get_model("ego4d", 3, use_txt_pos=True, **kw)
     rng = np.random.default_rng(19)
     B = 29
     lens_v = [opt.max_v_l] + [int(x) for x in rng.integers(1, opt.max_v_l + 1, B - 1)]
@@ -432,8 +434,8 @@ def test_use_txt_pos_runs_the_table_path():
         r = ref[k] * vm if k == "saliency_scores" else ref[k]       # (padded clips: 0 here, the masked head's value there)
         worst[k] = (maxdiff(a[k], g[k].cpu()), maxdiff(a[k], r))
         assert worst[k][0] < 5e-5 and worst[k][1] < TOL, (k, worst[k])
-    record_measured("txt_pos_table_path", **{k: list(v) for k, v in worst.items()})
-    plain, _, _ = get_model("ego4d", 3)
+    record_measured(f"txt_pos_table_path[pre_norm={int(pre_norm)}]", **{k: list(v) for k, v in worst.items()})
+    plain, _, _ = get_model("ego4d", 3, **kw)
     p = stage_b_forward("padded", plain, opt, inp, lens_v, lens_q, dev)
     assert maxdiff(a["pred_logits"], p["pred_logits"].cpu()) > 1e-3
     # a caller that hands over row caches WITHOUT the text position rows gets the general path, not wrong numbers
