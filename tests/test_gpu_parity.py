@@ -2645,3 +2645,27 @@ def test_hip_graph_replay_equals_eager_pipeline():
     for _ in range(2):
         got_s, _ = inf.predict_split(model, short, gopt)
         assert got_s == eager_s
+
+
+def test_hip_graph_replay_with_two_sources_and_text_positions():
+    """The graph's inputs are ALL the arenas: a store with a motion arena and a --use_txt_pos model (per-token text position rows
+    beside the row caches) replays bit-identically, also after every arena was refilled in place."""
+    from cone_amd import inference as inf
+    kw = dict(v_motion_feat_dim=128, use_txt_pos=True)
+    model, _, _ = get_model("ego4d", 2, **kw)
+    opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=4, **kw)
+    ann, vf, qf = synth.make_dataset(opt, 5, 2, seed=8, ctx_range=(250, 251), lq_range=(12, 13))
+    store = inf.FeatureStore(opt, ann, vf, qf, motion_feats=synth.make_motion_feats(opt, vf, seed=8))
+    eager, _ = inf.predict_split(model, store, opt)
+    gopt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=6, eval_bsz=4, hip_graph=True, **kw)
+    for _ in range(2):
+        got, _ = inf.predict_split(model, store, gopt)
+        assert got == eager
+    ann2, vf2, qf2 = synth.make_dataset(opt, 5, 2, seed=9, ctx_range=(250, 251), lq_range=(12, 13))
+    other = inf.FeatureStore(opt, ann2, vf2, qf2, motion_feats=synth.make_motion_feats(opt, vf2, seed=9))
+    ref2, _ = inf.predict_split(model, other, opt)
+    for k in ("vid_raw", "mot_raw", "tok_raw", "cls_raw"):
+        getattr(store, k).copy_(getattr(other, k))
+    got2, _ = inf.predict_split(model, store, gopt)
+    strip = lambda lists: [[{k: v for k, v in it.items() if k == "predicted_times"} for it in l] for l in lists]
+    assert strip(got2) == strip(ref2)
