@@ -860,7 +860,7 @@ def _graph_replay(model, store: FeatureStore, opt):
     windows: ~110 launches of a few microseconds each, bound by the host's launch rate when issued one by one).  The
     device pipeline never synchronises and takes every size from host metadata, so it captures as it is: after one
     eager warm-up (allocations, position tables, LDS attributes) the same call runs under stream capture; the store's
-    arenas are the graph's inputs (refill them in place -- ``vid_raw.copy_`` / ``tok_raw.copy_`` / ``cls_raw.copy_`` --
+    arenas are the graph's inputs (refill them in place -- ``vid_raw.copy_`` / ``mot_raw.copy_`` (a second visual source) / ``tok_raw.copy_`` / ``cls_raw.copy_`` --
     for new features of the same shapes), the returned tensors its outputs (valid until the next replay).
     Any mix of video lengths: the shape of the window list is host metadata (``Selection``), so there is no data-dependent
     size anywhere."""
