@@ -26,6 +26,8 @@ model_kw = {}
 for kv in (sys.argv[5].split(",") if len(sys.argv) > 5 and sys.argv[5] else []):
     k, _, v = kv.partition("=")
     model_kw[k] = v if not v.lstrip("-").isdigit() else (bool(int(v)) if k in ("use_txt_pos", "pre_norm") else int(v))
+# v_motion_feat_dim=<n>: a second visual source of that width for the window model (motion_feat_dir != appearance_feat_dir)
+two_sources = "v_motion_feat_dim" in model_kw
 torch.cuda.set_device(0)
 base = make_opt(preset, **model_kw)
 sd = synth.make_state_dict(base, 0)
@@ -49,9 +51,10 @@ for it in range(iters):
     nq, nv = int(rng.choice([1, 2, 7, 13])), int(rng.choice([1, 2, 3]))
     ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=seed0 + it, ctx_range=(lo, hi),
                                      lq_range=(1, int(rng.choice([2, 8, opt.max_q_l + 1]))))
-    store = inf.FeatureStore(opt, ann, vf, qf)
+    mf = synth.make_motion_feats(opt, vf, seed=seed0 + it) if two_sources else None
+    store = inf.FeatureStore(opt, ann, vf, qf, motion_feats=mf)
     (fusion, prop, match), info = inf.predict_split(model, store, opt)
-    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf)
+    (fo, po, mo), ranks, mr = O.eval_epoch(sd, opt, ann, vf, qf, motion_feats=mf)
     tag = f"iter {it} (seed {seed0 + it}: ctx [{lo},{hi}) nq {nq} nv {nv} topk {opt.topk_window} bsz {opt.eval_bsz} nms {opt.nms_thd} wb {opt.window_batch})"
     for qi, row in enumerate(ann):
         got = [w for w in info["win_idx"][qi].cpu().tolist() if w >= 0]
@@ -102,7 +105,7 @@ for it in range(iters):
     assert len(fusion) == len(fo) == nq, tag
     opt2 = make_opt(preset, **model_kw, **{k: getattr(opt, k) for k in ("nms_thd", "eval_split_name", "topk_window", "eval_bsz")},
                     window_batch=32768 if opt.window_batch != 32768 else 5)
-    again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf), opt2)
+    again, _ = inf.predict_split(model, inf.FeatureStore(opt2, ann, vf, qf, motion_feats=mf), opt2)
     assert again == (fusion, prop, match), f"{tag}: results depend on window_batch"
     # the reference's own call on its own zero-padded batch (cone/inference.py:45-50: model(**model_inputs) on eval_bsz queries
     # x top-k windows) = cone_forward_windows: compaction + projection of the valid rows + row caches inside the call, then the
