@@ -143,6 +143,8 @@ _SIGNATURES = {
                                  C.c_int, C.c_int, C.c_void_p]),
     "cone_test_ffn": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p]),
     "cone_test_proj_ffn": (C.c_int, [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p]),
+    "cone_test_proj_ffn_spread_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "cone_test_proj_ffn_spread": (C.c_int, [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cone_test_ffn_split_image_bytes": (C.c_size_t, [C.c_int]),
     "cone_test_ffn_split": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "cone_test_rows_split_image_bytes": (C.c_size_t, [C.c_int]),

@@ -77,6 +77,7 @@ struct cone_model {
     int opt_split_bf16 = 0;   // OPT-IN: layer tails on the bf16 matrix cores (six partial products of three-piece operands,
                               // fp32 accumulation: fp32-MFMA accuracy); 0 = exact-fp32 MFMA (default)
     int opt_res_gather = 1;   // first encoder layer's residual rows gathered by the fused layer tail (no packed input copy)
+    int opt_spread = 1;       // <= 16 row groups in a decoder tail: the spread form (four launches over single-wave workgroups)
     int opt_chain = 1;        // few rows: decoder.norm + class head + span MLP + span head, and the adapter pair of the proposal
                               // matching, as ONE launch each (rows_chain.h: the same arithmetic, bit-identical); 0 = separate launches
     int opt_ffn_fused = 2;    // 1: linear1 + ReLU + linear2 + residual + LayerNorm as one kernel (ffn.hip); 2: the attention
@@ -432,7 +433,7 @@ static int project_tokens(const cone_model* m, int which, const float* x, int64_
 struct FwdBuffers {
     int* off; int* RIDX;
     float *X, *POS, *XP, *QKV, *ATT, *X1, *H, *KD, *VD;
-    float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS;
+    float *TGT, *TGT1, *TGT2, *DQK, *DV, *DATT, *DQ, *DH, *HS, *S1, *S2, *LG, *SP, *QKS, *SPR;
 };
 struct FwdPlan { bool tables, fold, dec_xp = false; };
 // What a call runs on: the caller's cone_layer0 with the handle's position tables filled in where it brings none (ABI 6: a
@@ -509,6 +510,8 @@ static void carve_fwd(const cone_model* m, Carver& c, int B, int Lmax, const Fwd
     f.HS = c.take<float>(nd * T * 256); f.S1 = c.take<float>(nd * T * 256); f.S2 = c.take<float>(nd * T * 256);
     f.LG = c.take<float>(nd * T * 2); f.SP = c.take<float>(nd * T * 2);
     f.QKS = c.take<float>(dec_cross_mfma_slab_floats());
+    f.SPR = ffn_spread_supported((int)T, m->ff) || ffn_spread_supported((int)M, m->ff)                       // the spread tail's rows
+                ? c.take<float>(ffn_spread_scratch_floats(m->ff)) : nullptr;
 }
 static size_t fwd_ws_bytes(const cone_model* m, int B, int Lmax, const FwdPlan& p) {
     Carver c(nullptr, ~(size_t)0);
@@ -816,6 +819,14 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
                 // (exact-fp32 kernel: measured neutral against the separate GEMM launch -- 44.3 vs 44.1 ms of kernel time per
                 // step -- so only on request: qkv_fused = 2)
                 const bool next_qkv = m->opt_qkv_fused >= 2 && l + 1 < m->n_enc && plan.tables && ffn_fused_qkv_fits(ff, 768);
+                if (!next_qkv && m->opt_spread && f.SPR && ffn_spread_supported(Mmax, ff)) {
+                    // a few windows (<= 1 024 token rows): the spread form, as for the decoder tails of a small batch
+                    RUN(launch_proj_ffn_spread(f.ATT, 256, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b, e.l1.w,
+                                               e.l1.b, e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, ff, f.SPR, s, Mdev,
+                                               g0 ? RIDX : nullptr, g0 ? tproj : nullptr));
+                    qkv_fused = false;
+                    continue;
+                }
                 RUN(launch_proj_ffn_fused(f.ATT, 256, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, 256, e.n1.g, e.n1.b, e.l1.w,
                                           e.l1.b, e.l2.w, e.l2.b, e.n2.g, e.n2.b, f.X, 256, Mmax, Mdev, ff, s,
                                           g0 ? RIDX : nullptr, g0 ? tproj : nullptr,
@@ -919,6 +930,11 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
         if (m->opt_ffn_fused >= 2 && m->opt_split_bf16 && m->split_img) {
             RUN(launch_proj_ffn_split(f.DATT, 256, m->dec_wo_img[l], dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b,
                                       m->dec_ffn_img[l], dl.l1.b, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
+        } else if (m->opt_ffn_fused >= 2 && ffn_fused_supported(ff) && m->opt_spread && f.SPR && ffn_spread_supported(T, ff)) {
+            // a handful of slot rows (a single query's 20 windows = 7 row groups): the group's output elements spread over
+            // single-wave workgroups in four launches instead of one CU walking the whole block -- the same bits
+            RUN(launch_proj_ffn_spread(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b, dl.l1.w, dl.l1.b,
+                                       dl.l2.w, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, ff, f.SPR, s));
         } else if (m->opt_ffn_fused >= 2 && ffn_fused_supported(ff)) {
             RUN(launch_proj_ffn_fused(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT1, 256, dl.n2.g, dl.n2.b, dl.l1.w, dl.l1.b,
                                       dl.l2.w, dl.l2.b, dl.n3.g, dl.n3.b, f.TGT, 256, T, nullptr, ff, s));
@@ -1260,6 +1276,7 @@ extern "C" int cone_model_set_option(cone_model* m, const char* name, int value)
     }
     if (!strcmp(name, "res_gather")) { m->opt_res_gather = value != 0; return 0; }
     if (!strcmp(name, "rows_chain")) { m->opt_chain = value != 0; return 0; }
+    if (!strcmp(name, "ffn_spread")) { m->opt_spread = value != 0; return 0; }
     if (!strcmp(name, "gemm")) {
         CONE_REQUIRE(value >= GEMM_AUTO && value <= GEMM_ROWS8, "set_option: gemm tile family %d not in [0, 3]", value);
         m->opt_gemm = value;
@@ -1289,6 +1306,14 @@ extern "C" int cone_test_proj_ffn(const float* A, const float* Wo, const float* 
                                   const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* stream) {
     return launch_proj_ffn_fused(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, nullptr, ff,
                                  (hipStream_t)stream);
+}
+extern "C" size_t cone_test_proj_ffn_spread_scratch_bytes(int ff) { return ffn_spread_scratch_floats(ff) * sizeof(float); }
+extern "C" int cone_test_proj_ffn_spread(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,
+                                         const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                                         const float* ln_g, const float* ln_b, float* OUT, int M, int ff, void* scratch,
+                                         void* stream) {
+    return launch_proj_ffn_spread(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, ln_g, ln_b, OUT, 256, M, ff, (float*)scratch,
+                                  (hipStream_t)stream);
 }
 extern "C" size_t cone_test_ffn_split_image_bytes(int ff) { return ffn_split_supported(ff) ? ffn_split_image_bytes(ff) : 0; }
 extern "C" int cone_test_ffn_split(const float* X, const float* W1, const float* b1, const float* W2, const float* b2,

@@ -159,6 +159,13 @@ bool ffn_fused_qkv_fits(int ff, int n_qkv);
 // The same two computations with ONE workgroup per 16 rows whose eight waves split the output elements (projection and
 // GEMM2 by output channels, GEMM1 by hidden units): every element's fma chain is ffn.hip's, results are bit-identical.
 bool ffn_wide_supported(int ff);
+// the spread form of the projecting tail for <= 64 row groups (ffn_wide.hip): 4 launches over single-wave workgroups, same bits
+size_t ffn_spread_scratch_floats(int ff);
+bool ffn_spread_supported(int M, int ff);
+int launch_proj_ffn_spread(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                           const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                           const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, int ff, float* scratch,
+                           hipStream_t s, const int* M_dev = nullptr, const int* r_idx = nullptr, const float* R2 = nullptr);
 // m_off: the rows are rows m_off .. m_off + M of a larger job whose device-side row count is *M_dev
 int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
                     const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s,

@@ -277,6 +277,196 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// SPREAD form of the projecting tail for a handful of row groups (the decoder tails of a small batch: 20 windows x 5 slots = 7
+// groups).  In the wide form ONE CU walks a group's 9 216 MFMAs (31 us of matrix time + 20 us around it) while 249 CUs idle.
+// Here the group's OUTPUT elements are spread over single-wave workgroups, every element by the same fma chain as above:
+//   fs_proj_kernel : (16 tiles, groups)       channels [16 t, 16 t + 16) of R + A Wo^T          -> XP   (64 MFMAs per wave)
+//   fs_g1_kernel   : (ff / 16 chunks, groups) x1 = LayerNorm_p(XP + bo) in every wave (the same routine on the same layout);
+//                                              hidden chunk c = relu(W1[c] x1 + b1)              -> HG, x1 tiles -> X1
+//   fs_g2_kernel   : (16 tiles, groups)       tile t of x1 + b2 + W2 HG, the chunks in order    -> YG   (4 ff / 16 MFMAs)
+//   fs_ln_kernel   : (groups)                 LayerNorm of the full rows                        -> OUT
+// Rows move between the launches through a 1.8 MB scratch of the caller's workspace (L2); a launch boundary is the only
+// synchronisation.  Weights: a wave's slabs by LDS-DMA into its own ring, all requested at once (proj, g1) or two blocks of 16
+// ahead (g2).  4 launches, ~25 us instead of 53 (measured: see DESIGN.md), chosen by the host for M <= 256 rows.
+#ifndef CONE_FFN_SPREAD_GROUPS
+#define CONE_FFN_SPREAD_GROUPS 64
+#endif
+constexpr int FS_MAX_GROUPS = CONE_FFN_SPREAD_GROUPS;
+
+struct FfnSpreadBufs { float* XP; float* X1; float* HG; float* YG; };
+// the launch's row count: the host bound, cut to the device-side count where there is one (as ffn_wide_kernel)
+__device__ __forceinline__ int fs_rows(const FfnWideArgs& p) {
+    int M = p.M;
+    if (p.M_dev) { const int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
+    return M;
+}
+
+__global__ __launch_bounds__(64) void fs_proj_kernel(FfnWideArgs p, FfnSpreadBufs b) {
+    __shared__ __attribute__((aligned(16))) float ring[16 * 256];
+    const int t = blockIdx.x, g = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    const int M = fs_rows(p), my_row = g * 16 + li;
+    if (g * 16 >= M) return;
+    const size_t ld_row = (size_t)(my_row < M ? my_row : M - 1);
+    const int drow = lane >> 2, dq = ((lane & 3) ^ fw_swz16(drow)) << 2;
+    const int rdo = li * 16 + ((lg ^ fw_swz16(li)) << 2);
+    const float* src = p.Wo + (size_t)(16 * t) * 256 + drow * 256 + dq;              // + 16 q: k-slab q of tile t
+#pragma unroll
+    for (int q = 0; q < 16; ++q) FW_GLDS16(src + 16 * q, ring + q * 256);           // the whole weight tile at once
+    FW_SB();
+    f32x4w ar[16];
+    const float* ap = p.A + ld_row * p.lda + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ar[q] = *reinterpret_cast<const f32x4w*>(ap + 16 * q);
+    const float* rp = p.R + ld_row * p.ldr;
+    if (p.r_idx) {                      // the residual rows gathered through a row index (first encoder layer, as the wide form)
+        const int ix = p.r_idx[ld_row];
+        rp = ix >= 0 ? p.R + (size_t)ix * p.ldr : p.R2 + (size_t)(~ix) * p.ldr;
+    }
+    const f32x4w r0 = *reinterpret_cast<const f32x4w*>(rp + 16 * t + 4 * lg);
+    FW_SB();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4w ha[2];
+    ha[0] = f32x4w{0.f, 0.f, 0.f, 0.f}; ha[1] = ha[0];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4w c = *reinterpret_cast<const f32x4w*>(ring + q * 256 + rdo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) FW_MFMA(ha[r & 1], c[r], ar[q][r]);
+    }
+    const f32x4w x0 = r0 + (ha[0] + ha[1]);
+    *reinterpret_cast<f32x4w*>(b.XP + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = x0;
+}
+
+__global__ __launch_bounds__(64) void fs_g1_kernel(FfnWideArgs p, FfnSpreadBufs b) {
+    __shared__ __attribute__((aligned(16))) float ring[16 * 256];
+    const int c = blockIdx.x, g = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    if (g * 16 >= fs_rows(p)) return;
+    const int drow = lane >> 2, dq = ((lane & 3) ^ fw_swz16(drow)) << 2;
+    const int rdo = li * 16 + ((lg ^ fw_swz16(li)) << 2);
+    const float* src = p.W1 + (size_t)(16 * c) * 256 + drow * 256 + dq;              // + 16 q: k-slab q of hidden chunk c
+#pragma unroll
+    for (int q = 0; q < 16; ++q) FW_GLDS16(src + 16 * q, ring + q * 256);           // the chunk's 16 k-slabs, under the LayerNorm
+    FW_SB();
+    f32x4w xr[16];
+    const float* xp = b.XP + ((size_t)g * 16 + li) * 256 + 4 * lg;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        xr[t] = *reinterpret_cast<const f32x4w*>(xp + 16 * t) + *reinterpret_cast<const f32x4w*>(p.bo + 16 * t + 4 * lg);
+    float rstd;
+    fw_layernorm_regs(xr, rstd);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4w g4 = *reinterpret_cast<const f32x4w*>(p.pg + 16 * t + 4 * lg);
+        const f32x4w b4 = *reinterpret_cast<const f32x4w*>(p.pb + 16 * t + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[t][r] = xr[t][r] * rstd * g4[r] + b4[r];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)        // the block input of output tile t (its residual), kept for fs_g2_kernel
+        if (t == c) *reinterpret_cast<f32x4w*>(b.X1 + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = xr[t];
+    const f32x4w b1v = *reinterpret_cast<const f32x4w*>(p.b1 + 16 * c + 4 * lg);
+    FW_SB();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4w hp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hp[r] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x4w c0 = *reinterpret_cast<const f32x4w*>(ring + (2 * u) * 256 + rdo);
+        const f32x4w c1 = *reinterpret_cast<const f32x4w*>(ring + (2 * u + 1) * 256 + rdo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c0[r], xr[2 * u][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) FW_MFMA(hp[r], c1[r], xr[2 * u + 1][r]);
+    }
+    f32x4w h = (hp[0] + hp[1]) + (hp[2] + hp[3]) + b1v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+    *reinterpret_cast<f32x4w*>(b.HG + ((size_t)g * (p.ff >> 4) + c) * 256 + lane * 4) = h;
+}
+
+__global__ __launch_bounds__(64) void fs_g2_kernel(FfnWideArgs p, FfnSpreadBufs b) {
+    __shared__ __attribute__((aligned(16))) float ring[32 * 256];       // two blocks of 16 weight slabs
+    const int ff = p.ff, nc = ff >> 4, nb = nc >> 4;
+    const int t = blockIdx.x, g = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    if (g * 16 >= fs_rows(p)) return;
+    const int drow = lane >> 2, dq = ((lane & 3) ^ fw_swz16(drow)) << 2;
+    const int rdo = li * 16 + ((lg ^ fw_swz16(li)) << 2);
+    const float* src = p.W2 + (size_t)(16 * t) * ff + drow * ff + dq;                // + 16 c: hidden chunk c of tile t
+    const float* hg = b.HG + (size_t)g * nc * 256 + lane * 4;                        // + 256 c: chunk c in the accumulator layout
+    const f32x4w b2v = *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t + 4 * lg);
+    const f32x4w r0 = *reinterpret_cast<const f32x4w*>(b.X1 + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg);
+    // Issue order (vector-memory results return in order): hidden tiles of block 0, weight blocks 0 and 1; then per block i:
+    // hidden tiles of block i + 1, [the block's MFMAs], weight block i + 2.  At the top of block i everything but the 16 slabs
+    // of weight block i + 1 has to be there: one counted wait.
+    f32x4w hh0[16], hh1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hh0[j] = *reinterpret_cast<const f32x4w*>(hg + j * 256);
+    FW_SB();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) FW_GLDS16(src + 16 * j, ring + j * 256);
+    if (nb > 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) FW_GLDS16(src + 16 * (16 + j), ring + (16 + j) * 256);
+    }
+    f32x4w y = f32x4w{0.f, 0.f, 0.f, 0.f};
+    // (two blocks per trip so that the hidden tiles' two register sets are indexed statically)
+#define FS_G2_BLOCK(HC, HN, CUR, blk)                                                                                     \
+    {                                                                                                                     \
+        FW_SB();                                                                                                          \
+        if ((blk) + 1 < nb) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }                                         \
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                         \
+        FW_SB();                                                                                                          \
+        if ((blk) + 1 < nb) {                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                                \
+                HN[j] = *reinterpret_cast<const f32x4w*>(hg + (16 * ((blk) + 1) + j) * 256);                              \
+        }                                                                                                                 \
+        FW_SB();                                                                                                          \
+        const float* rb = ring + (CUR) * 16 * 256;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                                  \
+            const f32x4w cw = *reinterpret_cast<const f32x4w*>(rb + j * 256 + rdo);                                       \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) FW_MFMA(y, cw[r], HC[j][r]);                                    \
+        }                                                                                                                 \
+        if ((blk) + 2 < nb) {                                                                                             \
+            FW_SB();                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                /* the ring half has been read */           \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                                \
+                FW_GLDS16(src + 16 * (16 * ((blk) + 2) + j), ring + ((CUR) * 16 + j) * 256);                              \
+        }                                                                                                                 \
+    }
+    for (int blk = 0; blk < nb; blk += 2) {
+        FS_G2_BLOCK(hh0, hh1, 0, blk);
+        if (blk + 1 < nb) FS_G2_BLOCK(hh1, hh0, 1, blk + 1);
+    }
+#undef FS_G2_BLOCK
+    y = y + b2v + r0;
+    *reinterpret_cast<f32x4w*>(b.YG + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = y;
+}
+
+__global__ __launch_bounds__(64) void fs_ln_kernel(FfnWideArgs p, FfnSpreadBufs b) {
+    const int g = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    const int my_row = g * 16 + li, M = fs_rows(p);
+    if (g * 16 >= M) return;
+    f32x4w y[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) y[t] = *reinterpret_cast<const f32x4w*>(b.YG + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg);
+    float rstd;
+    fw_layernorm_regs(y, rstd);
+    if (my_row < M) {
+        float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4w gg = *reinterpret_cast<const f32x4w*>(p.ln_g + 16 * t + 4 * lg);
+            const f32x4w be = *reinterpret_cast<const f32x4w*>(p.ln_b + 16 * t + 4 * lg);
+            f32x4w o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = y[t][r] * rstd * gg[r] + be[r];
+            *reinterpret_cast<f32x4w*>(op + 16 * t) = o;
+        }
+    }
+}
+
 #undef FW_STEP_BEGIN
 #undef FW_STEP_END
 #undef FW_SB
@@ -320,6 +510,35 @@ int launch_proj_ffn_wide(const float* A, int lda, const float* Wo, const float* 
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
     a.OUT = OUT; a.ldo = ldo; a.M = M; a.M_dev = M_dev; a.ff = ff;
     return launch_wide_t<true>(a, s);
+}
+
+// ---- the spread form (above): scratch = XP | X1 | YG (16 groups x 16 rows x 256) + HG (16 groups x ff / 16 tiles of 256)
+size_t ffn_spread_scratch_floats(int ff) { return (size_t)FS_MAX_GROUPS * (3 * 16 * 256 + (size_t)(ff >> 4) * 256); }
+bool ffn_spread_supported(int M, int ff) {
+    return M > 0 && (M + 15) / 16 <= FS_MAX_GROUPS && ff >= 256 && ff % 256 == 0;
+}
+int launch_proj_ffn_spread(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                           const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                           const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, int ff, float* scratch,
+                           hipStream_t s, const int* M_dev, const int* r_idx, const float* R2) {
+    CONE_REQUIRE(ffn_spread_supported(M, ff) && scratch, "spread layer tail: unsupported size M=%d ff=%d", M, ff);
+    CONE_REQUIRE(!r_idx || R2, "spread layer tail: a gathered residual needs both source matrices");
+    CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "spread layer tail: row strides must be multiples of 4");
+    FfnWideArgs a{};
+    a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.ff = ff; a.M_dev = M_dev; a.r_idx = r_idx; a.R2 = R2;
+    const int groups = (M + 15) / 16, nc = ff >> 4;
+    FfnSpreadBufs b;
+    b.XP = scratch; b.X1 = b.XP + (size_t)FS_MAX_GROUPS * 16 * 256; b.YG = b.X1 + (size_t)FS_MAX_GROUPS * 16 * 256;
+    b.HG = b.YG + (size_t)FS_MAX_GROUPS * 16 * 256;
+    ProfScope ps(PK_FFN_PROJ_WIDE, M, ff, 256, M_dev, s, 0);
+    hipLaunchKernelGGL(fs_proj_kernel, dim3(16, groups), dim3(64), 0, s, a, b);
+    hipLaunchKernelGGL(fs_g1_kernel, dim3(nc, groups), dim3(64), 0, s, a, b);
+    hipLaunchKernelGGL(fs_g2_kernel, dim3(16, groups), dim3(64), 0, s, a, b);
+    hipLaunchKernelGGL(fs_ln_kernel, dim3(groups), dim3(64), 0, s, a, b);
+    CONE_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace cone

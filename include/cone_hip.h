@@ -450,6 +450,13 @@ int cone_test_ffn_split(const float* X, const float* W1, const float* b1, const 
 size_t cone_test_rows_split_image_bytes(int N);
 int cone_test_rows_split(const float* X, const float* W, const float* bias, float* C, int M, int N, void* img, int pack,
                          void* stream);
+/* The same block in its SPREAD form (ffn_wide.hip: four launches over single-wave workgroups; a handful of row groups only:
+ * M <= CONE_FFN_SPREAD_MAX_ROWS); scratch of cone_test_proj_ffn_spread_scratch_bytes(ff) bytes.  Bit-identical rows. */
+#define CONE_FFN_SPREAD_MAX_ROWS 256
+size_t cone_test_proj_ffn_spread_scratch_bytes(int ff);
+int cone_test_proj_ffn_spread(const float* A, const float* Wo, const float* bo, const float* R, const float* pg, const float* pb,
+                              const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_g,
+                              const float* ln_b, float* OUT, int M, int ff, void* scratch, void* stream);
 /* cone_test_proj_ffn on the bf16 matrix cores; wo_img = scratch of cone_test_proj_split_image_bytes() bytes. */
 size_t cone_test_proj_split_image_bytes(void);
 int cone_test_proj_ffn_split(const float* A, const float* Wo, const float* bo, const float* R, const float* pg,

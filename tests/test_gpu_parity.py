@@ -2669,3 +2669,29 @@ def test_hip_graph_replay_with_two_sources_and_text_positions():
     got2, _ = inf.predict_split(model, store, gopt)
     strip = lambda lists: [[{k: v for k, v in it.items() if k == "predicted_times"} for it in l] for l in lists]
     assert strip(got2) == strip(ref2)
+
+
+@pytest.mark.parametrize("B", [1, 3, 9, 20, 204, 205])
+def test_spread_layer_tail_is_bit_identical(B):
+    """Up to 64 row groups (1 024 rows: the decoder slot rows of up to 204 windows, the token rows of up to 9) run the projecting
+    layer tail as four launches over single-wave workgroups (ffn_wide.hip: fs_*_kernel) instead of one CU per group walking the
+    whole block: every output element by the same fma chain -- the same bits as the wide form, which has the bits of the
+    persistent form (test_layer_tail_forms_are_bit_identical).  B <= 9: encoder tails too (device-side row count, the first
+    layer's gathered residual); B = 205: 1 025 slot rows, past the threshold, both runs take the wide form."""
+    model, opt, _ = get_model("ego4d", 0)
+    rng = np.random.default_rng(5 + B)
+    lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
+    lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
+    inp = gi.stage_b_inputs(opt, 300 + B, lens_v, lens_q)
+    dev = _gpu()
+    outs = []
+    try:
+        for on in (1, 0):
+            model.set_option("ffn_spread", on)
+            outs.append(stage_b_forward("arena", model, opt, inp, lens_v, lens_q, dev))
+    finally:
+        model.set_option("ffn_spread", 1)
+    for k in ("pred_logits", "pred_spans", "saliency_scores"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    for k in ("pred_logits", "pred_spans"):
+        assert torch.equal(outs[0]["aux_outputs"][0][k], outs[1]["aux_outputs"][0][k]), ("aux", k)

@@ -4,10 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cone_amd import synth, inference as inf
 from cone_amd.config import make_opt
 from cone_amd.model import build_model
-opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20)
+# usage: latency_bench.py [graph] [name=value model options ...] [NQxNV ...]   e.g. latency_bench.py graph ffn_spread=0 1x1
+args = sys.argv[1:]
+graph = "graph" in args
+opt = make_opt("ego4d", nms_thd=0.5, eval_split_name="test", topk_window=20, hip_graph=graph)
 model, _ = build_model(opt)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 0).items()})
-cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1, 1), (8, 1), (64, 4)]   # e.g. 1x1
+for a in args:
+    if "=" in a:
+        model.set_option(a.split("=")[0], int(a.split("=")[1]))
+cases = [tuple(int(v) for v in a.split("x")) for a in args if "x" in a and "=" not in a] or [(1, 1), (8, 1), (64, 4)]   # e.g. 1x1
 for nq, nv in cases:
     ann, vf, qf = synth.make_dataset(opt, nq, nv, seed=0, ctx_range=(900, 901))
     store = inf.FeatureStore(opt, ann, vf, qf)
@@ -15,4 +21,4 @@ for nq, nv in cases:
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): out, dp = inf.predict_split(model, store, opt)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
-    print(f"{nq} queries x {nv} videos: {dp['n_windows']} windows, {dt*1e3:.2f} ms per split")
+    print(f"{nq} queries x {nv} videos: {dp['n_windows']} windows, {dt*1e3:.3f} ms per split{' (hip graph)' if graph else ''}")

@@ -25,17 +25,24 @@ lib, P = _lib.load(), _lib.ptr
 Ms = [int(a) for a in sys.argv[1:]] or [1, 15, 16, 100, 320, 800, 1600, 2048, 3000, 4096, 6000, 8192, 12000, 16384]
 Xall = torch.randn(max(Ms), 256, generator=g).to(dev)
 Aall = torch.randn(max(Ms), 256, generator=g).to(dev)
+scratch = torch.empty(lib.cone_test_proj_ffn_spread_scratch_bytes(ff), dtype=torch.uint8, device=dev)
+SPREAD_MAX = int(os.environ.get("SPREAD_MAX", 256))
 for M in Ms:
     X, A = Xall[:M].contiguous(), Aall[:M].contiguous()
     out = torch.empty(M, 256, device=dev)
     calls = {
         "proj": lambda: _lib.check(lib.cone_test_proj_ffn(P(A), P(Wo), P(bo), P(X), P(pg), P(pb), P(W1), P(b1), P(W2),
                                                           P(b2), P(lg), P(lb), P(out), M, ff, _lib.stream())),
+        # the spread form (four launches over single-wave workgroups): only up to its group limit
+        "spread": lambda: _lib.check(lib.cone_test_proj_ffn_spread(P(A), P(Wo), P(bo), P(X), P(pg), P(pb), P(W1), P(b1), P(W2),
+                                                                   P(b2), P(lg), P(lb), P(out), M, ff, P(scratch), _lib.stream())),
         "ffn": lambda: _lib.check(lib.cone_test_ffn(P(X), P(W1), P(b1), P(W2), P(b2), P(lg), P(lb), P(out), M, ff,
                                                     _lib.stream())),
     }
     line = f"M={M:6d}:"
     for name, call in calls.items():
+        if name == "spread" and M > SPREAD_MAX:
+            continue
         for _ in range(3):
             call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
