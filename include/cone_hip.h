@@ -421,6 +421,9 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  * "rows_chain" (default 1): for few rows (the regime of the row GEMM's 16-row form) decoder.norm + class head + span MLP +
  *   span head of a decoder layer, and the adapter pair of the proposal matching (d = 256 features), run as ONE launch each
  *   with the rows on chip in between (rows_chain.h); 0 = the separate launches.  Bit-identical.
+ * "ffn_spread" (default 1): a projecting layer tail of at most 1 024 rows (the decoder slot rows of a small batch, the token
+ *   rows of a few windows) runs as four launches over single-wave workgroups (ffn_wide.hip, fs_*_kernel) instead of one CU
+ *   per 16 rows walking the whole block; 0 = the wide form.  Bit-identical.
  * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
  *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
  *   exact-fp32 fma chains per output element that walk k in different orders. */
@@ -452,7 +455,7 @@ int cone_test_rows_split(const float* X, const float* W, const float* bias, floa
                          void* stream);
 /* The same block in its SPREAD form (ffn_wide.hip: four launches over single-wave workgroups; a handful of row groups only:
  * M <= CONE_FFN_SPREAD_MAX_ROWS); scratch of cone_test_proj_ffn_spread_scratch_bytes(ff) bytes.  Bit-identical rows. */
-#define CONE_FFN_SPREAD_MAX_ROWS 256
+#define CONE_FFN_SPREAD_MAX_ROWS 1024
 size_t cone_test_proj_ffn_spread_scratch_bytes(int ff);
 int cone_test_proj_ffn_spread(const float* A, const float* Wo, const float* bo, const float* R, const float* pg, const float* pb,
                               const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_g,

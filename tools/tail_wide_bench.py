@@ -26,7 +26,7 @@ Ms = [int(a) for a in sys.argv[1:]] or [1, 15, 16, 100, 320, 800, 1600, 2048, 30
 Xall = torch.randn(max(Ms), 256, generator=g).to(dev)
 Aall = torch.randn(max(Ms), 256, generator=g).to(dev)
 scratch = torch.empty(lib.cone_test_proj_ffn_spread_scratch_bytes(ff), dtype=torch.uint8, device=dev)
-SPREAD_MAX = int(os.environ.get("SPREAD_MAX", 256))
+SPREAD_MAX = int(os.environ.get("SPREAD_MAX", 1024))
 for M in Ms:
     X, A = Xall[:M].contiguous(), Aall[:M].contiguous()
     out = torch.empty(M, 256, device=dev)
