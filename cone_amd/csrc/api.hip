@@ -329,6 +329,7 @@ static GemmArgs G(const cone_model* m, const float* A, int lda, const float* W, 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.M_dev = M_dev; g.N = N; g.K = K; g.flags = flags;
     g.variant = m ? m->opt_gemm : GEMM_AUTO;
+    if (m && !m->opt_spread) g.flags |= GEMM_NO_SPREAD;        // option ffn_spread = 0: no spread forms anywhere
     return g;
 }
 

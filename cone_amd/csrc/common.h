@@ -104,7 +104,8 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------- GEMM launcher (gemm.hip)
-enum { EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_LN = 4 };
+enum { EPI_RELU = 1, EPI_RESIDUAL = 2, EPI_LN = 4,
+       GEMM_NO_SPREAD = 8 };      // (not an epilogue: keeps a small launch on the workgroup-per-16-rows form; A/B tests)
 
 struct GemmArgs {
     const float* A; int lda;              // (M,K) row-major, K contiguous

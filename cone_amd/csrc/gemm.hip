@@ -724,6 +724,61 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
     }
 }
 
+// SPREAD form of the small row GEMM for a handful of row groups without a LayerNorm epilogue (the slot-row projections of a
+// small batch: 100 rows x N = 768 is 7 workgroups of the form above, each streaming all of W through one CU): ONE WAVE per
+// (16 rows, 16 columns), its A and W slabs requested at once, the same chain per element -- for kt, for j: acc = mfma(a[j],
+// b[j], acc) -- and the same epilogue arithmetic (+ bias, ReLU, + residual) on the accumulator layout.  K <= 256.
+constexpr int RSP_MAX_GROUPS = 64;
+__global__ __launch_bounds__(64) void gemm_rows_spread_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[16 * 256];
+    __shared__ __attribute__((aligned(16))) float Ws[16 * 256];
+    int M = p.M;
+    if (p.M_dev) { int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    if (m0 >= M) return;
+    const int nk = p.K / 16;
+    const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+    const int drow = lane >> 2;
+    const int dq = ((lane & 3) ^ swz16(drow)) << 2;
+    const int arow = min(m0 + drow, M - 1);
+    const float* __restrict__ asrc = p.A + (size_t)arow * p.lda + dq;
+    const float* __restrict__ wsrc = p.W + (size_t)(n0 + drow) * p.ldw + dq;
+    const int rdo = li * 16 + ((lg ^ swz16(li)) << 2);
+    for (int kt = 0; kt < nk; ++kt) { GLDS16(asrc + 16 * kt, As + kt * 256); GLDS16(wsrc + 16 * kt, Ws + kt * 256); }
+    // the epilogue's operands under the slabs' flight (ordinary loads: everything is waited for below)
+    const int col = n0 + li;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const int flags = p.flags;
+    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (flags & EPI_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t m = (size_t)min(m0 + 4 * lg + r, M - 1);
+            rr[r] = p.R[(p.r_mod ? (m + (size_t)p.m_off) % (size_t)p.r_mod : m) * p.ldr + col];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4a acc = f32x4a{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        const f32x4a a = *reinterpret_cast<const f32x4a*>(As + kt * 256 + rdo);
+        const f32x4a b = *reinterpret_cast<const f32x4a*>(Ws + kt * 256 + rdo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    // accumulator r of lane (li, lg) = row 4 lg + r, column n0 + li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x = acc[r];
+        x += bias;
+        if (flags & EPI_RELU) x = fmaxf(x, 0.f);
+        if (flags & EPI_RESIDUAL) x += rr[r];
+        const int m = m0 + 4 * lg + r;
+        if (m < M) p.C[(size_t)m * p.ldc + col] = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // rows_chain_kernel (rows_chain.h): up to four row-wise stages over the 16 rows of a workgroup, the rows on chip in between.
 // A GEMM stage is gemm_rows_small_kernel's body on operand slabs that the PREVIOUS stage left in LDS (instead of LDS-DMA from
@@ -953,6 +1008,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                 if (a.R && !a.r_mod) t.R = a.R + (size_t)m1 * a.ldr;
                 return launch_gemm(t, s);
             }
+        }
+        if (small_ok && !(a.flags & EPI_LN) && a.K <= 256 && (a.M + 15) / 16 <= RSP_MAX_GROUPS && !(a.flags & GEMM_NO_SPREAD)) {
+            // a handful of row groups, no LayerNorm epilogue: one wave per 16 x 16 output tile (bit-identical; see the kernel)
+            ProfScope ps(PK_GEMM_ROWS_SMALL, a.M, a.N, a.K, a.M_dev, s, a.m_off);
+            hipLaunchKernelGGL(gemm_rows_spread_kernel, dim3((unsigned)(a.N / 16), (unsigned)((a.M + 15) / 16)), dim3(64), 0, s, a);
+            CONE_LAUNCH_CHECK();
+            return 0;
         }
         if (small_ok && (int64_t)((a.M + 15) / 16) * (a.N / RT_BN) <= RS_MAX_WGS) {
             // small-M form: the same chains on 16-row tiles spread over the CUs (bit-identical rows; see the kernel)

@@ -423,12 +423,14 @@ int64_t cone_prof_collect(double* out, int64_t max_rec);
  *   with the rows on chip in between (rows_chain.h); 0 = the separate launches.  Bit-identical.
  * "ffn_spread" (default 1): a projecting layer tail of at most 1 024 rows (the decoder slot rows of a small batch, the token
  *   rows of a few windows) runs as four launches over single-wave workgroups (ffn_wide.hip, fs_*_kernel) instead of one CU
- *   per 16 rows walking the whole block; 0 = the wide form.  Bit-identical.
+ *   per 16 rows walking the whole block, and a row GEMM of at most 1 024 rows without a LayerNorm epilogue as one wave per
+ *   16 x 16 output tile; 0 = the wide form / the workgroup-per-16-rows form.  Bit-identical.
  * "gemm" (default 0 = by shape): tile family of every dense layer: 1 = register-staged 128x128 / 64x256 tiles,
  *   2 / 3 = 128x256 row-owning LDS-DMA tile with 4 waves x 32 rows (32x32x2) / 8 waves x 16 rows (16x16x4) -- all
  *   exact-fp32 fma chains per output element that walk k in different orders. */
 int cone_model_set_option(cone_model* m, const char* name, int value);
-/* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256);
+/* C = epi((A [+ A2]) W^T + bias); flags: 1 relu, 2 add residual R, 4 LayerNorm(g,b) (N must be 256), 8 = keep a launch of a few
+ * row groups on the workgroup-per-16-rows form (else: one wave per 16 x 16 output tile, same bits);
  * bits 8-9 force a tile family (1 = 128x128 / 64x256 register-staged tiles, 2 = 128x256 row-owning LDS-DMA tile
  * with 4 waves x 32 rows, 3 = the same tile with 8 waves x 16 rows, 0 = automatic = 3 where the shape allows).  Optional second output C2 = C + ADD (row tile only). */
 int cone_test_gemm(const float* A, const float* A2, int a2_mod, const float* W, const float* bias,

@@ -183,14 +183,17 @@ def test_fused_ffn_matches_float64(M, ff):
 @pytest.mark.parametrize("M,N,K,flags", [(100, 256, 256, 0), (777, 768, 256, 1), (37, 256, 1024, 2 | 4), (4096, 512, 256, 2),
                                          (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0),
                                          (20_000, 256, 256, 2 | 4), (33_000, 256, 512, 1 | 2), (33_000, 768, 256, 2),
-                                         (100_000, 256, 256, 1 | 2 | 4), (64, 256, 2048, 1), (300, 512, 1536, 2)])
+                                         (100_000, 256, 256, 1 | 2 | 4), (64, 256, 2048, 1), (300, 512, 1536, 2),
+                                         (100, 768, 256, 2), (1000, 256, 256, 1 | 2), (1024, 768, 256, 0), (1025, 768, 256, 0)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     """gemm.hip: launches of at most 1 280 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel)
     instead of one 128 x 256 tile per 128 rows, and the rows past the last full round of 128-row tiles (33 000 rows = 258
     tiles on 256 CUs; 100 000 = 782) are launched as that small form too; same fma chains, same per-row epilogue -- the same
     bits as the 128-row tile (forced here with the tile-family test hook), so a row's result does not depend on the size of
     the batch it is computed in.  (K = 2 048: the staged activation slabs would not fit the LDS -- the launcher keeps the
-    128-row tile; K = 1 536: they fit with one workgroup per CU.)"""
+    128-row tile; K = 1 536: they fit with one workgroup per CU.)  Launches of at most 64 row groups with K <= 256 and no
+    LayerNorm epilogue take the SPREAD form (one wave per 16 x 16 output tile, gemm_rows_spread_kernel): the third run keeps
+    them on the workgroup form (flag 8) -- all three the same bits."""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(M * 7 + N + K + flags)
@@ -200,13 +203,13 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     lg, lb = d(torch.rand(N, generator=g) + 0.5), d(torch.randn(N, generator=g))
     lib, P = _lib.load(), _lib.ptr
     outs = []
-    for fam in (0, 0x300):                              # automatic (small-M form at this size) / forced 8-wave 128-row tile
+    for fam in (0, 0x300, 8):                           # automatic (small-M / spread form at this size) / forced 8-wave 128-row tile / no spread
         C = torch.full((M, N), float("nan"), device=dev)
         _lib.check(lib.cone_test_gemm(P(A), None, 0, P(W), P(bias), P(R) if flags & 2 else None, P(lg), P(lb), P(C), None, None,
                                       M, N, K, flags | fam, _lib.stream()))
         outs.append(C)
     torch.cuda.synchronize()
-    assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1])
+    assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("ff", [1024, 384, 2048, 128])
