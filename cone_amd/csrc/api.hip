@@ -866,7 +866,8 @@ static int forward_packed(const cone_model* m, const float* vproj, const int* vr
     float* SPo = want_aux ? f.SP + hoff * 2 : spans;
     // (the chain only where launch_gemm itself would run its 16-row form, and only on the automatic tile family: the A/B
     // families walk k in other orders)
-    const bool heads_chain = m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T);
+    const bool heads_chain = m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T) &&
+                             !(m->opt_spread && gemm_rows_spread_rows(T));      // (few rows: the spread GEMM launches are faster)
     // the position rows come from the tables inside the cross-attention kernels -- unless text tokens carry their own
     // (--use_txt_pos): then memory + pos is written once (dec_xp) and the kernels run their x + pos form
     const bool dec_tab = plan.tables && !plan.dec_xp;
@@ -1217,7 +1218,8 @@ extern "C" int cone_clip_matching_gathered(const cone_model* m, const float* cls
     if (!c.ok) { set_error("clip_matching: workspace too small (%zu < %zu)", ws_bytes, c.cur); return CONE_E_WORKSPACE; }
     RUN(launch_proposal_mean(vid, vid_row0, vid_len, pad_len, spans, B, m->nq, dv, pf, s));
     const float* feat = pf;
-    if (m->has_adapter && dv == 256 && m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T)) {
+    if (m->has_adapter && dv == 256 && m->opt_chain && m->opt_gemm == GEMM_AUTO && rows_chain_supported(T) &&
+        !(m->opt_spread && gemm_rows_spread_rows(T))) {
         ChainArgs ca{};     // few proposals: both adapter layers in one launch (rows_chain.h; the same arithmetic)
         ca.A = pf; ca.lda = dv; ca.M = T; ca.n_stages = 2;
         ca.st[0].kind = 0; ca.st[0].K = dv; ca.st[0].W = m->adapter[0].w; ca.st[0].bias = m->adapter[0].b; ca.st[0].flags = EPI_RELU;

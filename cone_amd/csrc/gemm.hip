@@ -1055,6 +1055,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 }
 
 bool rows_chain_supported(int M) { return M > 0 && (M + 15) / 16 <= RS_MAX_WGS; }
+// launches of this many rows (K <= 256, no LayerNorm epilogue) take the spread form of the row GEMM
+bool gemm_rows_spread_rows(int M) { return M > 0 && (M + 15) / 16 <= RSP_MAX_GROUPS; }
 
 int launch_rows_chain(const ChainArgs& a, hipStream_t s) {
     CONE_REQUIRE(a.A && a.n_stages >= 1 && a.n_stages <= CHAIN_MAX_STAGES && a.lda % 4 == 0, "rows chain: bad arguments");

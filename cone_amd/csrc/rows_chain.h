@@ -33,6 +33,9 @@ struct ChainArgs {
 // the row counts launch_gemm would run on its small form (16-row tiles): only there the chain is never slower than the
 // launches it replaces (the same weight traffic per 16 rows)
 bool rows_chain_supported(int M);
+// rows of a launch that takes the SPREAD form of the row GEMM instead (K <= 256, no LayerNorm epilogue): there the separate
+// launches beat the chain (one wave per output tile against one workgroup per 16 rows walking every stage)
+bool gemm_rows_spread_rows(int M);
 int launch_rows_chain(const ChainArgs& a, hipStream_t s);
 
 }  // namespace cone

@@ -610,14 +610,29 @@ def test_rows_chain_is_bit_identical(preset):
     store = inf.FeatureStore(popt, ann, vf, qf)
     res = {}
     try:
+        # (at these row counts the default is neither: the spread row GEMM, one wave per output tile, beats the chain up to
+        # 1 024 rows -- switched off here so that the chain runs, as it does from 1 025 to 20 480 rows)
+        model.set_option("ffn_spread", 0)
         for on in (1, 0):
             model.set_option("rows_chain", on)
             o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
             mt = model.forward_clip_matching(g(inp["src_cls_txt"]), g(inp["src_vid"]), g(inp["vid_mask"]), proposal=o["pred_spans"])
             dp = inf.device_pipeline(model, store, popt)
             res[on] = (o, mt, {k: dp[k].clone() for k in ("rows", "n", "cand")})
+        model.set_option("ffn_spread", 1)       # the default at this size (spread GEMM launches): the same bits again
+        model.set_option("rows_chain", 1)
+        o = model.forward(g(inp["src_txt"]), g(inp["txt_mask"]), g(inp["src_vid"]), g(inp["vid_mask"]), taps=True)
+        mt = model.forward_clip_matching(g(inp["src_cls_txt"]), g(inp["src_vid"]), g(inp["vid_mask"]), proposal=o["pred_spans"])
+        dp = inf.device_pipeline(model, store, popt)
+        res[2] = (o, mt, {k: dp[k].clone() for k in ("rows", "n", "cand")})
     finally:
         model.set_option("rows_chain", 1)
+        model.set_option("ffn_spread", 1)
+    for k in ("pred_logits", "pred_spans", "hs", "saliency_scores"):
+        assert torch.equal(res[2][0][k], res[0][0][k]), ("spread", k)
+    assert torch.equal(res[2][1], res[0][1])
+    for k in ("rows", "n", "cand"):
+        assert torch.equal(res[2][2][k], res[0][2][k]), ("spread", k)
     a, b = res[1], res[0]
     for k in ("pred_logits", "pred_spans", "hs", "saliency_scores"):
         assert torch.equal(a[0][k], b[0][k]), k
