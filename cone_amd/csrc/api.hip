@@ -617,6 +617,22 @@ static int forward_packed_prenorm(const cone_model* m, const float* vproj, const
 // block, the block, residual; the NEXT consumer's LayerNorm -- the next layer's norm1, the encoder's / decoder's final norm --
 // written as a second output), the folded decoder cross-attention.  What it does not have: the first layer's row caches (its
 // in_proj reads norm1(x)) and the first decoder layer's constants.
+// The pre-norm layer tail by row count, as the post-norm one: <= 1 024 rows the spread form, <= 12 288 the wide form, else the
+// persistent 128-row kernel -- the same bits in every form (option ffn_spread = 0: the persistent kernel only).
+static int tail_prenorm(const cone_model* m, const FwdBuffers& f, const float* A, const float* Wo, const float* bo, const float* R,
+                        const float* pg, const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
+                        float* OUT, const float* n2g, const float* n2b, float* OUT2, int M, const int* M_dev, int ff, hipStream_t s,
+                        const int* r_idx = nullptr, const float* R2 = nullptr) {
+    if (m->opt_spread && f.SPR && ffn_spread_supported(M, ff))
+        return launch_proj_ffn_spread(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, n2g ? n2g : pg, n2b ? n2b : pb, OUT, 256, M, ff,
+                                      f.SPR, s, M_dev, r_idx, R2, true, OUT2, 256);
+    if (m->opt_spread && (M + 15) / 16 <= 768 && ffn_wide_supported(ff))
+        return launch_proj_ffn_prenorm_wide(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, OUT, 256, n2g, n2b, OUT2, 256, M, M_dev,
+                                            ff, s, r_idx, R2);
+    return launch_proj_ffn_prenorm(A, 256, Wo, bo, R, 256, pg, pb, W1, b1, W2, b2, OUT, 256, n2g, n2b, OUT2, 256, M, M_dev, ff, s,
+                                   r_idx, R2);
+}
+
 static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj, const int* vrow0, const int* vlen,
                                         const float* tproj, const int* trow0, const int* qlen, int B, int Lv_max, int Lq_max,
                                         float* logits, float* spans, float* saliency, const cone_taps* taps, FwdBuffers& f,
@@ -651,9 +667,8 @@ static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj,
         }
         RUN(launch_enc_attn(g0 ? ATTN_GATHER : ATTN_POSADD, src, f.ATT, f.off, B, Lmax, s));
         const LNorm& nxt = l + 1 < m->n_enc ? m->enc[l + 1].n1 : m->enc_norm;
-        RUN(launch_proj_ffn_prenorm(f.ATT, 256, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, 256, e.n2.g, e.n2.b, e.l1.w, e.l1.b,
-                                    e.l2.w, e.l2.b, f.X, 256, nxt.g, nxt.b, Z, 256, Mmax, Mdev, ff, s,
-                                    g0 ? f.RIDX : nullptr, g0 ? tproj : nullptr));
+        RUN(tail_prenorm(m, f, f.ATT, e.sa.out.w, e.sa.out.b, g0 ? vproj : f.X, e.n2.g, e.n2.b, e.l1.w, e.l1.b, e.l2.w, e.l2.b, f.X,
+                         nxt.g, nxt.b, Z, Mmax, Mdev, ff, s, g0 ? f.RIDX : nullptr, g0 ? tproj : nullptr));
     }
     const float* MEM = Z;                                                                            // encoder.norm(src)
     // --use_txt_pos: the keys memory + pos written once (text rows from the tokens' own position rows), x + pos form of the fold
@@ -677,9 +692,8 @@ static int forward_packed_prenorm_fused(const cone_model* m, const float* vproj,
         RUN(launch_gemm(g, s));
         RUN(launch_dec_cross_mfma(f.DQ, xp ? f.XP : nullptr, MEM, xp ? nullptr : l0->pos_rows, vlen, f.off, dl.ca.in_w + 256 * 256,
                                   m->dec_vT[l], dl.ca.in_b + 512, f.DATT, B, m->nq, Lmax, nullptr, s, 3));
-        RUN(launch_proj_ffn_prenorm(f.DATT, 256, dl.ca.out.w, dl.ca.out.b, f.TGT, 256, dl.n3.g, dl.n3.b, dl.l1.w, dl.l1.b, dl.l2.w,
-                                    dl.l2.b, f.TGT, 256, m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, 256, T, nullptr,
-                                    ff, s));
+        RUN(tail_prenorm(m, f, f.DATT, dl.ca.out.w, dl.ca.out.b, f.TGT, dl.n3.g, dl.n3.b, dl.l1.w, dl.l1.b, dl.l2.w, dl.l2.b, f.TGT,
+                         m->dec_norm.g, m->dec_norm.b, f.HS + (size_t)l * T * 256, T, nullptr, ff, s));
     }
     const int HT = nd * T;
     RUN(launch_rowdot(f.HS, 256, m->class_embed.w, m->class_embed.b, f.LG, 2, HT, 2, 0, s));

@@ -166,7 +166,12 @@ bool ffn_spread_supported(int M, int ff);
 int launch_proj_ffn_spread(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
                            const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
                            const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, int ff, float* scratch,
-                           hipStream_t s, const int* M_dev = nullptr, const int* r_idx = nullptr, const float* R2 = nullptr);
+                           hipStream_t s, const int* M_dev = nullptr, const int* r_idx = nullptr, const float* R2 = nullptr,
+                           bool pre = false, float* OUT2 = nullptr, int ldo2 = 0);      // pre: the pre-norm tail (OUT = the stream, OUT2 = LN(OUT; ln_g, ln_b))
+int launch_proj_ffn_prenorm_wide(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                                 const float* pb, const float* W1, const float* b1, const float* W2, const float* b2, float* OUT,
+                                 int ldo, const float* n2g, const float* n2b, float* OUT2, int ldo2, int M, const int* M_dev, int ff,
+                                 hipStream_t s, const int* r_idx = nullptr, const float* R2 = nullptr);
 // m_off: the rows are rows m_off .. m_off + M of a larger job whose device-side row count is *M_dev
 int launch_ffn_wide(const float* X, int ldx, const float* W1, const float* b1, const float* W2, const float* b2,
                     const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, const int* M_dev, int ff, hipStream_t s,

@@ -40,6 +40,7 @@ struct FfnWideArgs {
     const float* Wo; const float* bo; const float* pg; const float* pb;
     const float* W1; const float* b1; const float* W2; const float* b2; const float* ln_g; const float* ln_b;
     float* OUT; int ldo; int M; const int* M_dev; int ff; int m_off;
+    float* OUT2; int ldo2;      // PRE (pre-norm tail): OUT = the un-normalised stream, OUT2 (may be null) = LayerNorm(OUT; ln_g, ln_b)
 };
 
 constexpr int FW_XLD = 260;     // row stride (floats) of the 16 x 256 exchange tile
@@ -102,8 +103,11 @@ __device__ __forceinline__ void fw_layernorm_regs(f32x4w (&v)[16], float& rstd) 
         FW_SB();                                               \
     }
 
-template <bool PROJ>
+// PRE (PROJ only; --pre_norm, as ffn.hip's PRE): the block input is LayerNorm_p(x1) of the un-normalised stream x1 = R + A Wo^T + bo,
+// the output accumulators START from x1 + b2, OUT = the stream, OUT2 = LayerNorm(OUT) for the next consumer.
+template <bool PROJ, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
+    static_assert(!PRE || PROJ, "the pre-norm form is the projecting tail");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ff = p.ff, nc = ff >> 4;
     float* XS = smem;                               // [16 tokens][FW_XLD]: projected rows, later the block's output rows
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     f32x4w c0, c1, n0, n1;                          // the current / next slab pair as MFMA operands
     // ---- the block input x1 (every wave holds the 16 rows: xr[q][r] = row[token li][16 q + 4 lg + r])
     f32x4w xr[16];
+    f32x4w pre_b2a = f32x4w{0.f, 0.f, 0.f, 0.f}, pre_b2b = pre_b2a, pre_y0 = pre_b2a, pre_y1 = pre_b2a;
     if (PROJ) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { FW_GLDS16(srcA(j, 0), ring + (2 * j) * 256); FW_GLDS16(srcA(j, 1), ring + (2 * j + 1) * 256); }
@@ -154,6 +159,10 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
         }
         const f32x4w r0 = *reinterpret_cast<const f32x4w*>(rp + 32 * wave);          // the residual of this wave's two tiles
         const f32x4w r1 = *reinterpret_cast<const f32x4w*>(rp + 32 * wave + 16);
+        if (PRE) {                                          // b2 of the two tiles: the start of their output accumulators
+            pre_b2a = *reinterpret_cast<const f32x4w*>(p.b2 + 32 * wave + 4 * lg);
+            pre_b2b = *reinterpret_cast<const f32x4w*>(p.b2 + 32 * wave + 16 + 4 * lg);
+        }
         FW_SB();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the younger row loads are needed by the first MFMA anyway)
         c0 = *reinterpret_cast<const f32x4w*>(ring + rdo);
@@ -182,6 +191,13 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
         for (int t = 0; t < 16; ++t)
             xr[t] = *reinterpret_cast<const f32x4w*>(XS + li * FW_XLD + 16 * t + 4 * lg) +
                     *reinterpret_cast<const f32x4w*>(p.bo + 16 * t + 4 * lg);
+        if (PRE) {      // the un-normalised stream is the residual: this wave's two output tiles start from x1 + b2
+            f32x4w s0 = xr[0], s1 = xr[1];
+#pragma unroll
+            for (int g = 1; g < 8; ++g)
+                if (wave == g) { s0 = xr[2 * g]; s1 = xr[2 * g + 1]; }
+            pre_y0 = s0 + pre_b2a; pre_y1 = s1 + pre_b2b;
+        }
         float rstd;
         fw_layernorm_regs(xr, rstd);
 #pragma unroll
@@ -210,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     for (int g = 1; g < 8; ++g)
         if (wave == g) { r0 = xr[2 * g]; r1 = xr[2 * g + 1]; }
     f32x4w y0 = f32x4w{0.f, 0.f, 0.f, 0.f}, y1 = y0;
+    if (PRE) { y0 = pre_y0; y1 = pre_y1; }
     for (int s = 0; s < npass; ++s) {
         // ---- GEMM1 block: hidden chunk c = wave + 8 s: four partial chains over the 16 k-slabs, as ffn.hip's FFN_MM_A
         const int c = wave + FW_PASS * s;
@@ -250,8 +267,17 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     const int t0 = 2 * wave;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the workgroup's LDS allocation
     // ---- epilogue: + b2 + residual of this wave's tiles -> LDS, full rows back, LayerNorm (same routine, same layout)
-    y0 = y0 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t0 + 4 * lg) + r0;
-    y1 = y1 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * (t0 + 1) + 4 * lg) + r1;
+    if (!PRE) {
+        y0 = y0 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t0 + 4 * lg) + r0;
+        y1 = y1 + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * (t0 + 1) + 4 * lg) + r1;
+    } else {
+        if (my_row < M) {                               // the un-normalised stream: each wave stores the two tiles it computed
+            float* sp = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+            *reinterpret_cast<f32x4w*>(sp + 16 * t0) = y0;
+            *reinterpret_cast<f32x4w*>(sp + 16 * (t0 + 1)) = y1;
+        }
+        if (!p.OUT2) return;
+    }
     __syncthreads();                                    // (PROJ: every wave is done reading the projected rows)
     *reinterpret_cast<f32x4w*>(XS + li * FW_XLD + 16 * t0 + 4 * lg) = y0;
     *reinterpret_cast<f32x4w*>(XS + li * FW_XLD + 16 * (t0 + 1) + 4 * lg) = y1;
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void ffn_wide_kernel(FfnWideArgs p) {
     float rstd;
     fw_layernorm_regs(y, rstd);
     if (my_row < M) {
-        float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+        float* op = PRE ? p.OUT2 + (size_t)my_row * p.ldo2 + 4 * lg : p.OUT + (size_t)my_row * p.ldo + 4 * lg;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {                  // each wave stores the two tiles it computed
             if ((t >> 1) == wave) {
@@ -338,6 +364,7 @@ __global__ __launch_bounds__(64) void fs_proj_kernel(FfnWideArgs p, FfnSpreadBuf
     *reinterpret_cast<f32x4w*>(b.XP + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = x0;
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(64) void fs_g1_kernel(FfnWideArgs p, FfnSpreadBufs b) {
     __shared__ __attribute__((aligned(16))) float ring[16 * 256];
     const int c = blockIdx.x, g = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
@@ -353,6 +380,13 @@ __global__ __launch_bounds__(64) void fs_g1_kernel(FfnWideArgs p, FfnSpreadBufs 
 #pragma unroll
     for (int t = 0; t < 16; ++t)
         xr[t] = *reinterpret_cast<const f32x4w*>(xp + 16 * t) + *reinterpret_cast<const f32x4w*>(p.bo + 16 * t + 4 * lg);
+    if (PRE) {      // pre-norm: output tile t starts from the un-normalised stream + b2 (as ffn.hip's PRE): kept for fs_g2_kernel
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t == c)
+                *reinterpret_cast<f32x4w*>(b.X1 + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) =
+                    xr[t] + *reinterpret_cast<const f32x4w*>(p.b2 + 16 * t + 4 * lg);
+    }
     float rstd;
     fw_layernorm_regs(xr, rstd);
 #pragma unroll
@@ -362,9 +396,11 @@ __global__ __launch_bounds__(64) void fs_g1_kernel(FfnWideArgs p, FfnSpreadBufs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) xr[t][r] = xr[t][r] * rstd * g4[r] + b4[r];
     }
+    if (!PRE) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t)        // the block input of output tile t (its residual), kept for fs_g2_kernel
-        if (t == c) *reinterpret_cast<f32x4w*>(b.X1 + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = xr[t];
+        for (int t = 0; t < 16; ++t)    // the block input of output tile t (its residual), kept for fs_g2_kernel
+            if (t == c) *reinterpret_cast<f32x4w*>(b.X1 + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = xr[t];
+    }
     const f32x4w b1v = *reinterpret_cast<const f32x4w*>(p.b1 + 16 * c + 4 * lg);
     FW_SB();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -386,6 +422,7 @@ __global__ __launch_bounds__(64) void fs_g1_kernel(FfnWideArgs p, FfnSpreadBufs 
     *reinterpret_cast<f32x4w*>(b.HG + ((size_t)g * (p.ff >> 4) + c) * 256 + lane * 4) = h;
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(64) void fs_g2_kernel(FfnWideArgs p, FfnSpreadBufs b) {
     __shared__ __attribute__((aligned(16))) float ring[32 * 256];       // two blocks of 16 weight slabs
     const int ff = p.ff, nc = ff >> 4, nb = nc >> 4;
@@ -411,6 +448,7 @@ __global__ __launch_bounds__(64) void fs_g2_kernel(FfnWideArgs p, FfnSpreadBufs 
         for (int j = 0; j < 16; ++j) FW_GLDS16(src + 16 * (16 + j), ring + (16 + j) * 256);
     }
     f32x4w y = f32x4w{0.f, 0.f, 0.f, 0.f};
+    if (PRE) y = r0;                    // (pre-norm: X1 holds the stream + b2, the accumulator's start)
     // (two blocks per trip so that the hidden tiles' two register sets are indexed statically)
 #define FS_G2_BLOCK(HC, HN, CUR, blk)                                                                                     \
     {                                                                                                                     \
@@ -440,10 +478,11 @@ __global__ __launch_bounds__(64) void fs_g2_kernel(FfnWideArgs p, FfnSpreadBufs 
         if (blk + 1 < nb) FS_G2_BLOCK(hh1, hh0, 1, blk + 1);
     }
 #undef FS_G2_BLOCK
-    y = y + b2v + r0;
+    if (!PRE) y = y + b2v + r0;
     *reinterpret_cast<f32x4w*>(b.YG + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg) = y;
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(64) void fs_ln_kernel(FfnWideArgs p, FfnSpreadBufs b) {
     const int g = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
     const int my_row = g * 16 + li, M = fs_rows(p);
@@ -451,10 +490,18 @@ __global__ __launch_bounds__(64) void fs_ln_kernel(FfnWideArgs p, FfnSpreadBufs 
     f32x4w y[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) y[t] = *reinterpret_cast<const f32x4w*>(b.YG + ((size_t)g * 16 + li) * 256 + 16 * t + 4 * lg);
+    if (PRE) {                          // the un-normalised stream; its LayerNorm only where a consumer wants it
+        if (my_row < M) {
+            float* sp = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4w*>(sp + 16 * t) = y[t];
+        }
+        if (!p.OUT2) return;
+    }
     float rstd;
     fw_layernorm_regs(y, rstd);
     if (my_row < M) {
-        float* op = p.OUT + (size_t)my_row * p.ldo + 4 * lg;
+        float* op = PRE ? p.OUT2 + (size_t)my_row * p.ldo2 + 4 * lg : p.OUT + (size_t)my_row * p.ldo + 4 * lg;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const f32x4w gg = *reinterpret_cast<const f32x4w*>(p.ln_g + 16 * t + 4 * lg);
@@ -477,15 +524,15 @@ static size_t fw_lds_bytes(int ff) { return (size_t)(16 * FW_XLD + FW_PASS * 256
 
 bool ffn_wide_supported(int ff) { return ff >= 128 && ff % 128 == 0 && fw_lds_bytes(ff) <= 160 * 1024; }
 
-template <bool PROJ>
+template <bool PROJ, bool PRE = false>
 static int launch_wide_t(const FfnWideArgs& a, hipStream_t s) {
     const size_t lds = fw_lds_bytes(a.ff);
     static DeviceOnce once;
     CONE_CHECK_HIP(device_once(once, [] {
-        return hipFuncSetAttribute((const void*)ffn_wide_kernel<PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return hipFuncSetAttribute((const void*)ffn_wide_kernel<PROJ, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }));
     ProfScope ps(PROJ ? PK_FFN_PROJ_WIDE : PK_FFN_WIDE, a.M, a.ff, 256, a.M_dev, s, a.m_off);
-    hipLaunchKernelGGL((ffn_wide_kernel<PROJ>), dim3((unsigned)((a.M + 15) / 16)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((ffn_wide_kernel<PROJ, PRE>), dim3((unsigned)((a.M + 15) / 16)), dim3(512), lds, s, a);
     CONE_LAUNCH_CHECK();
     return 0;
 }
@@ -512,6 +559,19 @@ int launch_proj_ffn_wide(const float* A, int lda, const float* Wo, const float* 
     return launch_wide_t<true>(a, s);
 }
 
+// The pre-norm tail (ffn.hip's PRE) in the wide form: OUT = x1 + FFN(LN_p(x1)), x1 = R + A Wo^T + bo; OUT2 (may be null) = LN(OUT).
+int launch_proj_ffn_prenorm_wide(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
+                                 const float* pb, const float* W1, const float* b1, const float* W2, const float* b2, float* OUT,
+                                 int ldo, const float* n2g, const float* n2b, float* OUT2, int ldo2, int M, const int* M_dev, int ff,
+                                 hipStream_t s, const int* r_idx, const float* R2) {
+    CONE_REQUIRE(ffn_wide_supported(ff) && (!OUT2 || (n2g && n2b)) && (!r_idx || R2), "pre-norm wide tail: bad arguments");
+    FfnWideArgs a{};
+    a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb; a.r_idx = r_idx; a.R2 = R2;
+    a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = n2g ? n2g : pg; a.ln_b = n2b ? n2b : pb;
+    a.OUT = OUT; a.ldo = ldo; a.OUT2 = OUT2; a.ldo2 = ldo2; a.M = M; a.M_dev = M_dev; a.ff = ff;
+    return launch_wide_t<true, true>(a, s);
+}
+
 // ---- the spread form (above): scratch = XP | X1 | YG (16 groups x 16 rows x 256) + HG (16 groups x ff / 16 tiles of 256)
 size_t ffn_spread_scratch_floats(int ff) { return (size_t)FS_MAX_GROUPS * (3 * 16 * 256 + (size_t)(ff >> 4) * 256); }
 bool ffn_spread_supported(int M, int ff) {
@@ -520,23 +580,29 @@ bool ffn_spread_supported(int M, int ff) {
 int launch_proj_ffn_spread(const float* A, int lda, const float* Wo, const float* bo, const float* R, int ldr, const float* pg,
                            const float* pb, const float* W1, const float* b1, const float* W2, const float* b2,
                            const float* ln_g, const float* ln_b, float* OUT, int ldo, int M, int ff, float* scratch,
-                           hipStream_t s, const int* M_dev, const int* r_idx, const float* R2) {
+                           hipStream_t s, const int* M_dev, const int* r_idx, const float* R2, bool pre, float* OUT2, int ldo2) {
     CONE_REQUIRE(ffn_spread_supported(M, ff) && scratch, "spread layer tail: unsupported size M=%d ff=%d", M, ff);
     CONE_REQUIRE(!r_idx || R2, "spread layer tail: a gathered residual needs both source matrices");
     CONE_REQUIRE(lda % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, "spread layer tail: row strides must be multiples of 4");
     FfnWideArgs a{};
     a.A = A; a.lda = lda; a.Wo = Wo; a.bo = bo; a.R = R; a.ldr = ldr; a.pg = pg; a.pb = pb;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b;
-    a.OUT = OUT; a.ldo = ldo; a.M = M; a.ff = ff; a.M_dev = M_dev; a.r_idx = r_idx; a.R2 = R2;
+    a.OUT = OUT; a.ldo = ldo; a.M = M; a.ff = ff; a.M_dev = M_dev; a.r_idx = r_idx; a.R2 = R2; a.OUT2 = OUT2; a.ldo2 = ldo2;
     const int groups = (M + 15) / 16, nc = ff >> 4;
     FfnSpreadBufs b;
     b.XP = scratch; b.X1 = b.XP + (size_t)FS_MAX_GROUPS * 16 * 256; b.YG = b.X1 + (size_t)FS_MAX_GROUPS * 16 * 256;
     b.HG = b.YG + (size_t)FS_MAX_GROUPS * 16 * 256;
     ProfScope ps(PK_FFN_PROJ_WIDE, M, ff, 256, M_dev, s, 0);
     hipLaunchKernelGGL(fs_proj_kernel, dim3(16, groups), dim3(64), 0, s, a, b);
-    hipLaunchKernelGGL(fs_g1_kernel, dim3(nc, groups), dim3(64), 0, s, a, b);
-    hipLaunchKernelGGL(fs_g2_kernel, dim3(16, groups), dim3(64), 0, s, a, b);
-    hipLaunchKernelGGL(fs_ln_kernel, dim3(groups), dim3(64), 0, s, a, b);
+    if (pre) {
+        hipLaunchKernelGGL(fs_g1_kernel<true>, dim3(nc, groups), dim3(64), 0, s, a, b);
+        hipLaunchKernelGGL(fs_g2_kernel<true>, dim3(16, groups), dim3(64), 0, s, a, b);
+        hipLaunchKernelGGL(fs_ln_kernel<true>, dim3(groups), dim3(64), 0, s, a, b);
+    } else {
+        hipLaunchKernelGGL(fs_g1_kernel<false>, dim3(nc, groups), dim3(64), 0, s, a, b);
+        hipLaunchKernelGGL(fs_g2_kernel<false>, dim3(16, groups), dim3(64), 0, s, a, b);
+        hipLaunchKernelGGL(fs_ln_kernel<false>, dim3(groups), dim3(64), 0, s, a, b);
+    }
     CONE_LAUNCH_CHECK();
     return 0;
 }

@@ -2689,14 +2689,18 @@ def test_hip_graph_replay_with_two_sources_and_text_positions():
     assert strip(got2) == strip(ref2)
 
 
-@pytest.mark.parametrize("B", [1, 3, 9, 20, 204, 205])
-def test_spread_layer_tail_is_bit_identical(B):
+@pytest.mark.parametrize("B,pre_norm", [(1, 0), (3, 0), (9, 0), (20, 0), (204, 0), (205, 0),
+                                        (1, 1), (9, 1), (20, 1), (100, 1), (205, 1)])
+def test_spread_layer_tail_is_bit_identical(B, pre_norm):
     """Up to 64 row groups (1 024 rows: the decoder slot rows of up to 204 windows, the token rows of up to 9) run the projecting
     layer tail as four launches over single-wave workgroups (ffn_wide.hip: fs_*_kernel) instead of one CU per group walking the
     whole block: every output element by the same fma chain -- the same bits as the wide form, which has the bits of the
     persistent form (test_layer_tail_forms_are_bit_identical).  B <= 9: encoder tails too (device-side row count, the first
-    layer's gathered residual); B = 205: 1 025 slot rows, past the threshold, both runs take the wide form."""
-    model, opt, _ = get_model("ego4d", 0)
+    layer's gathered residual); B = 205: 1 025 slot rows, past the threshold, both runs take the wide form.  pre_norm: the
+    pre-norm tail (the un-normalised stream out, the next consumer's LayerNorm as a second output) in its spread and wide forms
+    against the persistent 128-row kernel, the only form with the option off (B = 100: 11 000 token rows wide, 500 slot rows
+    spread; B = 205: the encoder tails persistent in both runs, the decoder tails wide)."""
+    model, opt, _ = get_model("ego4d", 4 if pre_norm else 0, **(dict(pre_norm=True) if pre_norm else {}))
     rng = np.random.default_rng(5 + B)
     lens_v = [int(x) for x in rng.integers(1, opt.max_v_l + 1, B)]
     lens_q = [int(x) for x in rng.integers(1, opt.max_q_l + 1, B)]
