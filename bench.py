@@ -434,7 +434,8 @@ def reference_batch_tensors(model, store, opt, n_batch_queries=None):
     src_vid = (store.vid_raw[rows] * vmask[..., None]).contiguous()
     # a store with two visual sources (dataloader :134-158): the model input is cut from the motion arena, the matching's
     # from the appearance arena; one source: the same tensor serves both, as in the reference's collate
-    src_mot = src_vid if getattr(store, "mot_raw", None) is None else (store.mot_raw[rows] * vmask[..., None]).contiguous()
+    # (the reference's motion reader hands out L2-normalised rows, :284-292: store.motion_rows())
+    src_mot = src_vid if getattr(store, "mot_raw", None) is None else (store.motion_rows()[rows] * vmask[..., None]).contiguous()
     src_txt = tok[(trow0[:, None] + ar_q).clamp_(max=tok.shape[0] - 1)] * tmask[..., None]
     return dict(src_txt=src_txt.contiguous(), src_txt_mask=tmask.float(), src_vid_motion=src_mot,
                 src_vid_motion_mask=vmask.float(), src_vid_appear=src_vid,

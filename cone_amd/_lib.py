@@ -52,6 +52,7 @@ class Weights(C.Structure):
         ("pos_dim_t", C.c_void_p),
         ("txt_pos_embed", C.c_void_p), ("txt_pos_rows", C.c_int32), ("txt_pos_ln", LNorm),      # ABI 5: --use_txt_pos (NULL: off)
         ("pre_norm", C.c_int32), ("enc_norm", LNorm),                                            # ABI 5: --pre_norm (0: post-norm)
+        ("table_max_v_l", C.c_int32),                                                            # ABI 8: tables for <= this many clips (0: 255)
     ]
 
 
@@ -183,7 +184,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.cone_abi_version() != 7:
+    if lib.cone_abi_version() != 8:
         raise ConeHipError("libcone_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

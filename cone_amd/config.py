@@ -41,6 +41,7 @@ EVAL_DEFAULTS = dict(
     nms_thd=-1.0, max_before_nms=200, max_after_nms=5, no_sort_results=False,
     eval_split_name="val", eval_modality="both", save_all=False, debug=False,
     num_workers=4, data_ratio=1.0, results_dir=".", device=0,
+    no_norm_vfeat=False, no_norm_tfeat=False,       # cone/config.py:80-81 -> normalize_v / normalize_t of the datasets (cone/inference.py:581-582)
 )
 
 

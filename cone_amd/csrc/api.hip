@@ -55,7 +55,7 @@ struct cone_model {
     // self-attention in_proj (ONE N = 768 GEMM on tgt, the table as a row-periodic residual) and a (nq, 256) table
     // qe W_q^T + b_q for the cross-attention query projection -- the same move as the encoder's position tables
     float* dec_sa_tab[CONE_MAX_LAYERS] = {}; float* dec_ca_tab[CONE_MAX_LAYERS] = {};
-    // derived (ABI 6): the static position tables of this checkpoint for windows of up to CONE_TABLE_MAX_V_L clips (row
+    // derived (ABI 6; sized by cone_weights.table_max_v_l since ABI 8): the static position tables of this checkpoint (row
     // lv (lv - 1) / 2 + p: the same rows whatever the bound) -- every entry point runs the table path without the caller
     // building anything (cone_forward_windows, cone_forward_packed without a cone_layer0 or with caches only)
     float* tab_arena = nullptr; const float* tab_pos_rows = nullptr; const float* tab_pos_qk = nullptr; int tab_max_v_l = 0;
@@ -291,11 +291,13 @@ static int build_model(const cone_weights* w, cone_model** out) {
         delete m;
         return CONE_E_HIP;
     }
-    {   // the handle's own position tables (19 MB + 38 MB per encoder layer at 192 clips)
-        const size_t rows = (size_t)pos_table_rows(CONE_TABLE_MAX_V_L);
+    {   // the handle's own position tables, for the window lengths this checkpoint is built for (ABI 8: cone_weights.
+        // table_max_v_l; rows (256 + 512 per encoder layer) floats each: 5 MB at 90 clips, 167 MB at 255 with two layers)
+        const int tab_l = (w->table_max_v_l >= 1 && w->table_max_v_l <= CONE_TABLE_MAX_V_L) ? w->table_max_v_l : CONE_TABLE_MAX_V_L;
+        const size_t rows = (size_t)pos_table_rows(tab_l);
         e = hipMalloc((void**)&m->tab_arena, rows * (256 + 512 * (size_t)m->n_enc) * sizeof(float));
         int rc = e == hipSuccess ? 0 : CONE_E_HIP;
-        if (rc == 0) rc = build_pos_tables(m, CONE_TABLE_MAX_V_L, m->tab_arena, m->tab_arena + rows * 256, nullptr);
+        if (rc == 0) rc = build_pos_tables(m, tab_l, m->tab_arena, m->tab_arena + rows * 256, nullptr);
         if (rc != 0 || hipDeviceSynchronize() != hipSuccess) {
             if (e != hipSuccess) set_error("model_create: hipMalloc of the position tables failed: %s", hipGetErrorString(e));
             if (m->tab_arena) (void)hipFree(m->tab_arena);
@@ -304,7 +306,7 @@ static int build_model(const cone_weights* w, cone_model** out) {
             delete m;
             return CONE_E_HIP;
         }
-        m->tab_pos_rows = m->tab_arena; m->tab_pos_qk = m->tab_arena + rows * 256; m->tab_max_v_l = CONE_TABLE_MAX_V_L;
+        m->tab_pos_rows = m->tab_arena; m->tab_pos_qk = m->tab_arena + rows * 256; m->tab_max_v_l = tab_l;
     }
     *out = m;
     return 0;

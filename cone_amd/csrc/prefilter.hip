@@ -812,17 +812,21 @@ __global__ __launch_bounds__(256) void topk_seg_kernel(const float* __restrict__
     if (n <= 1024) {
         // a short row (an Ego4D video: ~22 windows): the stable descending RANK of every window by counting -- rank = #{greater}
         // + #{equal with a lower index}, window j goes to slot rank if rank < k -- one pass and one barrier instead of k selection
-        // passes with three barriers each (23 -> 5 us for one query; the same list: the order is a total one)
+        // passes with three barriers each (23 -> 5 us for one query; the same list: the order is a total one).  NaN scores
+        // (an all-zero adapted clip row: cone/inference.py:258 divides by an un-eps'd norm) are ordered like torch.sort orders
+        // them -- ahead of every number, equal among themselves -- so the ranks stay a permutation and every slot is written
         __shared__ float s_row[1024];
         for (int j = tid; j < n; j += 256) s_row[j] = row[j];
         for (int p = n + tid; p < k; p += 256) idx[(size_t)q * k + p] = -1;        // fewer windows than k: pad with -1
         __syncthreads();
         for (int j = tid; j < n; j += 256) {
             const float v = s_row[j];
+            const bool v_nan = v != v;
             int rank = 0;
             for (int i = 0; i < n; ++i) {           // (every thread reads the same address: LDS broadcast)
                 const float x = s_row[i];
-                rank += (x > v) || (x == v && i < j);
+                const bool x_nan = x != x;
+                rank += (x > v) || (x_nan && !v_nan) || ((x == v || (x_nan && v_nan)) && i < j);
             }
             if (rank < k) idx[(size_t)q * k + rank] = j;
         }

@@ -57,18 +57,23 @@ class FeatureStore:
     StartEndDataset of cone/ego4d_mad_dataloader.py for the eval path)."""
 
     def __init__(self, opt, annotations, video_feats, query_feats, device=None, tok_normalized=False,
-                 cls_normalized=False, motion_feats=None):
+                 cls_normalized=False, motion_feats=None, mot_normalized=False):
         """``video_feats``: clip_id -> RAW (ctx_l, dv) features (hazard H2: the window model sees them un-normalised);
         ``motion_feats`` (optional): clip_id -> RAW (ctx_l, dv_motion) features of a SECOND visual source -- the reference's
         ``motion_feat_dir`` when it is not ``appearance_feat_dir`` (cone/ego4d_mad_dataloader.py:63-81, 94-95): the window
         model (Moment-DETR) reads the motion features, the pre-filter and the proposal matching the appearance features
-        (``video_feats``); the same clips, so the same number of rows per video.  None = one source for both (every shipped script);
+        (``video_feats``); the same clips, so the same number of rows per video.  None = one source for both (every shipped script).
+        Unlike the appearance reader, the reference's motion reader hands the window model L2-NORMALISED rows
+        (``_get_video_motion_feat_by_vid``, :284-292: ``x / (|x| + 1e-5)`` whenever ``normalize_v``): the arena ``mot_raw`` keeps what
+        it was given, ``motion_rows()`` is what the window model reads (normalised on the device per step, like the text tokens);
+        ``mot_normalized`` = the rows already went through that reader (``from_datasets``);
         ``query_feats``: query_id -> {token_features, cls_features | eot_features}.  ``tok_normalized`` /
         ``cls_normalized``: the text side already went through the reference's ``l2_normalize_np_array`` on the
         host (features taken from the reference's dataset objects, ``from_datasets``) and must not be normalised
         a second time."""
         self.opt = opt
         self.tok_normalized, self.cls_normalized = bool(tok_normalized), bool(cls_normalized)
+        self.mot_normalized = bool(mot_normalized)
         self.ann = AnnList(annotations)
         if opt.data_ratio != 1:
             self.ann = self.ann[:int(len(self.ann) * opt.data_ratio)]   # dataloader :116-121
@@ -117,6 +122,7 @@ class FeatureStore:
         sub = cls.__new__(cls)
         sub.opt, sub.device = store.opt, store.device
         sub.tok_normalized, sub.cls_normalized = store.tok_normalized, store.cls_normalized
+        sub.mot_normalized = store.mot_normalized
         sub.q_base, sub.nq_split = store.q_base + lo, store.nq_split
         sub.max_tok_len = store.max_tok_len
         sub.ann = store.ann[lo:hi]
@@ -153,6 +159,18 @@ class FeatureStore:
             v = views[(lo, hi)] = FeatureStore.subset(self, lo, hi)
             v._arenas = arenas
         return v
+
+    def motion_rows(self, r0=0, r1=None):
+        """Arena rows [r0, r1) as the WINDOW MODEL reads them (cone/ego4d_mad_dataloader.py:134-137, 150): one source -- the raw
+        appearance rows (hazard H2); two sources -- the motion rows, L2-normalised with the reference's eps (its motion
+        reader returns the normalised array, :284-292) unless they already are or ``--no_norm_vfeat`` is given."""
+        r1 = int(self.vid_raw.shape[0]) if r1 is None else r1
+        if self.mot_raw is None:
+            return self.vid_raw[r0:r1]
+        rows = self.mot_raw[r0:r1]
+        if self.mot_normalized or getattr(self.opt, "no_norm_vfeat", False):
+            return rows
+        return ops.l2_normalize(rows, 1e-5)
 
     def index_tensors(self):
         """Static per-query index metadata on the device (depends on the annotation file only)."""
@@ -264,7 +282,8 @@ class FeatureStore:
             tok, cq = intra._get_query_feat_by_qid(r["query_id"])
             qf[r["query_id"]] = dict(token_features=to_np(tok), cls_features=to_np(cq))
         st = cls(SimpleNamespace(**dict(vars(opt), data_ratio=1)), ann, vf, qf, device=device,
-                 tok_normalized=bool(getattr(intra, "normalize_t", True)), cls_normalized=True, motion_feats=mf)
+                 tok_normalized=bool(getattr(intra, "normalize_t", True)), cls_normalized=True, motion_feats=mf,
+                 mot_normalized=bool(getattr(intra, "normalize_v", True)))      # motion_videofeat: the reader's normalised rows
         st.opt = opt
         return st
 
@@ -280,7 +299,7 @@ class FeatureStore:
         if self.mot_raw is not None:
             arrs["mot_raw"] = self.mot_raw.cpu().numpy()     # (an optional fourth arena: files without it read as before)
         head = dict(version=1, ann=self.ann, clip_ids=self.clip_ids, ctx_l=self.ctx_l, tok_len=self.tok_len,
-                    arrays={})
+                    normalized=dict(tok=self.tok_normalized, cls=self.cls_normalized, mot=self.mot_normalized), arrays={})
         off = 0
         for k, a in arrs.items():
             head["arrays"][k] = dict(offset=off, shape=list(a.shape))
@@ -309,7 +328,9 @@ class FeatureStore:
               for k, v in head["arrays"].items()}
         st = cls.__new__(cls)
         st.opt = opt
-        st.tok_normalized = st.cls_normalized = False
+        nz = head.get("normalized", {})     # (files written before the flags: raw arenas)
+        st.tok_normalized, st.cls_normalized = bool(nz.get("tok", False)), bool(nz.get("cls", False))
+        st.mot_normalized = bool(nz.get("mot", False))
         dev = device or torch.device("cuda", torch.cuda.current_device())
         st.device = dev
         st.ann = AnnList(head["ann"])
@@ -504,7 +525,7 @@ def project_video(model, store: FeatureStore, row_range=None, ws=None):
     tables.  ``row_range`` = (r0, r1) restricts it to arena rows [r0, r1) (a rank that only runs the windows of
     some videos); ``vid_base`` is what window rows must be rebased by."""
     r0, r1 = row_range if row_range is not None else (0, int(store.vid_raw.shape[0]))
-    vproj = model.project(0, (store.vid_raw if store.mot_raw is None else store.mot_raw)[r0:r1], ws=ws)   # the MOTION source
+    vproj = model.project(0, store.motion_rows(r0, r1), ws=ws)   # the MOTION source (normalised when it is a second one)
     out = dict(vproj=vproj, vid_base=r0)
     if getattr(store.opt, "layer0_cache", True):
         out["l0_vid"] = model.layer0_rows(vproj, ws=ws)      # (the position tables are the model handle's own)

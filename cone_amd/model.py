@@ -116,6 +116,9 @@ class CONE:
         w.enc_layers, w.dec_layers, w.num_queries = a.enc_layers, a.dec_layers, a.num_queries
         w.n_input_proj, w.t_dim, w.v_dim, w.v_motion_dim = a.n_input_proj, a.t_feat_dim, a.v_appear_feat_dim, a.v_motion_feat_dim
         w.has_adapter = 1 if a.adapter_module == "linear" else 0
+        # ABI 8: the handle's position tables cover windows of up to max_v_l clips (build_model's own parameter, cone/model.py:
+        # 468-486); an args object without it gets the 255-clip tables.  Longer windows than that still run (general path)
+        w.table_max_v_l = min(int(getattr(a, "max_v_l", 0) or 0), 255)
         p = lambda k: sd[k].data_ptr()
 
         def lin(dst, prefix):
@@ -188,12 +191,9 @@ class CONE:
         """Prefix mask (utils/tensor_utils.py:50-52: 1 = valid) -> int32 valid lengths (cone_mask_lengths: one launch).  The
         reference's collate (pad_sequences_1d) only ever produces PREFIX masks and the packed kernels take lengths; a mask with
         holes is not representable.  ``CONE_AMD_CHECK_MASKS=1`` verifies it (one device round trip per call) and raises
-        ValueError.  The lengths of the last mask are kept: ``forward_clip_matching`` is called with the very mask tensor
-        ``forward`` just saw (cone/inference.py:45-50)."""
-        cache = self.__dict__.setdefault("_len_cache", [])          # [(mask tensor, its version, lengths)], the last two masks
-        for t, ver, n in cache:
-            if t is mask and ver == mask._version:                   # the SAME tensor object, not modified since
-                return n
+        ValueError.  Nothing is cached per mask tensor (one ~3 us launch per call): an identity / version-counter key goes
+        stale under writes that bypass the counter (``.data.copy_``, DLPack / numpy aliases) and does not exist for inference
+        tensors (``torch.inference_mode()``)."""
         m = mask.to(torch.float32).contiguous()
         n = torch.empty(m.shape[0], dtype=torch.int32, device=m.device)
         _lib.check(_lib.load().cone_mask_lengths(_lib.ptr(m), m.shape[0], m.shape[1], _lib.ptr(n), _lib.stream()))
@@ -201,8 +201,6 @@ class CONE:
             ar = torch.arange(m.shape[1], device=m.device)[None]
             if not bool(((ar < n[:, None]) == (m != 0)).all()):
                 raise ValueError("CONE.forward takes prefix masks (1 ... 1 0 ... 0), as the reference's collate produces")
-        cache.insert(0, (mask, mask._version, n))
-        del cache[2:]
         return n
 
     # ---- CONE.forward (cone/model.py:82-128) ----------------------------------------------------

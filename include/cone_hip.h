@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CONE_HIP_ABI_VERSION 7
+#define CONE_HIP_ABI_VERSION 8
 
 #define CONE_E_INVALID (-1)  /* bad argument / unsupported shape */
 #define CONE_E_HIP (-2)      /* a HIP runtime call failed        */
@@ -90,6 +90,12 @@ typedef struct {
      * then.  0 (every shipped configuration) = post-norm.  (ABI 6) such a model runs the table path as well: the fused layer
      * tail in its pre-norm form, first-layer row caches of in_proj(norm1(row)), the folded decoder cross-attention. */
     int32_t pre_norm; cone_ln_w enc_norm;
+    /* (ABI 8) The longest window, in clips, this checkpoint is run on = max_v_l of build_model (cone/model.py:468-486,
+     * WINDOW_LENGTH of the reference's scripts): cone_model_create builds the handle's position tables for windows of up to
+     * this many clips (row lv (lv - 1) / 2 + p: a shorter bound is a prefix of a longer one; 4 095 rows = 5 MB for 90 clips
+     * with two encoder layers, 32 641 rows = 167 MB for 255).  0 = CONE_TABLE_MAX_V_L.  Longer windows still run, on the
+     * general path (x + pos materialised), or on tables the caller brings (cone_pos_tables, cone_layer0). */
+    int32_t table_max_v_l;
 } cone_weights;
 
 const char* cone_last_error(void);

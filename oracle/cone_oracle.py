@@ -548,13 +548,21 @@ def prefilter(sd, opt, ann, video_feats, query_feats):
 def build_batch(opt, ann_rows, video_feats, query_feats, ranks, motion_feats=None):
     """A5: eval branch of StartEndDataset.__getitem__ + start_end_collate
     (cone/ego4d_mad_dataloader.py:144-159, 229-234, 305-358).  Model-side video features
-    are the RAW ones (H2).  ``motion_feats``: the second visual source (:134-137, 150-158): the window model's
-    input is sliced from it, the matching's from the appearance features -- both with the appearance length."""
+    are the RAW ones (H2).  ``motion_feats``: the RAW rows of the second visual source (:134-137, 150-158): the window
+    model's input is sliced from it, the matching's from the appearance features -- both with the appearance length.
+    Unlike the appearance reader (whose normalised copy is dropped: H2), the motion reader ``_get_video_motion_feat_by_vid``
+    (:284-292) RETURNS its L2-normalised rows (``x / (|x| + 1e-5)``) whenever ``normalize_v`` is set (= not
+    ``opt.no_norm_vfeat``, cone/inference.py:581), so that is what a two-source window model sees.  (With
+    ``--no_norm_vfeat`` the reference's reader raises NameError; the raw rows are used here.)"""
     metas, vids, mots, txts, clss = [], [], [], [], []
+    norm_v = not getattr(opt, "no_norm_vfeat", False)
     for row in ann_rows:
         tok, cls = prepare_query_inputs(opt, query_feats[row["query_id"]])
         v = torch.from_numpy(np.asarray(video_feats[row["clip_id"]], dtype=np.float32))
-        mo = v if motion_feats is None else torch.from_numpy(np.asarray(motion_feats[row["clip_id"]], dtype=np.float32))
+        mo = v
+        if motion_feats is not None:
+            m = np.asarray(motion_feats[row["clip_id"]], dtype=np.float32)
+            mo = torch.from_numpy(l2_normalize_np(m).astype(np.float32) if norm_v else m)
         ctx_l = v.shape[0]
         for w in ranks[row["query_id"]][:opt.topk_window]:
             s, e = window_bounds(w, ctx_l, opt.max_v_l)

@@ -102,6 +102,18 @@ class MemPre(PreFilteringDataset):
         return l2_normalize_np_array(self._q[qid]["cls_features"])
 
 
+class MemTxn:
+    """An LMDB read transaction over in-memory arrays: ``get(key)`` -> the np.savez blob the reference's readers parse."""
+
+    def __init__(self, entries):
+        self._e = entries
+
+    def get(self, key):
+        buf = io.BytesIO()
+        np.savez(buf, **self._e[bytes(key).decode()])
+        return buf.getvalue()
+
+
 class MemSE(StartEndDataset):
     """StartEndDataset (eval branch) with the LMDB readers replaced by dict lookups."""
 
@@ -117,8 +129,13 @@ class MemSE(StartEndDataset):
         self._q = query_feats
         self.videofeat = {k: torch.from_numpy(v) for k, v in video_feats.items()}  # RAW (H2)
         if motion_feats is not None:        # a second visual source (the reference's motion_feat_dir != appearance_feat_dir)
+            # through the reference's OWN reader (_get_video_motion_feat_by_vid, dataloader :284-292): unlike the appearance
+            # reader (H2) it hands back the L2-NORMALISED rows whenever normalize_v is set -- the motion LMDB is an in-memory
+            # transaction of np.savez blobs here, nothing else is replaced
             self.same_visual_path = False
-            self.motion_videofeat = {k: torch.from_numpy(v) for k, v in motion_feats.items()}
+            self.normalize_v = not opt.no_norm_vfeat
+            self.motion_visual_txn = MemTxn({k: {"features": v} for k, v in motion_feats.items()})
+            self.motion_videofeat = {k: self._get_video_motion_feat_by_vid(k) for k in motion_feats}
 
     def _get_query_feat_by_qid(self, qid):
         q = self._q[qid]

@@ -1230,8 +1230,21 @@ def test_two_visual_sources_pipeline_matches_oracle():
             agree += 1
     record_measured("two_sources_pipeline_vs_oracle", queries=len(f1), kept_moments_agree=agree, worst_proposal_score=float(worst))
     assert worst <= 2e-4 and agree >= PIPELINE_FLOOR * len(f1), (worst, agree)
+    # what the window model reads is the output of the reference's MOTION reader: x / (|x| + 1e-5) (dataloader :284-292; the
+    # appearance reader hands out raw rows, hazard H2) -- normalised on the device per step; a store built from rows that
+    # already went through that reader (from_datasets) takes them as they are
+    ref_rows = np.concatenate([O.l2_normalize_np(mf[c]) for c in store.clip_ids]).astype(np.float32)
+    assert np.abs(store.motion_rows().cpu().numpy() - ref_rows).max() < 1e-6
+    assert float(store.mot_raw.norm(dim=1).min()) > 2.0                   # (the arena itself keeps the raw rows)
+    pre = inf.FeatureStore(opt, ann, vf, qf, motion_feats={c: O.l2_normalize_np(m).astype(np.float32) for c, m in mf.items()},
+                           mot_normalized=True)
+    assert pre.motion_rows().data_ptr() == pre.mot_raw.data_ptr()
+    mine_pre, _ = inf.compute_mr_results(model, pre, opt, info["win_idx"])
+    assert max(np.abs(np.array(a["pred_relevant_windows"]) - np.array(b["pred_relevant_windows"]))[:, 2:].max()
+               for a, b in zip(mine, mine_pre)) <= 1e-4
     inputs, wt1, sub1 = B_.reference_batch_tensors(model, store, opt)
     assert inputs["src_vid_motion"].shape[2] == 256 and inputs["src_vid_appear"].shape[2] == 512
+    assert abs(float(inputs["src_vid_motion"][0, 0].norm()) - 1.0) < 1e-4
     o1 = model(**{k: inputs[k] for k in ("src_txt", "src_txt_mask", "src_vid_motion", "src_vid_motion_mask")})
     mt1 = model.forward_clip_matching(inputs["src_cls_txt"], inputs["src_vid_appear"], inputs["src_vid_motion_mask"],
                                       proposal=o1["pred_spans"])

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in cone_hip.h but not exported"
     assert set(declared) == set(_lib.EXPORTS), set(declared) ^ set(_lib.EXPORTS)
-    assert lib.cone_abi_version() == 7
+    assert lib.cone_abi_version() == 8
     assert lib.cone_num_windows(901, 90) == 22 and lib.cone_num_windows(1250, 125) == 22
 
 
@@ -258,13 +258,24 @@ def test_feature_store_with_two_visual_sources(tmp_path, monkeypatch):
     for k in ("vid_raw", "mot_raw", "tok_raw", "cls_raw"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     # the reference's dataset objects (eval_epoch(model, inter_ds, intra_ds, ...))
+    # -- whose motion table holds what its reader returns: the L2-NORMALISED rows (_get_video_motion_feat_by_vid, :284-292,
+    # unlike the appearance reader: hazard H2), so the store must not normalise them a second time
     ds = RefLikeDatasets(base, ann, vf, qf)
-    ds.same_visual_path, ds.motion_videofeat = False, {c: torch.from_numpy(m) for c, m in mf.items()}
+    ds.same_visual_path, ds.normalize_v = False, True
+    ds.motion_videofeat = {c: torch.from_numpy(O.l2_normalize_np(m).astype(np.float32)) for c, m in mf.items()}
     c = FeatureStore.from_datasets(base, ds, ds, device=cpu)
-    assert torch.equal(c.mot_raw, a.mot_raw) and torch.equal(c.vid_raw, a.vid_raw)
-    # the packed arena file carries the fourth arena; files without it load as before
+    assert c.mot_normalized and not a.mot_normalized and not b.mot_normalized
+    assert torch.equal(c.mot_raw, torch.cat([ds.motion_videofeat[k] for k in a.clip_ids])) and torch.equal(c.vid_raw, a.vid_raw)
+    assert c.motion_rows(3, 40).data_ptr() == c.mot_raw[3:40].data_ptr()           # taken as they are
+    nn = FeatureStore(make_opt("ego4d", v_motion_feat_dim=128, no_norm_vfeat=True), ann, vf, qf, device=cpu, motion_feats=mf)
+    assert nn.motion_rows(3, 40).data_ptr() == nn.mot_raw[3:40].data_ptr()         # --no_norm_vfeat: the raw rows
+    one_src = FeatureStore(base, ann, vf, qf, device=cpu)
+    assert one_src.motion_rows(2, 9).data_ptr() == one_src.vid_raw[2:9].data_ptr()    # one source: the raw appearance rows
+    # the packed arena file carries the fourth arena and the flags; files without it load as before
     d = FeatureStore.from_packed(base, a.save_packed(str(tmp_path / "two.conefs")), device=cpu)
-    assert torch.equal(d.mot_raw, a.mot_raw) and torch.equal(d.vid_raw, a.vid_raw)
+    assert torch.equal(d.mot_raw, a.mot_raw) and torch.equal(d.vid_raw, a.vid_raw) and not d.mot_normalized
+    e = FeatureStore.from_packed(base, c.save_packed(str(tmp_path / "two_n.conefs")), device=cpu)
+    assert e.mot_normalized and e.tok_normalized and e.cls_normalized and torch.equal(e.mot_raw, c.mot_raw)
     one = FeatureStore(base, ann, vf, qf, device=cpu)
     assert FeatureStore.from_packed(base, one.save_packed(str(tmp_path / "one.conefs")), device=cpu).mot_raw is None
     short = dict(mf)
