@@ -292,7 +292,7 @@ static int build_model(const cone_weights* w, cone_model** out) {
         return CONE_E_HIP;
     }
     {   // the handle's own position tables, for the window lengths this checkpoint is built for (ABI 8: cone_weights.
-        // table_max_v_l; rows (256 + 512 per encoder layer) floats each: 5 MB at 90 clips, 167 MB at 255 with two layers)
+        // table_max_v_l; rows (256 + 512 per encoder layer) floats each: 21 MB at 90 clips, 167 MB at 255 with two layers)
         const int tab_l = (w->table_max_v_l >= 1 && w->table_max_v_l <= CONE_TABLE_MAX_V_L) ? w->table_max_v_l : CONE_TABLE_MAX_V_L;
         const size_t rows = (size_t)pos_table_rows(tab_l);
         e = hipMalloc((void**)&m->tab_arena, rows * (256 + 512 * (size_t)m->n_enc) * sizeof(float));

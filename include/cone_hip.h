@@ -92,7 +92,7 @@ typedef struct {
     int32_t pre_norm; cone_ln_w enc_norm;
     /* (ABI 8) The longest window, in clips, this checkpoint is run on = max_v_l of build_model (cone/model.py:468-486,
      * WINDOW_LENGTH of the reference's scripts): cone_model_create builds the handle's position tables for windows of up to
-     * this many clips (row lv (lv - 1) / 2 + p: a shorter bound is a prefix of a longer one; 4 095 rows = 5 MB for 90 clips
+     * this many clips (row lv (lv - 1) / 2 + p: a shorter bound is a prefix of a longer one; 4 096 rows = 21 MB for 90 clips
      * with two encoder layers, 32 641 rows = 167 MB for 255).  0 = CONE_TABLE_MAX_V_L.  Longer windows still run, on the
      * general path (x + pos materialised), or on tables the caller brings (cone_pos_tables, cone_layer0). */
     int32_t table_max_v_l;

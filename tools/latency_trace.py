@@ -2,7 +2,7 @@
 """The launch sequence of ONE single-query step (BASELINE configs[0]) out of a rocprofv3 rocpd database:
     rocprofv3 --kernel-trace -d out -o t -- python3 tools/latency_bench.py 1x1
     python3 tools/latency_trace.py out/t_results.db
-prints the kernels of the last step in launch order with start offsets, durations and the idle gap ahead of each."""
+prints the kernels of the last step (--full: from stage A's first launch) in launch order with start offsets, durations and the idle gap ahead of each."""
 import sqlite3
 import sys
 
@@ -17,6 +17,8 @@ starts = [j for j, n in enumerate(names) if "l2norm_kernel" in n]
 j = starts[-1]
 while j - 1 in starts or (j - 2 in starts):
     j -= 1 if j - 1 in starts else 2
+if "--full" in sys.argv:        # the WHOLE step: stage A too (its head is the clip band's l2norm, two l2norm launches earlier)
+    j = starts[-3]
 sel = list(zip(ev[j:], names[j:]))
 t0 = sel[0][0][0]
 prev_end = t0
