@@ -14,6 +14,26 @@
 
 namespace cone {
 
+// The clip rows are read exactly once per launch: the stream's loads are NON-TEMPORAL (global_load_dwordx4 ... nt).  Measured
+// on one box (tools/ab_variants.sh prefilter.hip, the 12.7 GB MAD-scale video, 1 query): 2.11 ms = 6.0 TB/s with ordinary loads,
+// 1.89 - 1.96 ms = 6.5 - 6.7 TB/s with nt (0.75 -> 0.81 - 0.84 of the 8 TB/s peak): lines that will not be read again no longer
+// displace each other through the L2 / Infinity Cache.  CONE_PF_NT = 0 (the streaming kernels) / CONE_PF_NT_MQ = 0 (the
+// matrix-core kernels for >= 8 queries) restore ordinary loads for an A/B.
+#ifndef CONE_PF_NT
+#define CONE_PF_NT 1
+#endif
+#ifndef CONE_PF_NT_MQ
+#define CONE_PF_NT_MQ 0
+#endif
+__device__ __forceinline__ float4 pf_stream_ld(const float4* p) {
+#if CONE_PF_NT
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *p;
+#endif
+}
+
 // Fused frame scores + window max.  S = int(W/2), so window i = half-blocks i-1 and i (block h = frames [hS, (h+1)S)) plus,
 // when W is odd, the first frame of block i+1: a wave keeps the running max of the half-block it streams in registers and
 // writes ONE value per (query, half-block) -- hm -- and the block's first frame score -- fr; window_combine_kernel takes
@@ -52,7 +72,7 @@ __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restric
                 const int row = min(j0 + r, n - 1);
 #pragma unroll
                 for (int v = 0; v < VPL; ++v)
-                    x[r][v] = reinterpret_cast<const float4*>(base + (size_t)row * DV)[lane + 64 * v];
+                    x[r][v] = pf_stream_ld(reinterpret_cast<const float4*>(base + (size_t)row * DV) + lane + 64 * v);
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
@@ -357,6 +377,13 @@ __global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ sc, 
 typedef float pf4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int pf_swz16(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
+__device__ __forceinline__ pf4 pf_mq_ld(const float* p) {       // a frame's 16-B piece of the once-read stream
+#if CONE_PF_NT_MQ
+    return __builtin_nontemporal_load(reinterpret_cast<const pf4*>(p));
+#else
+    return *reinterpret_cast<const pf4*>(p);
+#endif
+}
 
 constexpr int MQ_NT = 768;     // 12 waves: the one workgroup a CU holds (128 KiB of LDS) runs three waves per SIMD
 
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* _
     const float* fp = vid + min(f0 + li, r_hi - 1) * dv + 4 * lg;
     pf4 cur[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+    for (int s = 0; s < 8; ++s) cur[s] = pf_mq_ld(fp + 16 * s);
     pf4 mx[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) mx[qt] = pf4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* _
             const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
             pf4 nxt[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
+            for (int s = 0; s < 8; ++s) nxt[s] = pf_mq_ld(np + 16 * s);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* 
     pf4 cur[8];
     if (live) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const pf4*>(fp + 16 * s);
+        for (int s = 0; s < 8; ++s) cur[s] = pf_mq_ld(fp + 16 * s);
     }
     pf4 mx[QT];
 #pragma unroll
@@ -644,7 +671,7 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq3_kernel(const float* 
             if (live) {
                 const float* np = c + 1 < nchunk ? fp + 128 * (c + 1) : fp2;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const pf4*>(np + 16 * s);
+                for (int s = 0; s < 8; ++s) nxt[s] = pf_mq_ld(np + 16 * s);
             }
             if (g + 2 < n_steps) stream(g + 2);
             if (live) {
@@ -765,7 +792,7 @@ __global__ __launch_bounds__(256) void frame_score_groups_kernel(const float* __
         for (int r = 0; r < RPW; ++r) {
             const int row = min(r0 + r, ctx_l - 1);
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) x[r][v] = reinterpret_cast<const float4*>(vid + (size_t)row * DV)[lane + 64 * v];
+            for (int v = 0; v < VPL; ++v) x[r][v] = pf_stream_ld(reinterpret_cast<const float4*>(vid + (size_t)row * DV) + lane + 64 * v);
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -872,11 +899,17 @@ __global__ __launch_bounds__(256) void topk_seg_kernel(const float* __restrict__
 template <int VPL>
 static int launch_frame_scores(const float* vid, int64_t ctx_l, int S, int64_t nh, const float* txt, int nq, float* fs,
                                float* hm, float* fr, hipStream_t s) {
-    constexpr int RPW = 4;
+#ifndef CONE_PF_RPW
+#define CONE_PF_RPW 4
+#endif
+#ifndef CONE_PF_WGS_PER_CU
+#define CONE_PF_WGS_PER_CU 8
+#endif
+    constexpr int RPW = CONE_PF_RPW;
     // long videos: one wave per half-block, 8 workgroups per CU grid-striding; short ones: a workgroup per half-block
     const bool wide = nh < 4096;
     int64_t blocks = wide ? nh : (nh + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks > 256 * CONE_PF_WGS_PER_CU) blocks = 256 * CONE_PF_WGS_PER_CU;
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
         const int qg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);

@@ -184,16 +184,19 @@ def test_fused_ffn_matches_float64(M, ff):
                                          (1, 1024, 256, 1), (130, 256, 512, 1 | 2 | 4), (2500, 256, 768, 4), (16, 256, 32, 0),
                                          (20_000, 256, 256, 2 | 4), (33_000, 256, 512, 1 | 2), (33_000, 768, 256, 2),
                                          (100_000, 256, 256, 1 | 2 | 4), (64, 256, 2048, 1), (300, 512, 1536, 2),
-                                         (100, 768, 256, 2), (1000, 256, 256, 1 | 2), (1024, 768, 256, 0), (1025, 768, 256, 0)])
+                                         (100, 768, 256, 2), (1000, 256, 256, 1 | 2), (1024, 768, 256, 0), (1025, 768, 256, 0),
+                                         (20, 256, 768, 1), (100, 256, 512, 1 | 2), (333, 256, 1024, 0), (64, 768, 768, 2),
+                                         (16, 256, 160, 0), (1000, 256, 416, 1), (7, 512, 288, 2), (40, 256, 96, 1)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     """gemm.hip: launches of at most 1 280 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel)
     instead of one 128 x 256 tile per 128 rows, and the rows past the last full round of 128-row tiles (33 000 rows = 258
     tiles on 256 CUs; 100 000 = 782) are launched as that small form too; same fma chains, same per-row epilogue -- the same
     bits as the 128-row tile (forced here with the tile-family test hook), so a row's result does not depend on the size of
     the batch it is computed in.  (K = 2 048: the staged activation slabs would not fit the LDS -- the launcher keeps the
-    128-row tile; K = 1 536: they fit with one workgroup per CU.)  Launches of at most 64 row groups with K <= 256 and no
-    LayerNorm epilogue take the SPREAD form (one wave per 16 x 16 output tile, gemm_rows_spread_kernel): the third run keeps
-    them on the workgroup form (flag 8) -- all three the same bits."""
+    128-row tile; K = 1 536: they fit with one workgroup per CU.)  Launches of at most 64 row groups with K <= 1 024 and no
+    LayerNorm epilogue take the SPREAD form (one wave per 16 x 16 output tile, gemm_rows_spread_kernel; the slabs in passes of
+    128 channels through two LDS buffers -- K = 160 / 288 / 416 / 96: a short last pass): the third run keeps them on the workgroup
+    form (flag 8) -- all three the same bits."""
     from cone_amd import _lib
     dev = _gpu()
     g = torch.Generator().manual_seed(M * 7 + N + K + flags)
@@ -209,7 +212,9 @@ def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
                                       M, N, K, flags | fam, _lib.stream()))
         outs.append(C)
     torch.cuda.synchronize()
-    assert not torch.isnan(outs[0]).any() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1]), ("automatic form vs 128-row tile", maxdiff(outs[0], outs[1].cpu()))
+    assert torch.equal(outs[0], outs[2]), ("automatic form vs workgroup-per-16-rows form", maxdiff(outs[0], outs[2].cpu()))
 
 
 @pytest.mark.parametrize("ff", [1024, 384, 2048, 128])

@@ -726,25 +726,17 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_small_kernel(GemmArgs p) {
 
 // SPREAD form of the small row GEMM for a handful of row groups without a LayerNorm epilogue (the slot-row projections of a
 // small batch: 100 rows x N = 768 is 7 workgroups of the form above, each streaming all of W through one CU): ONE WAVE per
-// (16 rows, 16 columns), the same chain per element -- for kt, for j: acc = mfma(a[j], b[j], acc) -- and the same epilogue
-// arithmetic (+ bias, ReLU, + residual) on the accumulator layout.  The A and W slabs arrive in passes of 8 k-slabs (128
-// channels) through two LDS buffers: K <= 256 is both passes requested at once, a longer K (the text input projection: 768 or
-// 512 channels) keeps two passes in flight ahead of the chain; K <= 1024.
+// (16 rows, 16 columns), its A and W slabs requested at once, the same chain per element -- for kt, for j: acc = mfma(a[j],
+// b[j], acc) -- and the same epilogue arithmetic (+ bias, ReLU, + residual) on the accumulator layout.  K <= 256.
 constexpr int RSP_MAX_GROUPS = 64;
-// ... and at most this many single-wave workgroups in all: every tile re-reads its row group's A slabs and its column tile's
-// W slabs, so beyond ~4 workgroups per CU the workgroup-per-16-rows form wins (tools/gemm_spread_bench.py, N = 768: 5.7 us
-// against 8.2 at 960 tiles, 8.5 against 8.4 at 1 536, 11.7 against 8.7 at 2 736; N = 256 never gets there: 64 groups = 1 024)
-constexpr int RSP_MAX_TILES = 1024;
-constexpr int RSP_PASS = 8;             // k-slabs per pass
 __global__ __launch_bounds__(64) void gemm_rows_spread_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float As[2][RSP_PASS * 256];
-    __shared__ __attribute__((aligned(16))) float Ws[2][RSP_PASS * 256];
+    __shared__ __attribute__((aligned(16))) float As[16 * 256];
+    __shared__ __attribute__((aligned(16))) float Ws[16 * 256];
     int M = p.M;
     if (p.M_dev) { int md = *p.M_dev - p.m_off; M = md < M ? md : M; }
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     if (m0 >= M) return;
     const int nk = p.K / 16;
-    const int np = (nk + RSP_PASS - 1) / RSP_PASS;
     const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
     const int drow = lane >> 2;
     const int dq = ((lane & 3) ^ swz16(drow)) << 2;
@@ -752,7 +744,8 @@ __global__ __launch_bounds__(64) void gemm_rows_spread_kernel(GemmArgs p) {
     const float* __restrict__ asrc = p.A + (size_t)arow * p.lda + dq;
     const float* __restrict__ wsrc = p.W + (size_t)(n0 + drow) * p.ldw + dq;
     const int rdo = li * 16 + ((lg ^ swz16(li)) << 2);
-    // the epilogue's operands first (ordinary loads; vmcnt retires in order: they are behind no slab)
+    for (int kt = 0; kt < nk; ++kt) { GLDS16(asrc + 16 * kt, As + kt * 256); GLDS16(wsrc + 16 * kt, Ws + kt * 256); }
+    // the epilogue's operands under the slabs' flight (ordinary loads: everything is waited for below)
     const int col = n0 + li;
     const float bias = p.bias ? p.bias[col] : 0.f;
     const int flags = p.flags;
@@ -765,38 +758,14 @@ __global__ __launch_bounds__(64) void gemm_rows_spread_kernel(GemmArgs p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    auto request = [&](int ps) {         // pass ps: its (up to) 8 slab pairs into buffer ps & 1
-        const int k0 = ps * RSP_PASS, k1 = min(k0 + RSP_PASS, nk);
-        for (int kt = k0; kt < k1; ++kt) {
-            GLDS16(asrc + 16 * kt, As[ps & 1] + (kt - k0) * 256);
-            GLDS16(wsrc + 16 * kt, Ws[ps & 1] + (kt - k0) * 256);
-        }
-    };
-    request(0);
-    if (np > 1) request(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     f32x4a acc = f32x4a{0.f, 0.f, 0.f, 0.f};
-    for (int ps = 0; ps < np; ++ps) {
-        // pass ps has landed: everything but the (complete, 16-request) pass behind it -- or everything
-        __builtin_amdgcn_sched_barrier(0);
-        if (ps + 1 < np && min(nk - (ps + 1) * RSP_PASS, RSP_PASS) == RSP_PASS)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const int k0 = ps * RSP_PASS, k1 = min(k0 + RSP_PASS, nk);
-        for (int kt = k0; kt < k1; ++kt) {
-            const f32x4a a = *reinterpret_cast<const f32x4a*>(As[ps & 1] + (kt - k0) * 256 + rdo);
-            const f32x4a b = *reinterpret_cast<const f32x4a*>(Ws[ps & 1] + (kt - k0) * 256 + rdo);
+    for (int kt = 0; kt < nk; ++kt) {
+        const f32x4a a = *reinterpret_cast<const f32x4a*>(As + kt * 256 + rdo);
+        const f32x4a b = *reinterpret_cast<const f32x4a*>(Ws + kt * 256 + rdo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-        }
-        if (ps + 2 < np) {              // this buffer's next pass: only once every read of it has returned
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            request(ps + 2);
-        }
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
     }
     // accumulator r of lane (li, lg) = row 4 lg + r, column n0 + li
 #pragma unroll
@@ -1040,8 +1009,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                 return launch_gemm(t, s);
             }
         }
-        if (small_ok && !(a.flags & EPI_LN) && a.K <= 1024 && (a.M + 15) / 16 <= RSP_MAX_GROUPS &&
-            (a.M + 15) / 16 * (a.N / 16) <= RSP_MAX_TILES && !(a.flags & GEMM_NO_SPREAD)) {
+        if (small_ok && !(a.flags & EPI_LN) && a.K <= 256 && (a.M + 15) / 16 <= RSP_MAX_GROUPS && !(a.flags & GEMM_NO_SPREAD)) {
             // a handful of row groups, no LayerNorm epilogue: one wave per 16 x 16 output tile (bit-identical; see the kernel)
             ProfScope ps(PK_GEMM_ROWS_SMALL, a.M, a.N, a.K, a.M_dev, s, a.m_off);
             hipLaunchKernelGGL(gemm_rows_spread_kernel, dim3((unsigned)(a.N / 16), (unsigned)((a.M + 15) / 16)), dim3(64), 0, s, a);
@@ -1087,7 +1055,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 }
 
 bool rows_chain_supported(int M) { return M > 0 && (M + 15) / 16 <= RS_MAX_WGS; }
-// launches of this many rows (K <= 1 024, no LayerNorm epilogue) take the spread form of the row GEMM
+// launches of this many rows (K <= 256, no LayerNorm epilogue) take the spread form of the row GEMM
 bool gemm_rows_spread_rows(int M) { return M > 0 && (M + 15) / 16 <= RSP_MAX_GROUPS; }
 
 int launch_rows_chain(const ChainArgs& a, hipStream_t s) {
