@@ -93,8 +93,8 @@ def csrc_hashes():
             for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".c"))}
 
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json")
-PMC_PREFILTER_FILES = ("r05_pmc_prefilter.json", "r04_pmc_prefilter.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")
+PMC_PREFILTER_FILES = ("r06_pmc_prefilter.json", "r05_pmc_prefilter.json", "r04_pmc_prefilter.json")
 
 
 def collect_profile():

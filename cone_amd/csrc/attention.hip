@@ -29,6 +29,10 @@
 //             consecutive keys 4 r .. 4 r + 3 and is skipped when they lie past the window's end.
 #include "common.h"
 
+#ifndef CONE_ATTN_NT
+#define CONE_ATTN_NT 0
+#endif
+
 namespace cone {
 
 constexpr float kQScale = 0.17677669529663687f;  // sqrt(1/32), applied to q after projection
@@ -188,8 +192,14 @@ __global__ __launch_bounds__(64 * NKT, (NKT > 12 ? 4 : 6)) void enc_attn16_kerne
             kv[it] = *reinterpret_cast<const f32x4m*>(rp + 256);
             vv[it] = *reinterpret_cast<const f32x4m*>(rp + 512);
         } else {
+#if CONE_ATTN_NT        // A/B (tools/ab_variants.sh): the packed q | k | v rows are read once -- non-temporal key / value loads:
+                        // 2.74 - 2.80 / 2.88 - 2.90 ms either way (tools/attn_bench.py), off
+            kv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4m*>(kb + (unsigned)row * sk + c4));
+            vv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4m*>(vb + (unsigned)row * sv + c4));
+#else
             kv[it] = *reinterpret_cast<const f32x4m*>(kb + (unsigned)row * sk + c4);
             vv[it] = *reinterpret_cast<const f32x4m*>(vb + (unsigned)row * sv + c4);
+#endif
         }
         if (MODE != ATTN_PACKED)
             kt_[it] = *reinterpret_cast<const f32x4m*>(prow(row) + 256u + c4);

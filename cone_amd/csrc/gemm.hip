@@ -20,6 +20,10 @@
 #include "common.h"
 #include "rows_chain.h"
 
+#ifndef CONE_GEMM_NT_STORE
+#define CONE_GEMM_NT_STORE 0
+#endif
+
 namespace cone {
 
 constexpr int BK = 32;
@@ -591,7 +595,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows16_kernel(GemmArgs p) {
                 }
                 if (8 * g + 4 * hf + k < rows_here) {
                     const size_t m = (size_t)(mrow0 + 8 * g + 4 * hf + k);
+#if CONE_GEMM_NT_STORE      // A/B (tools/ab_variants.sh): the output rows as non-temporal stores (1 KiB contiguous per wave):
+                            // 6.48 -> 6.42 ms on the 2 M x 768 x 256 shape (1 %), off
+                    __builtin_nontemporal_store(f32x4a{x.x, x.y, x.z, x.w}, reinterpret_cast<f32x4a*>(p.C + m * p.ldc + n0 + c4));
+#else
                     *reinterpret_cast<float4*>(p.C + m * p.ldc + n0 + c4) = x;
+#endif
                     if (p.C2) {
                         const float4 ad = *reinterpret_cast<const float4*>(p.ADD + m * p.ldc + n0 + c4);
                         x.x += ad.x; x.y += ad.y; x.z += ad.z; x.w += ad.w;

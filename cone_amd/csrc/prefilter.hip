@@ -17,8 +17,10 @@ namespace cone {
 // The clip rows are read exactly once per launch: the stream's loads are NON-TEMPORAL (global_load_dwordx4 ... nt).  Measured
 // on one box (tools/ab_variants.sh prefilter.hip, the 12.7 GB MAD-scale video, 1 query): 2.11 ms = 6.0 TB/s with ordinary loads,
 // 1.89 - 1.96 ms = 6.5 - 6.7 TB/s with nt (0.75 -> 0.81 - 0.84 of the 8 TB/s peak): lines that will not be read again no longer
-// displace each other through the L2 / Infinity Cache.  CONE_PF_NT = 0 (the streaming kernels) / CONE_PF_NT_MQ = 0 (the
-// matrix-core kernels for >= 8 queries) restore ordinary loads for an A/B.
+// displace each other through the L2 / Infinity Cache.  CONE_PF_NT = 0 restores ordinary loads for an A/B.  The matrix-core
+// kernels for >= 8 queries (CONE_PF_NT_MQ) keep ordinary loads: there a lane-row's 128-B line is fetched by two consecutive
+// instructions (64 B each: the MFMA operand layout), and with nt the second half loses its L1 hit -- measured 8 queries
+// 2.38 -> 2.45 ms, the three-piece bf16 form 3.42 -> 3.70 ms, 64 queries unchanged.
 #ifndef CONE_PF_NT
 #define CONE_PF_NT 1
 #endif

@@ -1,5 +1,5 @@
 set -u
-tag=r05; out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
+tag=${1:-r06}; out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
 rm -rf $out/pmc_fetch_pf $out/pmc_write_pf $out/pmc_mfma_pf
 P="python3 tools/prefilter_bench.py --queries 1,64 --steps 3 --both"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_pf -o f -- $P > $out/pmc_fetch_pf.log 2>&1
