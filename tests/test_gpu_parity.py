@@ -820,6 +820,28 @@ def test_prefilter_batched_equals_per_video_path():
             assert (idx[qi, k:] == -1).all()
 
 
+@pytest.mark.parametrize("ctx_l,dv,W", [(4_001, 512, 125), (901, 256, 90), (37, 768, 90), (3_003, 1024, 7)])
+def test_prefilter_scores_do_not_depend_on_the_query_batch(ctx_l, dv, W):
+    """Up to 7 queries over one video run the streaming kernel with 1, 2 or 4 query vectors in registers (and 3 / 5 / 6 / 7 as
+    several launches): a query's frame and window scores are the same bits whatever it is batched with -- the dot product's fma
+    chain is pinned (pf_dot4: left to the compiler's contraction the 2- and 4-query instantiations chose another pairing than
+    the 1-query one, 1 ulp apart), and the multi-value butterfly (wave_sum_multi) adds the same lane pairs as wave_sum."""
+    from cone_amd import ops
+    dev = _gpu()
+    g = torch.Generator().manual_seed(ctx_l + dv)
+    vid = ops.l2_normalize(torch.randn(ctx_l, dv, generator=g).to(dev), 0.0)
+    txt = ops.l2_normalize(torch.randn(7, dv, generator=g).to(dev), 0.0)
+    fs1, ws1 = zip(*[ops.prefilter_scores(vid, txt[i:i + 1].contiguous(), W) for i in range(7)])
+    for nq in (2, 3, 4, 5, 7):
+        fs, ws = ops.prefilter_scores(vid, txt[:nq].contiguous(), W)
+        _, ws_only = ops.prefilter_scores(vid, txt[:nq].contiguous(), W, frame_scores=False)
+        for i in range(nq):
+            assert torch.equal(fs[i], fs1[i][0]) and torch.equal(ws[i], ws1[i][0]) and torch.equal(ws_only[i], ws1[i][0]), (nq, i)
+    # and the scores themselves: fp64 on the host
+    ref = (vid.double().cpu() @ txt[:1].double().cpu().T)[:, 0]
+    assert float((fs1[0][0].double().cpu() - ref).abs().max()) < 1e-6
+
+
 def test_topk_ties_are_stable():
     from cone_amd import ops
     dev = _gpu()

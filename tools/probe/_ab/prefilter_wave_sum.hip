@@ -44,57 +44,14 @@ __device__ __forceinline__ float4 pf_stream_ld(const float4* p) {
 // reference needs it for nothing but this max (cone/inference.py:284-295).
 //   WPH = 1: one wave per half-block, grid-stride (long videos: every wave streams contiguous 4-row groups of its blocks);
 //   WPH = 4: the four waves of a workgroup share one half-block and combine through LDS (short videos: 4x the waves).
-// <x, q> over one float4 of channels, the arithmetic PINNED: each pair sum is fma(first factors, second product), the two
-// pair sums are added -- what hipcc's contraction made of (x.x q.x + x.y q.y) + (x.z q.z + x.w q.w) in the streaming kernels
-// since round 1.  Left to -ffp-contract=fast the choice is the backend's, per kernel: the per-video kernel and the batched
-// one (frame_score_groups_kernel) must produce the same bits (test_prefilter_batched_equals_per_video_path).
-__device__ __forceinline__ float pf_dot4(const float4& x, const float4& q) {
-#pragma clang fp contract(off)
-    const float m1 = x.y * q.y, m3 = x.w * q.w;
-    const float p01 = __builtin_fmaf(x.x, q.x, m1);
-    const float p23 = __builtin_fmaf(x.z, q.z, m3);
-    return p01 + p23;
-}
-
-// Sum of N per-lane values over the 64 lanes at once: the totals of wave_sum() -- the same butterfly (lane l adds its
-// partner l ^ 32, then l ^ 16, ... l ^ 1: the same pairs, so the same bits) -- but a lane keeps only HALF of its values at
-// each of the first log2(N) steps (the partner keeps the other half), so N totals cost N - 1 + (6 - log2 N) shuffles
-// instead of 6 N.  The lane's result is the total of value index J(l) = the top log2(N) bits of l (bit 5 = the index's
-// top bit); the 64 / N lanes that share those bits all hold it.  (Recursion on the array size: every index is static.)
-template <int N, int O = 32>
-__device__ __forceinline__ float wave_sum_multi(const float (&v)[N], int lane) {
-    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "a power of two");
-    if constexpr (N == 1) {
-        float x = v[0];
-#pragma unroll
-        for (int o = O; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-        return x;
-    } else {
-        constexpr int H = N / 2;
-        const bool up = (lane & O) != 0;                // this lane keeps the upper half of its values, its partner the lower
-        float w[H];
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const float send = up ? v[j] : v[j + H];
-            const float keep = up ? v[j + H] : v[j];
-            w[j] = keep + __shfl_xor(send, O, 64);
-        }
-        return wave_sum_multi<H, O / 2>(w, lane);
-    }
-}
-
 template <int VPL /* float4 per lane per row: dv = 256*VPL */, int QG, int RPW, int WPH>
 __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restrict__ vid, int64_t ctx_l, int S, int64_t nh,
                                                           const float* __restrict__ txt, int q0, int nq,
                                                           float* __restrict__ fs, float* __restrict__ hm,
                                                           float* __restrict__ fr) {
-    constexpr int DV = 256 * VPL, UPB = 4 / WPH, NV = RPW * QG;
-    static_assert((RPW & (RPW - 1)) == 0 && (QG & (QG - 1)) == 0 && NV <= 64, "row / query counts: powers of two");
+    constexpr int DV = 256 * VPL, UPB = 4 / WPH;
     __shared__ float red[4][QG];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % WPH;
-    // the (row, query) pair whose total this lane ends up with (wave_sum_multi: value index r * QG + g = the lane's top bits)
-    const int my_j = lane / (64 / NV), my_r = my_j / QG, my_g = my_j % QG;
-    const bool writer = (lane & (64 / NV - 1)) == 0;                   // one of the 64 / NV lanes that hold the same total
     float4 q[QG][VPL];
 #pragma unroll
     for (int g = 0; g < QG; ++g)
@@ -107,7 +64,9 @@ __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restric
         const int64_t r_lo = h * S;
         const int n = (int)min((int64_t)S, ctx_l - r_lo);            // frames of this half-block
         const float* base = vid + r_lo * DV;
-        float m = -INFINITY;                                         // running max of this lane's (row slot, query)
+        float m[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) m[g] = -INFINITY;
         for (int j0 = sub * RPW; j0 < n; j0 += WPH * RPW) {
             float4 x[RPW][VPL];
 #pragma unroll
@@ -117,33 +76,36 @@ __global__ __launch_bounds__(256) void frame_score_kernel(const float* __restric
                 for (int v = 0; v < VPL; ++v)
                     x[r][v] = pf_stream_ld(reinterpret_cast<const float4*>(base + (size_t)row * DV) + lane + 64 * v);
             }
-            float part[NV];
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
                     float s = 0.f;
 #pragma unroll
-                    for (int v = 0; v < VPL; ++v) s += pf_dot4(x[r][v], q[g][v]);
-                    part[r * QG + g] = s;
+                    for (int v = 0; v < VPL; ++v)
+                        s += (x[r][v].x * q[g][v].x + x[r][v].y * q[g][v].y) +
+                             (x[r][v].z * q[g][v].z + x[r][v].w * q[g][v].w);
+                    s = wave_sum(s);
+                    if (j0 + r < n) {
+                        m[g] = fmaxf(m[g], s);
+                        if (lane == 0 && q0 + g < nq) {
+                            if (fs) fs[(size_t)(q0 + g) * ctx_l + r_lo + j0 + r] = s;
+                            if (r == 0 && j0 == 0) fr[(size_t)(q0 + g) * nh + h] = s;      // the block's first frame
+                        }
+                    }
                 }
-            const float s = wave_sum_multi<NV>(part, lane);            // = wave_sum of (row j0 + my_r, query q0 + my_g)
-            if (j0 + my_r < n) {
-                m = fmaxf(m, s);
-                if (writer && q0 + my_g < nq) {
-                    if (fs) fs[(size_t)(q0 + my_g) * ctx_l + r_lo + j0 + my_r] = s;
-                    if (my_r == 0 && j0 == 0) fr[(size_t)(q0 + my_g) * nh + h] = s;      // the block's first frame
-                }
-            }
         }
-        // over the RPW row slots of a query: the lanes that differ in the index's top log2(RPW) bits (lane bits 5, 4, ...)
-#pragma unroll
-        for (int o = 32; o > 32 / RPW; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        const bool out_lane = writer && my_r == 0;                     // lane g * (64 / NV): query q0 + g
         if (WPH == 1) {
-            if (out_lane && q0 + my_g < nq) hm[(size_t)(q0 + my_g) * nh + h] = m;
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g)
+                    if (q0 + g < nq) hm[(size_t)(q0 + g) * nh + h] = m[g];
+            }
         } else {                                    // h is uniform over the workgroup: the barriers are too
-            if (out_lane) red[wave][my_g] = m;
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) red[wave][g] = m[g];
+            }
             __syncthreads();
             if (wave == 0 && lane < QG && q0 + lane < nq)
                 hm[(size_t)(q0 + lane) * nh + h] = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
@@ -840,7 +802,8 @@ __global__ __launch_bounds__(256) void frame_score_groups_kernel(const float* __
             for (int j = 0; j < 4; ++j) {
                 float s = 0.f;
 #pragma unroll
-                for (int v = 0; v < VPL; ++v) s += pf_dot4(x[r][v], q[j][v]);
+                for (int v = 0; v < VPL; ++v)
+                    s += (x[r][v].x * q[j][v].x + x[r][v].y * q[j][v].y) + (x[r][v].z * q[j][v].z + x[r][v].w * q[j][v].w);
                 s = wave_sum(s);
                 if (lane == 0 && r0 + r < ctx_l && qi[j] >= 0) fs[q_fs_off[qi[j]] + r0 + r] = s;
             }
