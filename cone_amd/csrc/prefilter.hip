@@ -24,6 +24,9 @@ namespace cone {
 #ifndef CONE_PF_NT
 #define CONE_PF_NT 1
 #endif
+#ifndef CONE_PF_MQ_MIN
+#define CONE_PF_MQ_MIN 5            // queries per video from which the matrix-core kernel takes over (A/B: 8 = round 5)
+#endif
 #ifndef CONE_PF_NT_MQ
 #define CONE_PF_NT_MQ 0
 #endif
@@ -532,10 +535,11 @@ __global__ __launch_bounds__(MQ_NT, 3) void frame_score_mq_kernel(const float* _
 static int prefilter_grid_setup(int* n_cu_out) {
     static DeviceOnce once;     // the many-query kernel's 128 KiB of LDS: opt-in once per device; its grid = one workgroup per CU
     const hipError_t rc = device_once(once, [] {
-        const void* fns[4] = {(const void*)frame_score_mq_kernel<4, false>, (const void*)frame_score_mq_kernel<4, true>,
-                              (const void*)frame_score_mq_kernel<2, false>, (const void*)frame_score_mq_kernel<2, true>};
+        const void* fns[6] = {(const void*)frame_score_mq_kernel<4, false>, (const void*)frame_score_mq_kernel<4, true>,
+                              (const void*)frame_score_mq_kernel<2, false>, (const void*)frame_score_mq_kernel<2, true>,
+                              (const void*)frame_score_mq_kernel<1, false>, (const void*)frame_score_mq_kernel<1, true>};
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        for (int i = 0; i < 6 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         return e;
     }, n_cu_out);
@@ -552,12 +556,14 @@ static int launch_frame_scores_mq(const float* vid, int64_t ctx_l, int dv, int S
     if (blocks > n_cu) blocks = n_cu;                                  // one workgroup per CU, grid-stride over half-blocks
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
-        const bool wide = qpl == 64 && rem > 32;                           // 4 query tiles, else 2
+        const bool wide = qpl == 64 && rem > 32;                           // 4 query tiles, else 2, or 1 for <= 16 queries:
+        const bool one = rem <= 16;                                        // half the matrix work of two, the stream is HBM-bound
         ProfScope ps(PK_FRAME_SCORE, ctx_l, dv, rem < (wide ? 64 : 32) ? rem : (wide ? 64 : 32), nullptr, s);
 #define CONE_MQ_LAUNCH(QT, FS, QN)                                                                                      \
     hipLaunchKernelGGL((frame_score_mq_kernel<QT, FS>), dim3((unsigned)blocks), dim3(MQ_NT), (size_t)(QN) * dv * 4, s, vid, \
                        ctx_l, dv, S, nh, txt, q0, nq, fs, hm, fr)
         if (wide) { if (fs) CONE_MQ_LAUNCH(4, true, 64); else CONE_MQ_LAUNCH(4, false, 64); }
+        else if (one) { if (fs) CONE_MQ_LAUNCH(1, true, 16); else CONE_MQ_LAUNCH(1, false, 16); }
         else { if (fs) CONE_MQ_LAUNCH(2, true, 32); else CONE_MQ_LAUNCH(2, false, 32); }
 #undef CONE_MQ_LAUNCH
         CONE_LAUNCH_CHECK();
@@ -832,8 +838,10 @@ __global__ __launch_bounds__(256) void frame_score_groups_kernel(const float* __
         for (int r = 0; r < RPW; ++r) {
             const int row = min(r0 + r, ctx_l - 1);
 #pragma unroll
-            for (int v = 0; v < VPL; ++v) x[r][v] = pf_stream_ld(reinterpret_cast<const float4*>(vid + (size_t)row * DV) + lane + 64 * v);
+            // (ordinary loads: the other groups of this video read the same rows again -- a split's arena sits in the caches)
+            for (int v = 0; v < VPL; ++v) x[r][v] = reinterpret_cast<const float4*>(vid + (size_t)row * DV)[lane + 64 * v];
         }
+        float part[RPW * 4];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
@@ -841,9 +849,15 @@ __global__ __launch_bounds__(256) void frame_score_groups_kernel(const float* __
                 float s = 0.f;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) s += pf_dot4(x[r][v], q[j][v]);
-                s = wave_sum(s);
-                if (lane == 0 && r0 + r < ctx_l && qi[j] >= 0) fs[q_fs_off[qi[j]] + r0 + r] = s;
+                part[r * 4 + j] = s;
             }
+        // the 16 sums by one butterfly (wave_sum_multi): lane l ends up with the total of (row l / 16, query (l / 4) % 4)
+        const float s = wave_sum_multi<RPW * 4>(part, lane);
+        const int my_r = lane >> 4;
+        int my_qi = qi[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) my_qi = ((lane >> 2) & 3) == j ? qi[j] : my_qi;
+        if ((lane & 3) == 0 && r0 + my_r < ctx_l && my_qi >= 0) fs[q_fs_off[my_qi] + r0 + my_r] = s;
     }
 }
 
@@ -951,7 +965,9 @@ static int launch_frame_scores(const float* vid, int64_t ctx_l, int S, int64_t n
     if (blocks > 256 * CONE_PF_WGS_PER_CU) blocks = 256 * CONE_PF_WGS_PER_CU;
     for (int q0 = 0; q0 < nq;) {
         const int rem = nq - q0;
-        const int qg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+        // 3 remaining queries ride a 4-query launch (the fourth slot repeats the last query and stores nothing): one pass over
+        // the video instead of two; a query's bits do not depend on the launch it shares (pf_dot4, wave_sum_multi)
+        const int qg = rem >= 3 ? 4 : (rem >= 2 ? 2 : 1);
         ProfScope ps(PK_FRAME_SCORE, ctx_l, 256 * VPL, qg, nullptr, s);
 #define CONE_FS_LAUNCH(QG, WPH)                                                                                        \
     hipLaunchKernelGGL((frame_score_kernel<VPL, QG, RPW, WPH>), dim3((unsigned)blocks), dim3(256), 0, s, vid, ctx_l, S, \
@@ -1006,9 +1022,10 @@ static int prefilter_scores_impl(const float* vid, int64_t ctx_l, int dv, const 
         CONE_REQUIRE(ws_bytes >= need + cone::frame_scores_split_image_bytes(dv), "prefilter (split): workspace too small (%zu < %zu)",
                      ws_bytes, need + cone::frame_scores_split_image_bytes(dv));
         rc = cone::launch_frame_scores_mq3(vid, ctx_l, dv, S, nh, txt, nq, hm, fr, (char*)ws + need, s);
-    } else if (nq >= 8) {
+    } else if (nq >= CONE_PF_MQ_MIN) {
         // Many queries over one video: the clip arena is read once for up to 64 queries by the fp32-MFMA kernel
-        // (BASELINE configs 3 / 5) instead of nq / 4 VALU passes over the features.
+        // (BASELINE configs 3 / 5) instead of nq / 4 VALU passes over the features.  From 5 queries on: they would be two
+        // passes of the streaming kernel (3.9 ms on the 12.7 GB video), one 16-query tile of this one is a single pass.
         rc = cone::launch_frame_scores_mq(vid, ctx_l, dv, S, nh, txt, nq, frame_scores, hm, fr, s);
     } else {
         switch (dv / 256) {

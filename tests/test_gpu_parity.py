@@ -822,8 +822,8 @@ def test_prefilter_batched_equals_per_video_path():
 
 @pytest.mark.parametrize("ctx_l,dv,W", [(4_001, 512, 125), (901, 256, 90), (37, 768, 90), (3_003, 1024, 7)])
 def test_prefilter_scores_do_not_depend_on_the_query_batch(ctx_l, dv, W):
-    """Up to 7 queries over one video run the streaming kernel with 1, 2 or 4 query vectors in registers (and 3 / 5 / 6 / 7 as
-    several launches): a query's frame and window scores are the same bits whatever it is batched with -- the dot product's fma
+    """Up to 4 queries over one video run the streaming kernel with 1, 2 or 4 query vectors in registers (3 ride a 4-query
+    launch): a query's frame and window scores are the same bits whatever it is batched with -- the dot product's fma
     chain is pinned (pf_dot4: left to the compiler's contraction the 2- and 4-query instantiations chose another pairing than
     the 1-query one, 1 ulp apart), and the multi-value butterfly (wave_sum_multi) adds the same lane pairs as wave_sum."""
     from cone_amd import ops
@@ -836,7 +836,11 @@ def test_prefilter_scores_do_not_depend_on_the_query_batch(ctx_l, dv, W):
         fs, ws = ops.prefilter_scores(vid, txt[:nq].contiguous(), W)
         _, ws_only = ops.prefilter_scores(vid, txt[:nq].contiguous(), W, frame_scores=False)
         for i in range(nq):
-            assert torch.equal(fs[i], fs1[i][0]) and torch.equal(ws[i], ws1[i][0]) and torch.equal(ws_only[i], ws1[i][0]), (nq, i)
+            if nq <= 4:
+                assert torch.equal(fs[i], fs1[i][0]) and torch.equal(ws[i], ws1[i][0]) and torch.equal(ws_only[i], ws1[i][0]), (nq, i)
+            else:       # from 5 queries on: one 16-query tile of the matrix-core kernel (another summation order, ~1e-7)
+                assert float((fs[i] - fs1[i][0]).abs().max()) < 1e-6 and float((ws[i] - ws1[i][0]).abs().max()) < 1e-6
+                assert torch.equal(ws_only[i], ws[i]), (nq, i)
     # and the scores themselves: fp64 on the host
     ref = (vid.double().cpu() @ txt[:1].double().cpu().T)[:, 0]
     assert float((fs1[0][0].double().cpu() - ref).abs().max()) < 1e-6
