@@ -26,7 +26,11 @@ LOCALIZER_OPT = dict(MODEL_DEFAULTS, v_motion_feat_dim=256, v_appear_feat_dim=25
 
 
 class CONELocalizator:
-    def __init__(self, load_checkpoint_path=None, device="cuda", state_dict=None, **overrides):
+    def __init__(self, load_checkpoint_path=None, device="cuda", state_dict=None, hip_graph=False, **overrides):
+        """``hip_graph`` (cone_amd extension, opt-in): a call at a (video length, query length) shape seen before replays the
+        whole launch sequence as ONE hipGraph launch -- the inputs are copied into the capture's own buffers first, the kept
+        moments are read back as usual; same kernels, same order, same bits as the eager call."""
+        self.hip_graph = bool(hip_graph)
         self.args = SimpleNamespace(**dict(LOCALIZER_OPT, **overrides))
         self.localizator, _ = build_model(self.args)
         if state_dict is None:
@@ -65,19 +69,13 @@ class CONELocalizator:
         return c
 
     @torch.no_grad()
-    def predict_moment(self, video_feats, text_feats):
-        """run_on_video/cone_localizator.py:121-221 on the eval driver's kernels, enqueued without a host round trip until
-        the kept moments are read back: window ranks stay on the device (the window table kernel turns them into row
-        ranges), first-layer q|k|v once per clip / token, position tables, fused layer tails."""
-        a, m, dev = self.args, self.localizator, self.device
-        text_token_feats, text_cls_feat = text_feats
-        if text_token_feats.shape[0] > a.max_q_l:
-            raise ValueError(f"query has {text_token_feats.shape[0]} tokens > max_q_l={a.max_q_l}")
-        vid = ops.l2_normalize(video_feats.to(dev, torch.float32), 1e-5, clamp=True)          # :129
-        tok = ops.l2_normalize(text_token_feats.to(dev, torch.float32), 1e-5, clamp=True)     # :133
-        cls = text_cls_feat.to(dev, torch.float32).reshape(1, -1).contiguous()
-        c = self._const(int(vid.shape[0]), int(tok.shape[0]))
+    def _enqueue(self, video_feats, text_token_feats, text_cls_feat, c):
+        """The device half of ``predict_moment``: everything up to the kept rows, no host round trip."""
+        a, m = self.args, self.localizator
         K, W = c["K"], a.max_v_l
+        vid = ops.l2_normalize(video_feats, 1e-5, clamp=True)                                  # :129
+        tok = ops.l2_normalize(text_token_feats, 1e-5, clamp=True)                             # :133
+        cls = text_cls_feat.reshape(1, -1)
         adapted = m.adapter_norm(vid, renorm=False)                                           # :135-138
         _, ws = ops.prefilter_scores(adapted, cls, W, frame_scores=False)                     # :83-100 (stable tie order)
         widx, _ = ops.topk_windows(ws, K)
@@ -92,5 +90,42 @@ class CONELocalizator:
         rows = ops.compose_rows(out["pred_logits"], out["pred_spans"], match, c["full_w"], wt["video_start"], a.clip_length,
                                 sort=False)                                                   # :191: scaled by max_v_l, no sort
         kept, n, _ = ops.fuse_nms(rows.reshape(1, K * m.num_queries, 4), c["n_valid"], 0.5, 100, 5)      # :200-219
+        return kept, n
+
+    def _replay(self, vid, tok, cls, c):
+        """``hip_graph``: the launch sequence of this (video length, query length) shape, captured once behind an eager warm-up
+        and replayed on the capture's own input buffers (the caller's tensors are copied in, stream-ordered)."""
+        g = c.get("graph")
+        if g is None:
+            bufs = (torch.empty_like(vid), torch.empty_like(tok), torch.empty_like(cls))
+            for b, x in zip(bufs, (vid, tok, cls)):
+                b.copy_(x)
+            self._enqueue(*bufs, c)                     # warm-up: workspace, kernel attributes
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._enqueue(*bufs, c)
+            # what the captured launches point at must outlive the graph: the capture's workspace (the model's grow-only
+            # scratch may be replaced by a larger one later)
+            g = c["graph"] = (graph, bufs, out, self.localizator._ws.buf)
+        for b, x in zip(g[1], (vid, tok, cls)):
+            b.copy_(x, non_blocking=True)
+        g[0].replay()
+        return g[2]
+
+    @torch.no_grad()
+    def predict_moment(self, video_feats, text_feats):
+        """run_on_video/cone_localizator.py:121-221 on the eval driver's kernels, enqueued without a host round trip until
+        the kept moments are read back: window ranks stay on the device (the window table kernel turns them into row
+        ranges), first-layer q|k|v once per clip / token, position tables, fused layer tails."""
+        a, dev = self.args, self.device
+        text_token_feats, text_cls_feat = text_feats
+        if text_token_feats.shape[0] > a.max_q_l:
+            raise ValueError(f"query has {text_token_feats.shape[0]} tokens > max_q_l={a.max_q_l}")
+        vid = video_feats.to(dev, torch.float32).contiguous()
+        tok = text_token_feats.to(dev, torch.float32).contiguous()
+        cls = text_cls_feat.to(dev, torch.float32).reshape(-1).contiguous()
+        c = self._const(int(vid.shape[0]), int(tok.shape[0]))
+        kept, n = self._replay(vid, tok, cls, c) if self.hip_graph else self._enqueue(vid, tok, cls, c)
         kept, n = kept[0, 0].cpu(), int(n[0, 0])        # the call's one read-back
         return [[r[0], r[1], r[4]] for r in kept[:n].tolist()]

@@ -1861,6 +1861,27 @@ def test_localizer_matches_reference_golden(golden_dir):
         assert np.abs(got[:, 2] - ref[:, 2]).max() < 2e-3
 
 
+def test_localizer_hip_graph_replay_equals_eager():
+    """CONELocalizator(hip_graph=True): a (video length, query length) shape seen before is ONE graph launch on the capture's own
+    input buffers -- the same moments as the eager call, bit for bit, for new inputs of a captured shape (device or host
+    tensors), for a second shape, and back."""
+    from cone_amd.localizator import CONELocalizator
+    opt = make_opt("ego4d")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(opt, 5).items()}
+    eager, graph = CONELocalizator(state_dict=sd), CONELocalizator(state_dict=sd, hip_graph=True)
+    g = torch.Generator().manual_seed(17)
+    shapes = [(900, 12), (900, 12), (333, 7), (900, 12), (44, 20), (333, 7)]
+    for i, (ctx_l, lq) in enumerate(shapes):
+        vid = torch.randn(ctx_l, 256, generator=g) * 2
+        tok, cls = torch.randn(lq, 768, generator=g), torch.randn(256, generator=g)
+        if i % 2:       # resident inputs
+            vid, tok, cls = vid.cuda(), tok.cuda(), cls.cuda()
+        want = eager.predict_moment(vid, (tok, cls))
+        got = graph.predict_moment(vid, (tok, cls))
+        assert got == want and len(want) >= 1, (i, ctx_l, lq)
+    assert sum("graph" in c for c in graph._consts.values()) == 3
+
+
 # ------------------------------------------------------------------------------- the reference's data sources
 def _checkpoint_dir(tmp_path, saved, seed):
     sdn = synth.make_state_dict(saved, seed)
