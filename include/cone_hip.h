@@ -125,7 +125,10 @@ int cone_l2_normalize_rows(const float* x, int64_t n_rows, int dim, float eps, i
  * The window max is fused into the frame-score stream (a running max per half window of S frames; each frame belongs
  * to two windows), so the (nq,ctx_l) frame-score matrix -- which the reference computes only to take this max -- is
  * OPTIONAL: frame_scores may be NULL (nothing of that size is written), or receives the scores as before.
- * ws >= cone_prefilter_scores_workspace(ctx_l, nq, W) bytes (two floats per query and half window). */
+ * ws >= cone_prefilter_scores_workspace(ctx_l, nq, W) bytes (two floats per query and half window).
+ * Forms (chosen by nq): 1 - 4 queries stream the clip rows once with non-temporal loads, the query vectors in registers (a
+ * query's bits do not depend on the others of the launch); 5 or more run fp32-MFMA tiles of 16 / 32 / 64 queries per pass
+ * (another summation order: ~1e-7 relative). */
 int64_t cone_num_windows(int64_t ctx_l, int W);
 size_t cone_prefilter_scores_workspace(int64_t ctx_l, int nq, int W);
 int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* txt, int nq,
@@ -135,7 +138,8 @@ int cone_prefilter_scores(const float* vid, int64_t ctx_l, int dv, const float* 
 /* OPT-IN form of cone_prefilter_scores without the frame-score matrix: 8 or more queries over one video run on the bf16
  * matrix cores, every fp32 product as six partial products of three-piece bf16 operands with fp32 accumulation -- the
  * accuracy of the exact-fp32 MFMA chain (tools/probe/split_bf16_probe.hip) at a rate that leaves the 64-query stream
- * HBM-bound instead of matrix-pipe-bound.  Fewer than 8 queries take cone_prefilter_scores' streaming kernel.
+ * HBM-bound instead of matrix-pipe-bound.  Fewer than 8 queries take cone_prefilter_scores' own kernels (1 - 4: the streaming
+ * kernel; 5 - 7: one 16-query tile of the exact-fp32 matrix-core kernel).
  * ws >= cone_prefilter_scores_split_workspace(...) bytes (the score planes + the split query image).  The default path
  * (cone_prefilter_scores, cone/inference.py's drop-in) stays exact fp32. */
 size_t cone_prefilter_scores_split_workspace(int64_t ctx_l, int nq, int W, int dv);
