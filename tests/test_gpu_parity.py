@@ -860,6 +860,33 @@ def test_topk_ties_are_stable():
         assert idx[q].cpu().tolist() == torch.sort(big[q], descending=True, stable=True)[1][:40].tolist()
 
 
+def test_rank_list_with_nan_features_is_a_permutation():
+    """NaN clip rows (an all-zero adapted row: cone/inference.py:258 divides by an un-eps'd norm) must not leave rank slots
+    unwritten: the fused window max skips NaN frame scores (a window of NaN frames only scores -inf), and the counting rank of a
+    short row is a total order even for NaN inputs, so every slot of every query holds a window index (or the -1 padding) and
+    the list is the stable descending order of the window scores the same call returns."""
+    from cone_amd import inference as inf
+    from cone_amd import ops
+    dev = _gpu()
+    opt = make_opt("ego4d", topk_window=30)
+    ann, vf, qf = synth.make_dataset(opt, 9, 2, seed=12, ctx_range=(400, 700))
+    store = inf.FeatureStore(opt, ann, vf, qf)
+    ctx = ops.l2_normalize(store.vid_raw, 1e-5)
+    ctx[37:41] = float("nan")                       # a few NaN frames inside windows that also hold numbers
+    ctx[150:330] = float("nan")                     # and 180 of them in a row: whole windows of NaN frames
+    cls = ops.l2_normalize(store.cls_raw, 1e-5)
+    plan = store.prefilter_plan()
+    idx, fs, ws = ops.prefilter_batched(ctx, cls, plan, opt.max_v_l, opt.topk_window)
+    assert not torch.isnan(ws).any() and torch.isinf(ws).any()
+    S = opt.max_v_l // 2
+    for qi in range(len(ann)):
+        nw = -(-store.ctx_l[int(store.q_vid[qi])] // S) + 1
+        w0 = int(plan["q_win_off"][qi])
+        want = torch.sort(ws[w0:w0 + nw].cpu(), descending=True, stable=True)[1].tolist()
+        got = idx[qi].cpu().tolist()
+        assert got[:nw] == want and got[nw:] == [-1] * (opt.topk_window - nw), qi
+
+
 # ------------------------------------------------------------------------------- stage C
 def test_stage_c_matches_reference_golden_bit_exact(golden_dir):
     from cone_amd import ops
