@@ -886,9 +886,15 @@ def _graph_replay(model, store: FeatureStore, opt):
     Any mix of video lengths: the shape of the window list is host metadata (``Selection``), so there is no data-dependent
     size anywhere."""
     cache = store.__dict__.setdefault("_graphs", {})
-    key = _graph_key(model, opt)
+    # the captured launches point INTO the arenas: refilling them in place keeps a capture valid, assigning new tensors to
+    # vid_raw / mot_raw / tok_raw / cls_raw does not -- such a store is captured again (as FeatureStore.view rebuilds its views)
+    arenas = (store.vid_raw.data_ptr(), store.tok_raw.data_ptr(), store.cls_raw.data_ptr(),
+              0 if store.mot_raw is None else store.mot_raw.data_ptr())
+    key = _graph_key(model, opt) + arenas
     hit = cache.get(key)
     if hit is None:
+        if len(cache) > 8:
+            cache.clear()
         device_pipeline(model, store, opt)              # warm-up: workspace, kernel attributes
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

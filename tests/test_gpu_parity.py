@@ -2747,6 +2747,16 @@ def test_hip_graph_replay_equals_eager_pipeline():
     got2, _ = inf.predict_split(model, store, gopt)
     strip = lambda lists: [[{k: v for k, v in it.items() if k == "predicted_times"} for it in l] for l in lists]
     assert strip(got2) == strip(ref2)
+    # NEW tensors assigned to the arenas (not refilled in place): the capture points at the old ones -- captured again, never
+    # replayed on stale pointers
+    ann3, vf3, qf3 = synth.make_dataset(opt, 3, 1, seed=9, ctx_range=(900, 901), lq_range=(12, 13))
+    third = inf.FeatureStore(opt, ann3, vf3, qf3)
+    ref3, _ = inf.predict_split(model, third, opt)
+    store.vid_raw, store.tok_raw, store.cls_raw = third.vid_raw.clone(), third.tok_raw.clone(), third.cls_raw.clone()
+    for _ in range(2):
+        got3, _ = inf.predict_split(model, store, gopt)
+        assert strip(got3) == strip(ref3)
+    assert len(store._graphs) == 2
     # a video of fewer than top-k windows captures too: the shape of the window list is host metadata (Selection), there is
     # no data-dependent size anywhere -- same lists as the eager run
     short = inf.FeatureStore(opt, *synth.make_dataset(opt, 2, 1, seed=7, ctx_range=(100, 101)))
