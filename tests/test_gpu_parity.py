@@ -1364,12 +1364,20 @@ def test_distributed_drivers_single_rank_equal_plain_pipeline():
     plain, _ = inf.predict_split(model, store, opt)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=_gpu())          # (bench.py's form: eager communicator)
     try:
+        import bench as B_
+        pf = B_.rccl_preflight(dist, 1, 0, 64, 5, "nccl")       # the step's message shape (fp64 rows + int32 counts) over RCCL
+        assert pf["ok"] and pf["backend"] == "nccl"
         for mode in ("window", "query"):
             got, info = par.predict_split_distributed(model, store, opt, mode=mode)
             assert got == plain, mode
             assert info["shard"] == (0, 11) and info["world"] == 1
+            # the async entry with steps in flight (the N > 1 headline's stepping): the collectives are stream-ordered
+            hs = [par.predict_split_distributed_async(model, store, opt, mode=mode, format_shard=True) for _ in range(3)]
+            assert all(h.result()[0] == plain for h in hs), mode
+        dist.barrier()
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 
