@@ -186,7 +186,8 @@ def test_fused_ffn_matches_float64(M, ff):
                                          (100_000, 256, 256, 1 | 2 | 4), (64, 256, 2048, 1), (300, 512, 1536, 2),
                                          (100, 768, 256, 2), (1000, 256, 256, 1 | 2), (1024, 768, 256, 0), (1025, 768, 256, 0),
                                          (20, 256, 768, 1), (100, 256, 512, 1 | 2), (333, 256, 1024, 0), (64, 768, 768, 2),
-                                         (16, 256, 160, 0), (1000, 256, 416, 1), (7, 512, 288, 2), (40, 256, 96, 1)])
+                                         (16, 256, 160, 0), (1000, 256, 416, 1), (7, 512, 288, 2), (40, 256, 96, 1),
+                                         (33_000, 768, 256, 0), (100_001, 768, 256, 1), (32_768, 768, 512, 0), (40_000, 768, 64, 0)])
 def test_row_gemm_small_m_form_is_bit_identical(M, N, K, flags):
     """gemm.hip: launches of at most 1 280 tiles of 16 x 256 take 16-row tiles spread over the CUs (gemm_rows_small_kernel)
     instead of one 128 x 256 tile per 128 rows, and the rows past the last full round of 128-row tiles (33 000 rows = 258
